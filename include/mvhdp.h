@@ -1,0 +1,164 @@
+/*
+ * mvhdp.h — C ABI of libmvhdp.so: the MI355X (gfx950) multi-view HDP
+ * collapsed-Gibbs sweep that replaces the iteration body of
+ * FastQMVWVParallelTopicModel.estimate() in hmetaxa/MVTopicModel.
+ *
+ * Reference aliases (under src/main/java/org/madgik/ of the reference):
+ *   PTM = MVTopicModel/FastQMVWVParallelTopicModel.java
+ *   WRK = MVTopicModel/FastQMVWVWorkerRunnable.java
+ *   UPD = MVTopicModel/FastQMVWVUpdaterRunnable.java
+ *   FT  = utils/FTree.java   QD = utils/FastQDelta.java
+ *   MTA = utils/MixTopicModelTopicAssignment.java
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every function returns
+ * 0 (MVHDP_OK) or a negative mvhdp_status; no exceptions cross the boundary;
+ * the caller owns every host buffer, the library copies.  A handle is bound to
+ * one HIP device and is not thread-safe (estimate() is single-threaded,
+ * PTM:1033).  The JNI stub that binds these entry points from Java is shown
+ * in INTEGRATION.md.
+ */
+#ifndef MVHDP_H
+#define MVHDP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVHDP_MAX_MODALITIES 8
+#define MVHDP_MAX_TOPICS     2048
+#define MVHDP_UNASSIGNED_TOPIC (-1)          /* PTM:63 */
+
+typedef enum {
+    MVHDP_OK = 0,
+    MVHDP_ERR_INVALID_ARG   = -1,
+    MVHDP_ERR_STATE         = -2,  /* call order violated (e.g. sweep before set_corpus) */
+    MVHDP_ERR_HIP           = -3,  /* HIP runtime failure, see mvhdp_last_error */
+    MVHDP_ERR_NO_DEVICE     = -4,  /* no gfx950 device: there is NO CPU fallback */
+    MVHDP_ERR_NEGATIVE_COUNT= -5,  /* a count went below zero (the reference only logs it, UPD:202-215) */
+    MVHDP_ERR_UNSUPPORTED   = -6
+} mvhdp_status;
+
+typedef struct mvhdp_ctx* mvhdp_handle;
+
+/* Shape of the model: replaces the ctor arguments PTM:183 + numTypes PTM:413. */
+typedef struct {
+    int32_t num_topics;                          /* K, PTM:193 */
+    int32_t num_modalities;                      /* M, PTM:189 */
+    int32_t num_types[MVHDP_MAX_MODALITIES];     /* V_m = alphabet[m].size(), PTM:413 */
+    int32_t device;                              /* HIP device ordinal */
+    int64_t doc_id_base;                         /* global id of local entity 0 (document shards, one per GPU) */
+    uint32_t flags;                              /* reserved, 0 */
+} mvhdp_config;
+
+/* Hyper-parameters the sampler reads: PTM:79-83,130-131,95. */
+typedef struct {
+    const double* alpha;                         /* [M][K+1], index K = new-topic weight PTM:196 */
+    double alpha_sum[MVHDP_MAX_MODALITIES];      /* PTM:80 */
+    double beta[MVHDP_MAX_MODALITIES];           /* PTM:81 */
+    double beta_sum[MVHDP_MAX_MODALITIES];       /* PTM:82, = beta*V_m PTM:420 */
+    double gamma[MVHDP_MAX_MODALITIES];          /* PTM:83 */
+    double p_a[MVHDP_MAX_MODALITIES][MVHDP_MAX_MODALITIES]; /* PTM:130 */
+    double p_b[MVHDP_MAX_MODALITIES][MVHDP_MAX_MODALITIES]; /* PTM:131 */
+    const uint8_t* inactive;                     /* [K] 1 = member of inActiveTopicIndex (PTM:95); NULL = none */
+} mvhdp_hyper;
+
+/* What one sweep reports: the reference's branch counters WRK:33-35 plus
+ * bookkeeping. */
+typedef struct {
+    int64_t tokens;               /* tokens sampled */
+    int64_t changed;              /* tokens whose topic changed = FastQDelta records, WRK:587 */
+    int64_t new_mass_cnt;         /* WRK:523 */
+    int64_t topic_doc_mass_cnt;   /* WRK:530 */
+    int64_t word_ftree_mass_cnt;  /* WRK:533 */
+    int64_t oov_skipped;          /* WRK:427-428 */
+    int64_t aborted_docs;         /* Q11 (WRK:599-601): always 0 unless a mass is NaN */
+    int64_t exact_fallbacks;      /* tokens that left the certified scan for the sequential sum */
+    int32_t activated_topic;      /* UPD:263-270: topic leaving inActiveTopicIndex, -1 if none */
+    int32_t activated_modality;   /*   and the view whose alpha[m][k] took alpha[m][K] */
+    int64_t activation_key;       /* ordering key (global doc<<24 | view<<20.. see DESIGN.md) of that first delta; INT64_MAX if none */
+    double  sweep_kernel_ms;      /* device time of the sweep kernel alone (hipEvents on the handle's stream) */
+    double  total_ms;             /* device time of the whole call: trees + view weights + sweep + apply */
+} mvhdp_sweep_stats;
+
+/* Optional debug outputs of a sweep (parity tests only; slows the kernel). */
+typedef struct {
+    /* per view: 4 doubles per token {newTopicMass, topicDocWordMass, tree root, sample}
+     * (WRK:515-519); NULL entries are skipped. Host pointers. */
+    double* tok_dbg[MVHDP_MAX_MODALITIES];
+    /* full conditionals of selected tokens: (doc, view, pos) -> K+1 doubles,
+     * normalised; slot K is the new-topic mass (SURVEY §8a "full conditional"). */
+    int32_t n_trace;
+    const int64_t* trace_doc;     /* local entity index */
+    const int32_t* trace_view;
+    const int32_t* trace_pos;
+    double* trace_out;            /* [n_trace][K+1] host */
+} mvhdp_debug;
+
+/* sweep flags */
+#define MVHDP_SWEEP_REUSE_TREES 0x1u  /* do not rebuild the F+trees from the counts first (PTM:1209 cadence is the host's) */
+#define MVHDP_SWEEP_NO_APPLY    0x2u  /* leave the deltas unapplied (multi-GPU: all-reduce MVHDP_BUF_DELTA, then mvhdp_apply_delta) */
+#define MVHDP_SWEEP_EXACT_CHAIN 0x4u  /* always use the sequential WRK:501-513 sum (test mode for the certified scan) */
+
+/* device buffers a host may hand to a collective (RCCL through torch.distributed or directly) */
+typedef enum {
+    MVHDP_BUF_COUNTS = 0,  /* int32 [sumV*K + M*K]: n_wk rows of every view, then n_k */
+    MVHDP_BUF_DELTA  = 1   /* int32 [sumV*K + M*K]: the last sweep's deltas, same layout */
+} mvhdp_buffer;
+
+/* ---- lifetime ---- */
+int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out);   /* replaces new FastQMVWV…TopicModel PTM:183 + initSpace PTM:575 */
+int mvhdp_destroy(mvhdp_handle h);
+const char* mvhdp_last_error(mvhdp_handle h);                    /* h may be NULL: last create error */
+const char* mvhdp_version(void);
+
+/* ---- corpus and assignments: MTA / MALLET FeatureSequence + LabelSequence flattened to CSR ---- */
+/* One call per view m; D entities in `data` order (PTM:443-455); an entity
+ * without view m (Assignments[m]==null, MTA:19) is an empty span. */
+int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t num_docs,
+                     const int64_t* doc_off /*[D+1]*/, const int32_t* tokens /*[N_m]*/);
+int mvhdp_set_assignments(mvhdp_handle h, int32_t m, const int32_t* z /*[N_m]*/);  /* topicSequence.getFeatures() PTM:481 */
+int mvhdp_get_assignments(mvhdp_handle h, int32_t m, int32_t* z /*[N_m]*/);
+
+/* ---- model state ---- */
+int mvhdp_set_hyper(mvhdp_handle h, const mvhdp_hyper* hy);
+int mvhdp_get_alpha(mvhdp_handle h, double* alpha /*[M][K+1]*/, uint8_t* inactive /*[K]*/); /* after a topic activation UPD:263-270 */
+int mvhdp_build_counts(mvhdp_handle h);                          /* buildInitialTypeTopicCounts PTM:600-652 */
+int mvhdp_build_trees(mvhdp_handle h);                           /* buildFTrees PTM:2660-2696 */
+int mvhdp_get_counts(mvhdp_handle h, int32_t m, int32_t* n_wk /*[V_m][K] or NULL*/, int32_t* n_k /*[K] or NULL*/);
+int mvhdp_set_counts(mvhdp_handle h, int32_t m, const int32_t* n_wk, const int32_t* n_k);
+int mvhdp_get_tree(mvhdp_handle h, int32_t m, int32_t type, double* tree /*[2K], FTree.tree FT:21*/);
+/* topicDocCounts[m][k][c] (c < hist_len) and docLengthCounts[m][len] (PTM:107-108,
+ * 620-651), recomputed from z instead of the updater's incremental bookkeeping
+ * UPD:220-232. Either output may be NULL. */
+int mvhdp_get_doc_topic_hist(mvhdp_handle h, int32_t m, int32_t* hist /*[K][hist_len]*/, int32_t hist_len,
+                             int32_t* doc_len_counts /*[len_len]*/, int32_t len_len);
+
+/* ---- the hot path ---- */
+/* One Gibbs sweep over every entity: replaces "submit updaters + submit
+ * workers + barrier.await()" PTM:1213-1239, i.e. WRK:186-233 x nst threads and
+ * UPD:164-297 x nut threads.  sweep_idx and seed select the counter-based RNG
+ * stream that stands in for ThreadLocalRandom (WRK:517,534).  p_override:
+ * host [D][M][M] view weights drawn as WRK:327-337, or NULL to draw them on
+ * the device (same nextBeta algorithm over a Philox stream).  dbg may be NULL.
+ * Synchronous. */
+int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
+                const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats);
+/* n_wk += delta, n_k += delta, delta = 0; also performs the topic activation
+ * recorded by the sweep when (topic,modality) >= 0 (multi-GPU: the host passes
+ * the winner of the min-reduction over activation_key). */
+int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_t activated_modality);
+/* the per-document view weights used by the last sweep */
+int mvhdp_get_view_weights(mvhdp_handle h, double* p /*[D][M][M]*/);
+
+/* ---- interop for collectives and stream sharing ---- */
+int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** dev_ptr, size_t* bytes);
+int mvhdp_set_stream(mvhdp_handle h, void* hip_stream /* hipStream_t, NULL = library's own */);
+int mvhdp_synchronize(mvhdp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVHDP_H */

@@ -1,0 +1,95 @@
+"""ctypes loader of libmvhdp.so (the C ABI of include/mvhdp.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvhdp.so")
+
+MAX_M = 8
+
+# every symbol include/mvhdp.h declares
+ABI_SYMBOLS = [
+    "mvhdp_create", "mvhdp_destroy", "mvhdp_last_error", "mvhdp_version",
+    "mvhdp_set_corpus", "mvhdp_set_assignments", "mvhdp_get_assignments",
+    "mvhdp_set_hyper", "mvhdp_get_alpha", "mvhdp_build_counts", "mvhdp_build_trees",
+    "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
+    "mvhdp_sweep", "mvhdp_apply_delta", "mvhdp_get_view_weights",
+    "mvhdp_device_buffer", "mvhdp_set_stream", "mvhdp_synchronize",
+]
+
+
+class MvhdpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mvhdp error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("num_topics", C.c_int32), ("num_modalities", C.c_int32),
+                ("num_types", C.c_int32 * MAX_M), ("device", C.c_int32),
+                ("doc_id_base", C.c_int64), ("flags", C.c_uint32)]
+
+
+class HyperC(C.Structure):
+    _fields_ = [("alpha", C.c_void_p),
+                ("alpha_sum", C.c_double * MAX_M), ("beta", C.c_double * MAX_M),
+                ("beta_sum", C.c_double * MAX_M), ("gamma", C.c_double * MAX_M),
+                ("p_a", (C.c_double * MAX_M) * MAX_M), ("p_b", (C.c_double * MAX_M) * MAX_M),
+                ("inactive", C.c_void_p)]
+
+
+class SweepStatsC(C.Structure):
+    _fields_ = [("tokens", C.c_int64), ("changed", C.c_int64), ("new_mass_cnt", C.c_int64),
+                ("topic_doc_mass_cnt", C.c_int64), ("word_ftree_mass_cnt", C.c_int64),
+                ("oov_skipped", C.c_int64), ("aborted_docs", C.c_int64), ("exact_fallbacks", C.c_int64),
+                ("activated_topic", C.c_int32), ("activated_modality", C.c_int32),
+                ("activation_key", C.c_int64), ("sweep_kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+class DebugC(C.Structure):
+    _fields_ = [("tok_dbg", C.c_void_p * MAX_M), ("n_trace", C.c_int32),
+                ("trace_doc", C.c_void_p), ("trace_view", C.c_void_p), ("trace_pos", C.c_void_p),
+                ("trace_out", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmvhdp.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C mvtopicmodel_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+    L.mvhdp_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.mvhdp_destroy.argtypes = [vp]
+    L.mvhdp_last_error.argtypes = [vp]; L.mvhdp_last_error.restype = C.c_char_p
+    L.mvhdp_version.restype = C.c_char_p
+    L.mvhdp_set_corpus.argtypes = [vp, i32, i64, vp, vp]
+    L.mvhdp_set_assignments.argtypes = [vp, i32, vp]
+    L.mvhdp_get_assignments.argtypes = [vp, i32, vp]
+    L.mvhdp_set_hyper.argtypes = [vp, C.POINTER(HyperC)]
+    L.mvhdp_get_alpha.argtypes = [vp, vp, vp]
+    L.mvhdp_build_counts.argtypes = [vp]
+    L.mvhdp_build_trees.argtypes = [vp]
+    L.mvhdp_get_counts.argtypes = [vp, i32, vp, vp]
+    L.mvhdp_set_counts.argtypes = [vp, i32, vp, vp]
+    L.mvhdp_get_tree.argtypes = [vp, i32, i32, vp]
+    L.mvhdp_get_doc_topic_hist.argtypes = [vp, i32, vp, i32, vp, i32]
+    L.mvhdp_sweep.argtypes = [vp, u32, u64, u32, vp, C.POINTER(DebugC), C.POINTER(SweepStatsC)]
+    L.mvhdp_apply_delta.argtypes = [vp, i32, i32]
+    L.mvhdp_get_view_weights.argtypes = [vp, vp]
+    L.mvhdp_device_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.mvhdp_set_stream.argtypes = [vp, vp]
+    L.mvhdp_synchronize.argtypes = [vp]
+    for name in ABI_SYMBOLS:
+        f = getattr(L, name)  # raises AttributeError if the symbol is not exported
+        if name not in ("mvhdp_last_error", "mvhdp_version"):
+            f.restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,543 @@
+// mvhdp_api.hip — host side of the C ABI declared in include/mvhdp.h.
+// Owns the device state of one model shard (one HIP device), launches the
+// kernels of mvhdp_kernels.hip on one stream and copies results back.
+// There is NO CPU fallback: without a gfx950 device mvhdp_create fails.
+#include "mvhdp_device.h"
+#include "../../include/mvhdp.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_create_error;
+
+struct mvhdp_ctx {
+    mvhdp_config cfg{};
+    MvModel mm{};
+    int device = 0;
+    int num_cus = 256;
+    size_t max_lds = 65536;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[4]{};
+    std::string err;
+
+    int64_t N[MVHDP_MAXM]{};                 // tokens per view
+    bool have_corpus[MVHDP_MAXM]{};
+    std::vector<int64_t> h_doc_off[MVHDP_MAXM];
+    void* d_doc_off[MVHDP_MAXM]{};
+    void* d_tok[MVHDP_MAXM]{};
+    void* d_z[MVHDP_MAXM]{};
+    int64_t max_doc_tokens = -1;             // over all views, lazily computed
+
+    double* d_alpha = nullptr;
+    uint8_t* d_inactive = nullptr;
+    std::vector<double> h_alpha;
+    std::vector<uint8_t> h_inactive;
+    bool have_hyper = false, have_counts = false, have_trees = false;
+
+    unsigned long long* d_stats = nullptr;   // [ST_COUNT]
+    long long* d_act_key = nullptr;
+    size_t lds_attr_set = 0;
+};
+
+#define CHECK_H(h) do { if (!(h)) return MVHDP_ERR_INVALID_ARG; } while (0)
+#define HIPC(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
+#define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
+
+static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
+
+extern "C" const char* mvhdp_version(void) { return "mvhdp 0.1 (gfx950)"; }
+
+extern "C" const char* mvhdp_last_error(mvhdp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
+{
+    if (!cfg || !out) { g_create_error = "null argument"; return MVHDP_ERR_INVALID_ARG; }
+    *out = nullptr;
+    const int K = cfg->num_topics, M = cfg->num_modalities;
+    if (K < 1 || K > MVHDP_MAX_TOPICS || M < 1 || M > MVHDP_MAX_MODALITIES) {
+        g_create_error = "num_topics must be in [1,2048] and num_modalities in [1,8]";
+        return MVHDP_ERR_INVALID_ARG;
+    }
+    for (int m = 0; m < M; m++) if (cfg->num_types[m] < 1) { g_create_error = "num_types[m] must be >= 1"; return MVHDP_ERR_INVALID_ARG; }
+    if (cfg->doc_id_base < 0 || cfg->doc_id_base >= (1LL << 29)) { g_create_error = "doc_id_base out of range"; return MVHDP_ERR_INVALID_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_error = "no usable HIP device (the sweep has no CPU fallback)";
+        return MVHDP_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return MVHDP_ERR_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return MVHDP_ERR_NO_DEVICE;
+    }
+    mvhdp_ctx* h = new mvhdp_ctx();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    h->num_cus = prop.multiProcessorCount;
+    h->max_lds = 160 * 1024;
+    MvModel& mm = h->mm;
+    mm.K = K; mm.M = M;
+    mm.rowbase[0] = 0;
+    for (int m = 0; m < M; m++) { mm.V[m] = cfg->num_types[m]; mm.rowbase[m + 1] = mm.rowbase[m] + cfg->num_types[m]; }
+    mm.doc_id_base = cfg->doc_id_base;
+    mm.first_inactive = -1;
+    mm.D = -1;
+#define CREATE_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); mvhdp_destroy(h); return MVHDP_ERR_HIP; } } while (0)
+    CREATE_HIP(hipSetDevice(h->device));
+    CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    for (auto& e : h->ev) CREATE_HIP(hipEventCreate(&e));
+    const int64_t nrows = mm.rowbase[M];
+    const size_t cbytes = (size_t)(nrows * K + (int64_t)M * K) * sizeof(int32_t);
+    CREATE_HIP(hipMalloc(&mm.counts, cbytes));
+    CREATE_HIP(hipMalloc(&mm.delta, cbytes));
+    CREATE_HIP(hipMemset(mm.counts, 0, cbytes));
+    CREATE_HIP(hipMemset(mm.delta, 0, cbytes));
+    CREATE_HIP(hipMalloc(&mm.trees, (size_t)nrows * 2 * K * sizeof(double)));
+    CREATE_HIP(hipMalloc(&mm.root, (size_t)nrows * sizeof(double)));
+    CREATE_HIP(hipMalloc(&h->d_alpha, (size_t)M * (K + 1) * sizeof(double)));
+    CREATE_HIP(hipMalloc(&h->d_inactive, (size_t)K));
+    CREATE_HIP(hipMemset(h->d_inactive, 0, (size_t)K));
+    CREATE_HIP(hipMalloc(&h->d_stats, ST_COUNT * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc(&h->d_act_key, sizeof(long long)));
+    mm.alpha = h->d_alpha;
+    mm.inactive = h->d_inactive;
+    h->h_alpha.assign((size_t)M * (K + 1), 0.0);
+    h->h_inactive.assign((size_t)K, 0);
+    *out = h;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_destroy(mvhdp_handle h)
+{
+    if (!h) return MVHDP_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (int m = 0; m < MVHDP_MAXM; m++) {
+        if (h->d_doc_off[m]) hipFree(h->d_doc_off[m]);
+        if (h->d_tok[m]) hipFree(h->d_tok[m]);
+        if (h->d_z[m]) hipFree(h->d_z[m]);
+    }
+    if (h->mm.counts) hipFree(h->mm.counts);
+    if (h->mm.delta) hipFree(h->mm.delta);
+    if (h->mm.trees) hipFree(h->mm.trees);
+    if (h->mm.root) hipFree(h->mm.root);
+    if (h->mm.p) hipFree(h->mm.p);
+    if (h->d_alpha) hipFree(h->d_alpha);
+    if (h->d_inactive) hipFree(h->d_inactive);
+    if (h->d_stats) hipFree(h->d_stats);
+    if (h->d_act_key) hipFree(h->d_act_key);
+    for (auto& e : h->ev) if (e) hipEventDestroy(e);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_set_stream(mvhdp_handle h, void* hip_stream)
+{
+    CHECK_H(h);
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream) { hipStreamDestroy(h->stream); h->own_stream = false; }
+    if (hip_stream) h->stream = (hipStream_t)hip_stream;
+    else { HIPC(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_synchronize(mvhdp_handle h)
+{
+    CHECK_H(h);
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int64_t* doc_off, const int32_t* tokens)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M || D < 0 || !doc_off) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_corpus: bad view, num_docs or doc_off");
+    if (mm.D >= 0 && D != mm.D) {
+        bool any_other = false;
+        for (int j = 0; j < mm.M; j++) if (j != m && h->have_corpus[j]) any_other = true;
+        if (any_other) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_corpus: every view must list the same entities (empty span = view absent)");
+    }
+    if (mm.doc_id_base + D >= (1LL << 29)) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_corpus: too many entities");
+    if (doc_off[0] != 0) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_corpus: doc_off[0] must be 0");
+    for (int64_t d = 0; d < D; d++) {
+        int64_t len = doc_off[d + 1] - doc_off[d];
+        if (len < 0) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_corpus: doc_off must be non-decreasing");
+        if (len >= (1 << 20)) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_corpus: a view of one entity is limited to 2^20-1 tokens");
+    }
+    const int64_t N = doc_off[D];
+    if (N > 0 && !tokens) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_corpus: tokens is null");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (h->d_doc_off[m]) { hipFree(h->d_doc_off[m]); h->d_doc_off[m] = nullptr; }
+    if (h->d_tok[m]) { hipFree(h->d_tok[m]); h->d_tok[m] = nullptr; }
+    if (h->d_z[m]) { hipFree(h->d_z[m]); h->d_z[m] = nullptr; }
+    HIPC(h, hipMalloc(&h->d_doc_off[m], (size_t)(D + 1) * sizeof(int64_t)));
+    HIPC(h, hipMemcpy(h->d_doc_off[m], doc_off, (size_t)(D + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    const size_t nb = (size_t)std::max<int64_t>(N, 1) * sizeof(int32_t);
+    HIPC(h, hipMalloc(&h->d_tok[m], nb));
+    HIPC(h, hipMalloc(&h->d_z[m], nb));
+    if (N > 0) HIPC(h, hipMemcpy(h->d_tok[m], tokens, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPC(h, hipMemset(h->d_z[m], 0xff, nb));               // UNASSIGNED_TOPIC (-1), PTM:63
+    h->h_doc_off[m].assign(doc_off, doc_off + D + 1);
+    h->N[m] = N;
+    h->have_corpus[m] = true;
+    h->max_doc_tokens = -1;
+    mm.D = D;
+    mm.doc_off[m] = (const int64_t*)h->d_doc_off[m];
+    mm.tok[m] = (const int32_t*)h->d_tok[m];
+    mm.z[m] = (int32_t*)h->d_z[m];
+    if (mm.p) { hipFree(mm.p); mm.p = nullptr; }
+    h->have_counts = false; h->have_trees = false;
+    return MVHDP_OK;
+}
+
+static int require_corpus(mvhdp_ctx* h)
+{
+    for (int m = 0; m < h->mm.M; m++)
+        if (!h->have_corpus[m]) FAIL(h, MVHDP_ERR_STATE, "set_corpus has not been called for every view");
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_set_assignments(mvhdp_handle h, int32_t m, const int32_t* z)
+{
+    CHECK_H(h);
+    if (m < 0 || m >= h->mm.M) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_assignments: bad view");
+    if (!h->have_corpus[m]) FAIL(h, MVHDP_ERR_STATE, "set_assignments before set_corpus");
+    if (h->N[m] > 0 && !z) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_assignments: null z");
+    for (int64_t i = 0; i < h->N[m]; i++)
+        if (z[i] < -1 || z[i] >= h->mm.K) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_assignments: topic out of range");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (h->N[m] > 0) HIPC(h, hipMemcpy(h->d_z[m], z, (size_t)h->N[m] * sizeof(int32_t), hipMemcpyHostToDevice));
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_get_assignments(mvhdp_handle h, int32_t m, int32_t* z)
+{
+    CHECK_H(h);
+    if (m < 0 || m >= h->mm.M) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_assignments: bad view");
+    if (!h->have_corpus[m]) FAIL(h, MVHDP_ERR_STATE, "get_assignments before set_corpus");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (h->N[m] > 0) HIPC(h, hipMemcpy(z, h->d_z[m], (size_t)h->N[m] * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_set_hyper(mvhdp_handle h, const mvhdp_hyper* hy)
+{
+    CHECK_H(h);
+    if (!hy || !hy->alpha) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_hyper: null");
+    MvModel& mm = h->mm;
+    const int K = mm.K, M = mm.M;
+    for (int m = 0; m < M; m++) {
+        if (!(hy->beta_sum[m] > 0) || !(hy->beta[m] > 0)) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_hyper: beta and beta_sum must be > 0");
+        mm.alpha_sum[m] = hy->alpha_sum[m]; mm.beta[m] = hy->beta[m];
+        mm.beta_sum[m] = hy->beta_sum[m];   mm.gamma[m] = hy->gamma[m];
+        for (int j = 0; j < M; j++) { mm.p_a[m][j] = hy->p_a[m][j]; mm.p_b[m][j] = hy->p_b[m][j]; }
+    }
+    h->h_alpha.assign(hy->alpha, hy->alpha + (size_t)M * (K + 1));
+    if (hy->inactive) h->h_inactive.assign(hy->inactive, hy->inactive + K);
+    else h->h_inactive.assign((size_t)K, 0);
+    mm.first_inactive = -1;
+    for (int k = 0; k < K; k++) if (h->h_inactive[k]) { mm.first_inactive = k; break; }
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipMemcpy(h->d_alpha, h->h_alpha.data(), (size_t)M * (K + 1) * sizeof(double), hipMemcpyHostToDevice));
+    HIPC(h, hipMemcpy(h->d_inactive, h->h_inactive.data(), (size_t)K, hipMemcpyHostToDevice));
+    h->have_hyper = true;
+    h->have_trees = false;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_get_alpha(mvhdp_handle h, double* alpha, uint8_t* inactive)
+{
+    CHECK_H(h);
+    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "get_alpha before set_hyper");
+    if (alpha) memcpy(alpha, h->h_alpha.data(), h->h_alpha.size() * sizeof(double));
+    if (inactive) memcpy(inactive, h->h_inactive.data(), h->h_inactive.size());
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_build_counts(mvhdp_handle h)
+{
+    CHECK_H(h);
+    int rc = require_corpus(h); if (rc) return rc;
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, mvhdp_launch_build_counts(h->mm, h->N, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->have_counts = true; h->have_trees = false;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_build_trees(mvhdp_handle h)
+{
+    CHECK_H(h);
+    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "build_trees before set_hyper");
+    if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "build_trees before build_counts/set_counts");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, mvhdp_launch_build_trees(h->mm, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->have_trees = true;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_get_counts(mvhdp_handle h, int32_t m, int32_t* n_wk, int32_t* n_k)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_counts: bad view");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    const int K = mm.K;
+    if (n_wk) HIPC(h, hipMemcpy(n_wk, mm.counts + mm.rowbase[m] * K, (size_t)mm.V[m] * K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_k) HIPC(h, hipMemcpy(n_k, mm.counts + mm.rowbase[mm.M] * K + (int64_t)m * K, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_set_counts(mvhdp_handle h, int32_t m, const int32_t* n_wk, const int32_t* n_k)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_counts: bad view");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    const int K = mm.K;
+    if (n_wk) HIPC(h, hipMemcpy(mm.counts + mm.rowbase[m] * K, n_wk, (size_t)mm.V[m] * K * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (n_k) HIPC(h, hipMemcpy(mm.counts + mm.rowbase[mm.M] * K + (int64_t)m * K, n_k, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->have_counts = true; h->have_trees = false;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_get_tree(mvhdp_handle h, int32_t m, int32_t type, double* tree)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M || type < 0 || type >= mm.V[m] || !tree) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_tree: bad argument");
+    if (!h->have_trees) FAIL(h, MVHDP_ERR_STATE, "get_tree before build_trees");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipMemcpy(tree, mm.trees + (mm.rowbase[m] + type) * 2 * mm.K, (size_t)2 * mm.K * sizeof(double), hipMemcpyDeviceToHost));
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_get_doc_topic_hist(mvhdp_handle h, int32_t m, int32_t* hist, int32_t hist_len,
+                                        int32_t* doc_len_counts, int32_t len_len)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M || (hist && hist_len < 1) || (doc_len_counts && len_len < 1))
+        FAIL(h, MVHDP_ERR_INVALID_ARG, "get_doc_topic_hist: bad argument");
+    int rc = require_corpus(h); if (rc) return rc;
+    HIPC(h, hipSetDevice(h->device));
+    int32_t *d_hist = nullptr, *d_len = nullptr;
+    if (hist) HIPC(h, hipMalloc(&d_hist, (size_t)mm.K * hist_len * sizeof(int32_t)));
+    if (doc_len_counts) HIPC(h, hipMalloc(&d_len, (size_t)len_len * sizeof(int32_t)));
+    hipError_t e = mvhdp_launch_doc_topic_hist(mm, m, d_hist, hist_len, d_len, len_len, h->stream);
+    if (e == hipSuccess && hist) e = hipMemcpy(hist, d_hist, (size_t)mm.K * hist_len * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && doc_len_counts) e = hipMemcpy(doc_len_counts, d_len, (size_t)len_len * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (d_hist) hipFree(d_hist);
+    if (d_len) hipFree(d_len);
+    HIPC(h, e);
+    return MVHDP_OK;
+}
+
+static int64_t compute_max_doc_tokens(mvhdp_ctx* h)
+{
+    if (h->max_doc_tokens >= 0) return h->max_doc_tokens;
+    int64_t mx = 0;
+    const MvModel& mm = h->mm;
+    for (int64_t d = 0; d < mm.D; d++) {
+        int64_t t = 0;
+        for (int m = 0; m < mm.M; m++) t += h->h_doc_off[m][d + 1] - h->h_doc_off[m][d];
+        mx = std::max(mx, t);
+    }
+    h->max_doc_tokens = mx;
+    return mx;
+}
+
+extern "C" int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_t activated_modality)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipMemsetAsync(h->d_stats + ST_NEGATIVE, 0, sizeof(unsigned long long), h->stream));
+    HIPC(h, mvhdp_launch_apply_delta(mm, h->d_stats, h->stream));
+    unsigned long long neg = 0;
+    HIPC(h, hipMemcpyAsync(&neg, h->d_stats + ST_NEGATIVE, sizeof neg, hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->have_trees = false;
+    if (activated_topic >= 0) {                                  // UPD:263-270
+        if (activated_topic >= mm.K || activated_modality < 0 || activated_modality >= mm.M)
+            FAIL(h, MVHDP_ERR_INVALID_ARG, "apply_delta: bad activation");
+        if (h->h_inactive[activated_topic]) {
+            h->h_inactive[activated_topic] = 0;
+            h->h_alpha[(size_t)activated_modality * (mm.K + 1) + activated_topic] = h->h_alpha[(size_t)activated_modality * (mm.K + 1) + mm.K];
+            mm.first_inactive = -1;
+            for (int k = 0; k < mm.K; k++) if (h->h_inactive[k]) { mm.first_inactive = k; break; }
+            HIPC(h, hipMemcpy(h->d_alpha, h->h_alpha.data(), h->h_alpha.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPC(h, hipMemcpy(h->d_inactive, h->h_inactive.data(), (size_t)mm.K, hipMemcpyHostToDevice));
+        }
+    }
+    if (neg) FAIL(h, MVHDP_ERR_NEGATIVE_COUNT, "a topic count went below zero (UPD:202-215)");
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
+                           const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    int rc = require_corpus(h); if (rc) return rc;
+    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "sweep before set_hyper");
+    if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "sweep before build_counts/set_counts");
+    if ((flags & MVHDP_SWEEP_REUSE_TREES) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES without trees");
+    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+    const int K = mm.K, M = mm.M;
+    HIPC(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+
+    // launch geometry
+    int64_t mdt = compute_max_doc_tokens(h);
+    int S_cap = (int)std::min<int64_t>(K, std::max<int64_t>(mdt, 1));
+    S_cap = (S_cap + 63) / 64 * 64;
+    SweepLaunch sl{};
+    sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
+    sl.flags = flags; sl.S_cap = S_cap;
+    sl.block_shared_bytes = (uint32_t)(((size_t)M * K * sizeof(int) + 15) & ~(size_t)15);
+    sl.wave_bytes = (uint32_t)mvhdp_sweep_wave_bytes(M, S_cap);
+    int wpb = 4;
+    while (wpb > 1 && sl.block_shared_bytes + (size_t)wpb * sl.wave_bytes > h->max_lds) wpb >>= 1;
+    size_t lds = sl.block_shared_bytes + (size_t)wpb * sl.wave_bytes;
+    if (lds > h->max_lds) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB (K * modalities too large)");
+    sl.waves_per_block = wpb;
+    if (lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
+    int blocks_per_cu = (int)std::min<size_t>(h->max_lds / lds, (size_t)(32 / wpb));
+    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+    int64_t need = (mm.D + wpb - 1) / wpb;
+    int grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * blocks_per_cu));
+    sl.stats = h->d_stats;
+    sl.act_key = h->d_act_key;
+
+    // debug buffers
+    const bool debug = dbg != nullptr;
+    std::vector<void*> to_free;
+    auto cleanup = [&]() { for (void* p : to_free) hipFree(p); };
+    if (debug) {
+        for (int m = 0; m < M; m++) {
+            if (dbg->tok_dbg[m] && h->N[m] > 0) {
+                void* p = nullptr;
+                hipError_t e = hipMalloc(&p, (size_t)h->N[m] * 4 * sizeof(double));
+                if (e != hipSuccess) { cleanup(); HIPC(h, e); }
+                to_free.push_back(p);
+                hipMemsetAsync(p, 0, (size_t)h->N[m] * 4 * sizeof(double), s);
+                sl.tok_dbg[m] = (double*)p;
+            }
+        }
+        if (dbg->n_trace > 0) {
+            void *a = nullptr, *b = nullptr, *c = nullptr, *o = nullptr;
+            size_t n = (size_t)dbg->n_trace;
+            if (hipMalloc(&a, n * 8) != hipSuccess || hipMalloc(&b, n * 4) != hipSuccess ||
+                hipMalloc(&c, n * 4) != hipSuccess || hipMalloc(&o, n * (K + 1) * 8) != hipSuccess) {
+                cleanup(); FAIL(h, MVHDP_ERR_HIP, "debug trace allocation failed");
+            }
+            to_free.push_back(a); to_free.push_back(b); to_free.push_back(c); to_free.push_back(o);
+            hipMemcpyAsync(a, dbg->trace_doc, n * 8, hipMemcpyHostToDevice, s);
+            hipMemcpyAsync(b, dbg->trace_view, n * 4, hipMemcpyHostToDevice, s);
+            hipMemcpyAsync(c, dbg->trace_pos, n * 4, hipMemcpyHostToDevice, s);
+            hipMemsetAsync(o, 0, n * (K + 1) * 8, s);
+            sl.n_trace = dbg->n_trace;
+            sl.trace_doc = (const int64_t*)a; sl.trace_view = (const int32_t*)b; sl.trace_pos = (const int32_t*)c;
+            sl.trace_out = (double*)o;
+        }
+    }
+
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    step(hipEventRecord(h->ev[0], s));
+    if (M > 1) {
+        if (!mm.p && mm.D > 0) step(hipMalloc(&mm.p, (size_t)mm.D * M * M * sizeof(double)));
+        if (e == hipSuccess) {
+            if (p_override) step(hipMemcpyAsync(mm.p, p_override, (size_t)mm.D * M * M * sizeof(double), hipMemcpyHostToDevice, s));
+            else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, s));
+        }
+    }
+    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) { step(mvhdp_launch_build_trees(mm, s)); h->have_trees = true; }
+    step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
+    step(hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
+    const long long kmax = LLONG_MAX;
+    step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
+    step(hipEventRecord(h->ev[1], s));
+    if (e == hipSuccess && mm.D > 0) step(mvhdp_launch_sweep(mm, sl, grid, debug, s));
+    step(hipEventRecord(h->ev[2], s));
+    unsigned long long hs[ST_COUNT] = {0};
+    long long act = LLONG_MAX;
+    step(hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, s));
+    step(hipMemcpyAsync(&act, h->d_act_key, sizeof act, hipMemcpyDeviceToHost, s));
+    step(hipStreamSynchronize(s));
+    if (e != hipSuccess) { cleanup(); HIPC(h, e); }
+
+    if (debug) {
+        for (int m = 0; m < M; m++)
+            if (sl.tok_dbg[m]) step(hipMemcpy(dbg->tok_dbg[m], sl.tok_dbg[m], (size_t)h->N[m] * 4 * sizeof(double), hipMemcpyDeviceToHost));
+        if (sl.n_trace > 0) step(hipMemcpy(dbg->trace_out, sl.trace_out, (size_t)sl.n_trace * (K + 1) * sizeof(double), hipMemcpyDeviceToHost));
+        cleanup();
+        if (e != hipSuccess) HIPC(h, e);
+    }
+
+    mvhdp_sweep_stats st{};
+    st.tokens = (int64_t)hs[ST_TOKENS]; st.changed = (int64_t)hs[ST_CHANGED];
+    st.new_mass_cnt = (int64_t)hs[ST_NEW]; st.topic_doc_mass_cnt = (int64_t)hs[ST_DOC];
+    st.word_ftree_mass_cnt = (int64_t)hs[ST_TREE]; st.oov_skipped = (int64_t)hs[ST_OOV];
+    st.aborted_docs = (int64_t)hs[ST_ABORT]; st.exact_fallbacks = (int64_t)hs[ST_FALLBACK];
+    st.activation_key = act;
+    st.activated_topic = -1; st.activated_modality = -1;
+    if (act != LLONG_MAX) { st.activated_topic = (int32_t)(act & 0x7ff); st.activated_modality = (int32_t)((act >> 31) & 0x7); }
+
+    int ret = MVHDP_OK;
+    if (!(flags & MVHDP_SWEEP_NO_APPLY)) ret = mvhdp_apply_delta(h, st.activated_topic, st.activated_modality);
+    HIPC(h, hipEventRecord(h->ev[3], s));
+    HIPC(h, hipEventSynchronize(h->ev[3]));
+    float ms_k = 0, ms_t = 0;
+    hipEventElapsedTime(&ms_k, h->ev[1], h->ev[2]);
+    hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
+    st.sweep_kernel_ms = ms_k; st.total_ms = ms_t;
+    if (stats) *stats = st;
+    return ret;
+}
+
+extern "C" int mvhdp_get_view_weights(mvhdp_handle h, double* p)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (!p) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_view_weights: null");
+    if (mm.M == 1) { for (int64_t d = 0; d < mm.D; d++) p[d] = 1.0; return MVHDP_OK; }
+    if (!mm.p) FAIL(h, MVHDP_ERR_STATE, "get_view_weights before the first sweep");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipMemcpy(p, mm.p, (size_t)mm.D * mm.M * mm.M * sizeof(double), hipMemcpyDeviceToHost));
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** dev_ptr, size_t* bytes)
+{
+    CHECK_H(h);
+    if (!dev_ptr || !bytes) FAIL(h, MVHDP_ERR_INVALID_ARG, "device_buffer: null");
+    size_t b = (size_t)counts_len(h) * sizeof(int32_t);
+    if (which == MVHDP_BUF_COUNTS) { *dev_ptr = h->mm.counts; *bytes = b; h->have_counts = true; h->have_trees = false; return MVHDP_OK; }
+    if (which == MVHDP_BUF_DELTA) { *dev_ptr = h->mm.delta; *bytes = b; return MVHDP_OK; }
+    FAIL(h, MVHDP_ERR_INVALID_ARG, "device_buffer: unknown buffer");
+}

@@ -1,0 +1,63 @@
+// mvhdp_device.h — kernel argument block and launch prototypes shared by the
+// HIP kernels (mvhdp_kernels.hip) and the C-ABI host side (mvhdp_api.hip).
+// gfx950 only: 64-lane wavefronts are assumed everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MVHDP_MAXM 8
+
+// Everything a kernel needs, passed by value (lands in SGPRs / constant memory).
+struct MvModel {
+    int32_t K, M;
+    int32_t V[MVHDP_MAXM];
+    int64_t rowbase[MVHDP_MAXM + 1];   // cumulative V: n_wk row of (m,w) = rowbase[m]+w
+    int64_t D;                         // local entities
+    int64_t doc_id_base;               // global id of entity 0
+    const int64_t* doc_off[MVHDP_MAXM];
+    const int32_t* tok[MVHDP_MAXM];
+    int32_t* z[MVHDP_MAXM];
+    // model: counts = [sumV*K n_wk | M*K n_k], delta same layout
+    int32_t* counts;
+    int32_t* delta;
+    double* trees;                     // [sumV][2K]  FTree.tree (FT:21)
+    double* root;                      // [sumV]      tree[1]
+    const double* alpha;               // [M][K+1]
+    const uint8_t* inactive;           // [K]
+    double alpha_sum[MVHDP_MAXM], beta[MVHDP_MAXM], beta_sum[MVHDP_MAXM], gamma[MVHDP_MAXM];
+    double p_a[MVHDP_MAXM][MVHDP_MAXM], p_b[MVHDP_MAXM][MVHDP_MAXM];
+    double* p;                         // [D][M][M] view weights (nullptr when M==1)
+    int32_t first_inactive;            // inActiveTopicIndex.first() or -1
+};
+
+struct SweepLaunch {
+    uint32_t sweep_idx;
+    uint32_t seed_lo, seed_hi;
+    uint32_t flags;                    // MVHDP_SWEEP_EXACT_CHAIN
+    int32_t  S_cap;                    // dense-slot capacity per wave (multiple of 64)
+    int32_t  waves_per_block;
+    uint32_t block_shared_bytes;       // n_k delta table
+    uint32_t wave_bytes;               // per-wave LDS region
+    unsigned long long* stats;         // [16] device counters
+    long long* act_key;                // activation key (atomicMin)
+    // debug
+    double* tok_dbg[MVHDP_MAXM];
+    int32_t n_trace;
+    const int64_t* trace_doc; const int32_t* trace_view; const int32_t* trace_pos;
+    double* trace_out;
+};
+
+enum {
+    ST_TOKENS = 0, ST_CHANGED, ST_NEW, ST_DOC, ST_TREE, ST_OOV, ST_ABORT, ST_FALLBACK, ST_NEGATIVE, ST_COUNT
+};
+
+size_t mvhdp_sweep_wave_bytes(int M, int S_cap);
+
+hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens_per_view, hipStream_t s);
+hipError_t mvhdp_launch_build_trees(const MvModel& mm, hipStream_t s);
+hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
+hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s);
+hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s);
+hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
+                                       int32_t* doc_len_counts, int32_t len_len, hipStream_t s);
+hipError_t mvhdp_sweep_set_max_lds(size_t bytes);

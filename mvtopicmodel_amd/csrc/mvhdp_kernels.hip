@@ -1,0 +1,771 @@
+// mvhdp_kernels.hip — hand-written CDNA4 (gfx950) kernels of the multi-view HDP
+// collapsed-Gibbs sweep.  One 64-lane wavefront owns one entity (document) for
+// all of its views; see DESIGN.md for the layout and the roofline of each kernel.
+//
+// Reference (hmetaxa/MVTopicModel, src/main/java/org/madgik/...):
+//   sweep_kernel       <- FastQMVWVWorkerRunnable.sampleTopicsForOneDoc  WRK:301-601
+//                         + FastQMVWVUpdaterRunnable count updates         UPD:197-218
+//   build_trees_kernel <- FastQMVWVParallelTopicModel.buildFTrees          PTM:2660-2696, FTree FT:96-109
+//   build_counts_kernel<- buildInitialTypeTopicCounts                      PTM:600-652
+//   draw_p_kernel      <- per-document view weights                        WRK:327-337 (MALLET Randoms.nextBeta)
+//   tree_sample()      <- FTree.sample                                     FT:111-136
+//
+// Build with -ffp-contract=off: every fp64 expression below is evaluated in the
+// reference's order with one rounding per operation (Java never fuses a*b+c).
+#include "mvhdp_device.h"
+#include "../../include/mvhdp.h"
+
+#define WAVE 64
+// LDS accesses of one wave execute in issue order, so within a wave only the
+// compiler has to be kept from reordering / caching LDS traffic.
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
+// ---------------------------------------------------------------------------
+// small wave-level helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ int bcast_i(int v, int src_lane)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_lane));
+}
+
+__device__ __forceinline__ double bcast_d(double v, int src_lane)
+{
+    int s = __builtin_amdgcn_readfirstlane(src_lane);
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), s);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), s);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// inclusive prefix sums across the 64 lanes (any association order is fine:
+// the fp64 one is only used under the certified-scan tolerance, see below)
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        int o = __shfl_up(v, s, WAVE);
+        if (lane >= s) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ double wave_incl_scan_d(double v, int lane)
+{
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        double o = __shfl_up(v, s, WAVE);
+        if (lane >= s) v += o;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Random123); the stream contract is in DESIGN.md §RNG
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double bits_to_unit(uint32_t hi, uint32_t lo)
+{
+    // the 53-bit shape of ThreadLocalRandom.nextDouble() (WRK:517,534)
+    unsigned long long x = ((unsigned long long)hi << 32) | lo;
+    return (double)(x >> 11) * 0x1.0p-53;
+}
+
+// ---------------------------------------------------------------------------
+// build_counts: PTM:600-652.  One thread per token, int32 atomics.
+// n_k is privatised in LDS per block and flushed once.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_counts_kernel(MvModel mm, int m, int64_t n_tokens)
+{
+    extern __shared__ int nk_local[];
+    const int K = mm.K;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) nk_local[i] = 0;
+    __syncthreads();
+    int32_t* nwk = mm.counts;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_tokens; i += stride) {
+        int topic = mm.z[m][i];
+        if (topic == MVHDP_UNASSIGNED_TOPIC) continue;            // PTM:634
+        int type = mm.tok[m][i];
+        if (type < 0 || type >= mm.V[m] || topic < 0 || topic >= K) continue;
+        atomicAdd(&nk_local[topic], 1);                           // PTM:640
+        atomicAdd(&nwk[(mm.rowbase[m] + type) * K + topic], 1);   // PTM:643
+    }
+    __syncthreads();
+    int32_t* nk = mm.counts + mm.rowbase[mm.M] * K + (int64_t)m * K;
+    for (int i = threadIdx.x; i < K; i += blockDim.x)
+        if (nk_local[i]) atomicAdd(&nk[i], nk_local[i]);
+}
+
+hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens, hipStream_t s)
+{
+    const int K = mm.K;
+    size_t total = (size_t)(mm.rowbase[mm.M] * K + (int64_t)mm.M * K) * sizeof(int32_t);
+    hipError_t e = hipMemsetAsync(mm.counts, 0, total, s);
+    if (e != hipSuccess) return e;
+    for (int m = 0; m < mm.M; m++) {
+        if (n_tokens[m] <= 0) continue;
+        int64_t blocks = (n_tokens[m] + 255) / 256;
+        int grid = (int)(blocks < 2048 ? blocks : 2048);
+        hipLaunchKernelGGL(build_counts_kernel, dim3(grid), dim3(256), (size_t)K * sizeof(int), s, mm, m, n_tokens[m]);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------
+// build_trees: PTM:2660-2696 + FTree.constructTree FT:96-109.
+// One wave per (view, type) row; the 2K-double tree is assembled in LDS level
+// by level (children always have larger indices, so descending depth is safe)
+// and written out whole, coalesced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm)
+{
+    extern __shared__ double t[];                  // 2K doubles
+    const int K = mm.K, lane = threadIdx.x;
+    const int64_t nrows = mm.rowbase[mm.M];
+    const int32_t* nk_all = mm.counts + nrows * K;
+    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        int m = 0;
+        while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
+        const int32_t* cnt = mm.counts + row * K;
+        const int32_t* nk = nk_all + (int64_t)m * K;
+        const double* al = mm.alpha + (int64_t)m * (K + 1);
+        const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
+        for (int k = lane; k < K; k += WAVE) {
+            double leaf;
+            if (mm.inactive[k]) {                                  // PTM:2670-2671
+                leaf = 0.0;
+            } else {
+                double p_wt = ((double)cnt[k] + beta) / ((double)nk[k] + beta_sum);   // PTM:2676
+                leaf = gamma * al[k] * p_wt;                        // PTM:2678
+            }
+            t[K + k] = leaf;
+        }
+        if (lane == 0) t[0] = 0.0;
+        __syncthreads();
+        if (K > 1) {
+            int dmax = 31 - __clz(K - 1);                          // depth of node K-1
+            for (int d = dmax; d >= 0; d--) {
+                int lo = 1 << d, hi = min(2 << d, K);
+                for (int i = lo + lane; i < hi; i += WAVE) t[i] = t[2 * i] + t[2 * i + 1];   // FT:105
+                __syncthreads();
+            }
+        }
+        double* out = mm.trees + row * 2 * K;
+        for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
+        if (lane == 0) mm.root[row] = t[1];
+        __syncthreads();
+    }
+}
+
+hipError_t mvhdp_launch_build_trees(const MvModel& mm, hipStream_t s)
+{
+    int64_t nrows = mm.rowbase[mm.M];
+    int grid = (int)(nrows < 65536 ? nrows : 65536);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// draw_p: WRK:327-337.  MALLET Randoms.nextBeta restated over a per-(doc,pair)
+// Philox uniform stream (uniform n of the pair = word pair (n&1) of Philox
+// counter (n>>1, 0x100+pair, doc, sweep)).  One thread per entity.
+// ---------------------------------------------------------------------------
+struct PStream {
+    uint32_t c1, c2, c3, k0, k1, n;
+    int have_gauss; double next_gauss;
+    __device__ double uniform()
+    {
+        uint32_t x[4];
+        philox4x32_10(n >> 1, c1, c2, c3, k0, k1, x);
+        double u = (n & 1) ? bits_to_unit(x[2], x[3]) : bits_to_unit(x[0], x[1]);
+        n++;
+        return u;
+    }
+    __device__ double gaussian()
+    {
+        if (!have_gauss) {
+            double v1 = uniform(), v2 = uniform();
+            double x1 = sqrt(-2 * log(v1)) * cos(2 * M_PI * v2);
+            double x2 = sqrt(-2 * log(v1)) * sin(2 * M_PI * v2);
+            next_gauss = x2; have_gauss = 1;
+            return x1;
+        }
+        have_gauss = 0;
+        return next_gauss;
+    }
+    __device__ double beta(double alpha, double beta_)
+    {
+        if (alpha == 1 && beta_ == 1) return uniform();
+        if (alpha >= 1 && beta_ >= 1) {
+            double A = alpha - 1, B = beta_ - 1, C = A + B, L = C * log(C), mu = A / C, sigma = 0.5 / sqrt(C);
+            double y = gaussian(), x = sigma * y + mu;
+            while (x < 0 || x > 1) { y = gaussian(); x = sigma * y + mu; }
+            double u = uniform();
+            // with beta==1 the B*log((1-x)/B) term is NaN and the comparison false (reference quirk, kept)
+            while (log(u) >= A * log(x / A) + B * log((1 - x) / B) + L + 0.5 * y * y) {
+                y = gaussian(); x = sigma * y + mu;
+                while (x < 0 || x > 1) { y = gaussian(); x = sigma * y + mu; }
+                u = uniform();
+            }
+            return x;
+        }
+        double v1 = pow(uniform(), 1 / alpha), v2 = pow(uniform(), 1 / beta_);
+        while (v1 + v2 > 1) { v1 = pow(uniform(), 1 / alpha); v2 = pow(uniform(), 1 / beta_); }
+        return v1 / (v1 + v2);
+    }
+};
+
+__device__ __forceinline__ double java_round_div1000(double b)
+{
+    // (double) Math.round(1000 * b) / (double) 1000   WRK:333
+    double x = 1000 * b;
+    double f = floor(x);
+    if (x - f >= 0.5) f += 1.0;
+    return (double)(long long)f / (double)1000;
+}
+
+__global__ __launch_bounds__(256) void draw_p_kernel(MvModel mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const int M = mm.M;
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= mm.D) return;
+    int64_t dg = mm.doc_id_base + d;
+    double* p = mm.p + d * M * M;
+    for (int m = 0; m < M; m++) {
+        for (int j = m; j < M; j++) {
+            double pRand;
+            if (m == j) pRand = 1.0;
+            else if (mm.p_a[m][j] == 0) pRand = 0;
+            else {
+                PStream s;
+                s.c1 = 0x100u + (uint32_t)(m * M + j); s.c2 = (uint32_t)dg; s.c3 = sweep_idx;
+                s.k0 = seed_lo; s.k1 = seed_hi ^ (uint32_t)((unsigned long long)dg >> 32);
+                s.n = 0; s.have_gauss = 0; s.next_gauss = 0;
+                pRand = java_round_div1000(s.beta(mm.p_a[m][j], mm.p_b[m][j]));
+            }
+            p[m * M + j] = (j != 0 && mm.beta[j] == 0.0001) ? 0 : pRand;   // WRK:335
+            p[j * M + m] = (m != 0 && mm.beta[m] == 0.0001) ? 0 : pRand;   // WRK:336
+        }
+    }
+}
+
+hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s)
+{
+    if (mm.M <= 1 || mm.D == 0) return hipSuccess;
+    int grid = (int)((mm.D + 255) / 256);
+    hipLaunchKernelGGL(draw_p_kernel, dim3(grid), dim3(256), 0, s, mm, sweep_idx, seed_lo, seed_hi);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// FTree.sample (FT:111-136) against the stored tree of one (view,type).
+// The descent reads whole sub-trees per round: the 62 nodes of the five levels
+// below the current node sit in 5 contiguous runs of the tree array, one node
+// per lane, so a K<=2048 descent needs at most 3 dependent load rounds instead
+// of log2(K) of them.  All lanes walk the same path (u is wave-uniform).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int tree_sample(const double* __restrict__ tree, int K, double u2, double root, int lane)
+{
+    int i = 1;
+    double u = u2 * root;                                  // FT:120  u = u * tree[1]
+    const int j = lane + 2;
+    const int t = 31 - __clz(j);                           // 1..6 (6 only for lanes 62,63: unused)
+    const int o = j - (1 << t);
+    while (i < K) {                                        // FT:122
+        long long idx = ((long long)i << t) + o;
+        double v = (lane < 62 && idx < 2LL * K) ? tree[idx] : 0.0;
+        int rel_t = 0, rel_o = 0;
+#pragma unroll
+        for (int step = 0; step < 5; step++) {
+            if (i < K) {
+                int src = (2 << rel_t) + 2 * rel_o - 2;   // lane holding tree[2*i]
+                double l = bcast_d(v, src);
+                if (u < l) { i = 2 * i; rel_o = 2 * rel_o; }               // FT:124-125
+                else { u = u - l; i = 2 * i + 1; rel_o = 2 * rel_o + 1; }  // FT:127-128
+                rel_t++;
+            }
+        }
+        i = uniform_i(i);
+    }
+    return i - K;                                          // FT:132
+}
+
+// ---------------------------------------------------------------------------
+// The sweep.  Per wave (one entity at a time), LDS holds the "dense index" of
+// WRK:376-391 in slot form:
+//   bitmap[ceil(K/32)]  topics present in the entity (any view) at entry
+//   prefix[...]         exclusive popcount prefix -> slot of a topic
+//   sk[S]               slot -> topic, ascending; sign bit = removed (WRK:451-468)
+//   sn[M][S]            localTopicCounts of the listed topics
+//   soth[S], sden[S]    per-view totalMassOtherModalities (WRK:399-410) and n_k+betaSum
+//   scum[S]             topicDocWordMasses (WRK:511)
+// Slots are never moved: a removed topic keeps its slot with a zero term, which
+// leaves every partial sum bit-identical to the compacted list (x + 0.0 == x).
+// Q1/Q2: the list never grows during a visit, exactly as in the reference.
+// ---------------------------------------------------------------------------
+size_t mvhdp_sweep_wave_bytes(int M, int S_cap)
+{
+    size_t b = 64 * 4 /*bitmap*/ + 64 * 4 /*prefix*/ + 16 * 4 /*wlen + pad*/;
+    b += (size_t)S_cap * 4;             // sk
+    b += (size_t)M * S_cap * 4;         // sn
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)3 * S_cap * 8;         // soth, sden, scum
+    return (b + 15) & ~(size_t)15;
+}
+
+template <bool DEBUG>
+__global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i(threadIdx.x >> 6);
+    const int K = mm.K, M = mm.M, S = sl.S_cap;
+    const int NW = (K + 31) >> 5;
+    const bool exact_only = (sl.flags & MVHDP_SWEEP_EXACT_CHAIN) != 0;
+
+    int* nkd = (int*)smem;                                  // [M*K] n_k deltas of this block
+    for (int i = threadIdx.x; i < M * K; i += blockDim.x) nkd[i] = 0;
+    __syncthreads();
+
+    unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
+    uint32_t* bitmap = (uint32_t*)wb;
+    uint32_t* prefix = bitmap + 64;
+    int* wlen = (int*)(prefix + 64);                        // [8] + pad
+    int* sk = wlen + 16;
+    int* sn = sk + S;
+    size_t off = (size_t)(64 + 64 + 16 + S + M * S) * 4;
+    off = (off + 7) & ~(size_t)7;
+    double* soth = (double*)(wb + off);
+    double* sden = soth + S;
+    double* scum = sden + S;
+
+    const int32_t* __restrict__ nwk = mm.counts;
+    const int32_t* __restrict__ nk_all = mm.counts + mm.rowbase[M] * K;
+    int32_t* dnwk = mm.delta;
+
+    unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
+
+    const int64_t wstride = (int64_t)gridDim.x * sl.waves_per_block;
+    for (int64_t d = (int64_t)blockIdx.x * sl.waves_per_block + wave; d < mm.D; d += wstride) {
+        const int64_t dg = mm.doc_id_base + d;
+
+        // ---- WRK:339-391: gather the entity's topics into the slot list ----
+        if (lane < 64) { bitmap[lane] = 0; }
+        LDS_FENCE();
+        for (int m = 0; m < M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            if (lane == 0) wlen[m] = (int)(e - b);
+            for (int64_t i = b + lane; i < e; i += WAVE) {
+                int zz = mm.z[m][i];
+                if (zz >= 0) atomicOr(&bitmap[zz >> 5], 1u << (zz & 31));
+            }
+        }
+        LDS_FENCE();
+        int S_used;
+        {
+            uint32_t wbits = (lane < NW) ? bitmap[lane] : 0u;
+            int cnt = __popc(wbits);
+            int incl = wave_incl_scan_i(cnt, lane);
+            prefix[lane] = (uint32_t)(incl - cnt);
+            S_used = bcast_i(incl, 63);
+        }
+        LDS_FENCE();
+        for (int k0 = 0; k0 < K; k0 += WAVE) {
+            int k = k0 + lane;
+            if (k < K) {
+                uint32_t w = bitmap[k >> 5];
+                if ((w >> (k & 31)) & 1u) sk[prefix[k >> 5] + __popc(w & ((1u << (k & 31)) - 1u))] = k;
+            }
+        }
+        for (int m = 0; m < M; m++)
+            for (int i = lane; i < S_used; i += WAVE) sn[m * S + i] = 0;
+        LDS_FENCE();
+        for (int m = 0; m < M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            for (int64_t i = b + lane; i < e; i += WAVE) {
+                int zz = mm.z[m][i];
+                if (zz >= 0) {
+                    uint32_t w = bitmap[zz >> 5];
+                    int slot = prefix[zz >> 5] + __popc(w & ((1u << (zz & 31)) - 1u));
+                    atomicAdd(&sn[m * S + slot], 1);                       // WRK:357
+                }
+            }
+        }
+        LDS_FENCE();
+
+        const double* pd = (M > 1) ? (mm.p + d * M * M) : nullptr;        // WRK:327-337 (draw_p_kernel / host override)
+        bool aborted = false;
+
+        for (int m = 0; m < M && !aborted; m++) {                         // WRK:393
+            const int lenm = uniform_i(wlen[m]);
+            if (lenm == 0) continue;
+            const double beta_m = mm.beta[m];
+            const double scale_m = (double)lenm + mm.gamma[m] * mm.alpha_sum[m];
+            const double p_mm = pd ? pd[m * M + m] : 1.0;
+            const int32_t* nk = nk_all + (int64_t)m * K;
+
+            // WRK:395-410 totalMassOtherModalities for the listed topics (frozen for this view, Q3)
+            for (int i = lane; i < S_used; i += WAVE) {
+                int k = sk[i] & 0x7fffffff;
+                double acc = 0.0;
+                for (int j = 0; j < M; j++) {
+                    int lj = wlen[j];
+                    if (j != m && lj != 0) {
+                        acc += pd[m * M + j] * ((double)sn[j * S + i] + mm.gamma[j] * mm.alpha[(int64_t)j * (K + 1) + k])
+                               / ((double)lj + mm.gamma[j] * mm.alpha_sum[j]);
+                    }
+                }
+                soth[i] = acc * scale_m;
+                sden[i] = (double)nk[k] + mm.beta_sum[m];                   // tokensPerTopic + betaSum  WRK:507
+            }
+            // WRK:413-418 newTopicMassAllModalities
+            double newAll = 0.0;
+            for (int j = 0; j < M; j++) {
+                double pmj = pd ? pd[m * M + j] : 1.0;
+                newAll += pmj * (mm.gamma[j] * mm.alpha[(int64_t)j * (K + 1) + K]) / ((double)wlen[j] + mm.gamma[j] * mm.alpha_sum[j]);
+            }
+            newAll = newAll * scale_m;
+            const double newMass = (mm.first_inactive < 0) ? 0.0 : newAll / (double)K;   // WRK:515
+            LDS_FENCE();
+
+            const int64_t base = mm.doc_off[m][d];
+            const int64_t row0 = mm.rowbase[m];
+            const int Vm = mm.V[m];
+
+            for (int c0 = 0; c0 < lenm && !aborted; c0 += WAVE) {
+                // one lane per token of the chunk: token id, old topic, slot, RNG, tree root
+                const int ti = c0 + lane;
+                const bool tvalid = ti < lenm;
+                int w_l = tvalid ? mm.tok[m][base + ti] : 0;
+                int z_l = tvalid ? mm.z[m][base + ti] : -1;
+                int so_l = -1;
+                if (z_l >= 0) {
+                    uint32_t w = bitmap[z_l >> 5];
+                    so_l = prefix[z_l >> 5] + __popc(w & ((1u << (z_l & 31)) - 1u));
+                }
+                double u1_l, u2_l;
+                {
+                    uint32_t x[4];
+                    philox4x32_10((uint32_t)ti, (uint32_t)m, (uint32_t)dg, sl.sweep_idx,
+                                  sl.seed_lo, sl.seed_hi ^ (uint32_t)((unsigned long long)dg >> 32), x);
+                    u1_l = bits_to_unit(x[0], x[1]);
+                    u2_l = bits_to_unit(x[2], x[3]);
+                }
+                const bool in_vocab = tvalid && w_l >= 0 && w_l < Vm;
+                double root_l = in_vocab ? mm.root[row0 + w_l] : 0.0;
+                int znew_l = z_l;
+                const int nt = min(WAVE, lenm - c0);
+
+                for (int t = 0; t < nt; t++) {                              // WRK:425
+                    const int w = bcast_i(w_l, t);
+                    if (w < 0 || w >= Vm) { n_oov++; continue; }            // WRK:427-428
+                    const int zold = bcast_i(z_l, t);
+                    const int so = bcast_i(so_l, t);
+                    const double u1 = bcast_d(u1_l, t), u2 = bcast_d(u2_l, t);
+                    const double root = bcast_d(root_l, t);
+                    const int64_t row = row0 + w;
+                    const int32_t* __restrict__ cnt = nwk + row * K;
+
+                    // WRK:434-468 decrement the local count; drop the topic from the list when it is gone from all views
+                    if (so >= 0) {
+                        int c = sn[m * S + so] - 1;
+                        if (lane == 0) sn[m * S + so] = c;
+                        LDS_FENCE();
+                        if (c == 0) {
+                            bool gone = true;
+                            for (int j = 0; j < M; j++) if (sn[j * S + so] != 0) gone = false;
+                            if (gone && lane == 0) sk[so] |= 0x80000000;
+                            LDS_FENCE();
+                        }
+                    }
+
+                    // WRK:496-513 topicDocWordMasses.  pass 0: wave prefix scan (certified below);
+                    // pass 1: the reference's sequential left-to-right sum.
+                    double mass = 0.0, s0 = 0.0, s1 = 0.0, total = 0.0;
+                    int branch = 0;          // 0 new-topic, 1 doc, 2 tree
+                    int slot_new = -1;
+                    for (int pass = exact_only ? 1 : 0; pass < 2; pass++) {
+                        if (pass == 0) {
+                            double carry = 0.0;
+                            for (int r0 = 0; r0 < S_used; r0 += WAVE) {
+                                const int i = r0 + lane;
+                                double term = 0.0;
+                                if (i < S_used) {
+                                    int k = sk[i];
+                                    if (k >= 0) {
+                                        double p_wt = ((double)cnt[k] + beta_m) / sden[i];                  // WRK:507
+                                        term = (p_mm * (double)sn[m * S + i] + soth[i]) * p_wt;            // WRK:509
+                                    }
+                                }
+                                double cum = carry + wave_incl_scan_d(term, lane);
+                                if (i < S_used) scum[i] = cum;
+                                carry = bcast_d(cum, 63);
+                            }
+                            mass = carry;
+                        } else {
+                            for (int i = lane; i < S_used; i += WAVE) {
+                                int k = sk[i];
+                                double term = 0.0;
+                                if (k >= 0) {
+                                    double p_wt = ((double)cnt[k] + beta_m) / sden[i];
+                                    term = (p_mm * (double)sn[m * S + i] + soth[i]) * p_wt;
+                                }
+                                scum[i] = term;
+                            }
+                            LDS_FENCE();
+                            double c = 0.0;
+                            for (int i = 0; i < S_used; i++) {               // WRK:501-513, dense order
+                                c += scum[i];
+                                if (lane == 0) scum[i] = c;
+                            }
+                            mass = c;
+                        }
+                        LDS_FENCE();
+
+                        total = newMass + mass + root;                       // WRK:519
+                        s0 = u1 * total;
+                        // Certified scan: any summation order of the same non-negative terms differs
+                        // from the sequential one by < (2n) ulp-units of the total; if no comparison
+                        // below is closer than tol the decisions equal the reference's bit for bit.
+                        const double tol = (pass == 0) ? total * (double)(4 * S_used + 16) * 0x1.0p-53 : -1.0;
+                        bool unsafe = false;
+                        if (s0 < newMass) {                                  // WRK:522
+                            branch = 0;
+                            if (fabs(s0 - newMass) <= tol) unsafe = true;
+                        } else {
+                            if (newMass != 0.0 && fabs(s0 - newMass) <= tol) unsafe = true;
+                            s1 = s0 - newMass;                               // WRK:528
+                            if (fabs(s1 - mass) <= tol) unsafe = true;
+                            if (s1 < mass) {                                 // WRK:529
+                                branch = 1;
+                                slot_new = -1;
+                                for (int r0 = 0; r0 < S_used; r0 += WAVE) {  // WRK:531 lower_bound over the live list
+                                    const int i = r0 + lane;
+                                    bool live = (i < S_used) && (sk[i] >= 0);
+                                    double cv = live ? scum[i] : 0.0;
+                                    if (__ballot(live && fabs(cv - s1) <= tol)) unsafe = true;
+                                    unsigned long long hit = __ballot(live && cv >= s1);
+                                    if (hit && slot_new < 0) slot_new = r0 + (int)__builtin_ctzll(hit);
+                                }
+                            } else {
+                                branch = 2;
+                            }
+                        }
+                        if (!(pass == 0 && unsafe)) break;
+                        n_fb++;
+                    }
+
+                    if (DEBUG) {
+                        if (sl.tok_dbg[m] && lane == 0) {
+                            double* g = sl.tok_dbg[m] + (base + c0 + t) * 4;
+                            g[0] = newMass; g[1] = mass; g[2] = root; g[3] = s0;
+                        }
+                        for (int q = 0; q < sl.n_trace; q++) {
+                            if (sl.trace_doc[q] == d && sl.trace_view[q] == m && sl.trace_pos[q] == c0 + t) {
+                                double* out = sl.trace_out + (int64_t)q * (K + 1);
+                                const double* tr = mm.trees + row * 2 * K;
+                                for (int k = lane; k < K; k += WAVE) out[k] = tr[K + k] / total;
+                                __threadfence();
+                                if (lane == 0) {
+                                    double prev = 0.0;
+                                    for (int i = 0; i < S_used; i++) {
+                                        if (sk[i] >= 0) { out[sk[i]] += (scum[i] - prev) / total; }
+                                        prev = scum[i];
+                                    }
+                                    out[K] = newMass / total;
+                                }
+                            }
+                        }
+                    }
+
+                    int znew;
+                    if (branch == 0) {                                       // WRK:523-526
+                        c_new++;
+                        znew = mm.first_inactive;
+                    } else if (branch == 1) {                                // WRK:530-531
+                        c_doc++;
+                        if (slot_new < 0) { aborted = true; break; }         // lower_bound == -1 -> exception, Q11
+                        znew = uniform_i(sk[slot_new]);
+                    } else {                                                 // WRK:533-535
+                        c_tree++;
+                        znew = tree_sample(mm.trees + row * 2 * K, K, u2, root, lane);
+                    }
+                    if (znew < 0) znew = K - 1;                              // WRK:549-552
+                    znew = uniform_i(znew);
+
+                    // WRK:557-560
+                    if (lane == t) znew_l = znew;
+                    if (branch != 1) {
+                        uint32_t wbit = bitmap[znew >> 5];
+                        slot_new = ((wbit >> (znew & 31)) & 1u) ? (int)(prefix[znew >> 5] + __popc(wbit & ((1u << (znew & 31)) - 1u))) : -1;
+                    }
+                    if (slot_new >= 0 && lane == 0) sn[m * S + slot_new] += 1;
+                    LDS_FENCE();
+                    n_tok++;
+
+                    // WRK:587-589 + UPD:197-218: the FastQDelta becomes integer atomics on the delta arrays
+                    if (znew != zold) {
+                        n_chg++;
+                        if (lane == 0 && zold >= 0) {
+                            atomicAdd(&dnwk[row * K + zold], -1);
+                            atomicAdd(&nkd[m * K + zold], -1);
+                        }
+                        if (lane == 1) {
+                            atomicAdd(&dnwk[row * K + znew], 1);
+                            atomicAdd(&nkd[m * K + znew], 1);
+                        }
+                        if (mm.first_inactive >= 0 && lane == 2 && mm.inactive[znew]) {   // UPD:263
+                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)(c0 + t) << 11) | (long long)znew;
+                            atomicMin(sl.act_key, key);
+                        }
+                    }
+                }
+                if (tvalid) mm.z[m][base + ti] = znew_l;                     // coalesced write-back of the chunk
+            }
+        }
+        if (aborted) n_abort++;
+        LDS_FENCE();
+    }
+
+    __syncthreads();
+    int32_t* dnk = mm.delta + mm.rowbase[M] * K;
+    for (int i = threadIdx.x; i < M * K; i += blockDim.x)
+        if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
+    if (lane == 0) {
+        if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
+        if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
+        if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
+        if (c_doc) atomicAdd(&sl.stats[ST_DOC], (unsigned long long)c_doc);
+        if (c_tree) atomicAdd(&sl.stats[ST_TREE], (unsigned long long)c_tree);
+        if (n_oov) atomicAdd(&sl.stats[ST_OOV], (unsigned long long)n_oov);
+        if (n_abort) atomicAdd(&sl.stats[ST_ABORT], (unsigned long long)n_abort);
+        if (n_fb) atomicAdd(&sl.stats[ST_FALLBACK], (unsigned long long)n_fb);
+    }
+}
+
+hipError_t mvhdp_sweep_set_max_lds(size_t bytes)
+{
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s)
+{
+    size_t lds = sl.block_shared_bytes + (size_t)sl.waves_per_block * sl.wave_bytes;
+    dim3 block(64 * sl.waves_per_block);
+    if (debug) hipLaunchKernelGGL(sweep_kernel<true>, dim3(grid_blocks), block, lds, s, mm, sl);
+    else       hipLaunchKernelGGL(sweep_kernel<false>, dim3(grid_blocks), block, lds, s, mm, sl);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// apply_delta: counts += delta; delta = 0 (the updater's effect, UPD:197-218,
+// after the optional cross-GPU all-reduce of the delta buffer).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apply_delta_kernel(int32_t* counts, int32_t* delta, int64_t n, unsigned long long* stats)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int neg = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int dl = delta[i];
+        if (dl) {
+            int c = counts[i] + dl;
+            counts[i] = c;
+            delta[i] = 0;
+            if (c < 0) neg++;                              // UPD:202-215 logs this; here it is a hard error
+        }
+    }
+    if (neg) atomicAdd(&stats[ST_NEGATIVE], (unsigned long long)neg);
+}
+
+hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s)
+{
+    int64_t n = mm.rowbase[mm.M] * mm.K + (int64_t)mm.M * mm.K;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(apply_delta_kernel, dim3(grid), dim3(256), 0, s, mm.counts, mm.delta, n, stats);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// doc_topic_hist: topicDocCounts[m][k][n_dk] and docLengthCounts[m][len]
+// (PTM:620-651) recomputed from z.  One wave per entity.  Bucket 0 is filled
+// afterwards from the totals (docs with the view minus docs holding the topic).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void doc_topic_hist_kernel(MvModel mm, int m, int32_t* hist, int32_t hist_len,
+                                                             int32_t* doc_len_counts, int32_t len_len, int32_t* docs_with_view)
+{
+    extern __shared__ int ldk[];                           // [waves][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K = mm.K;
+    int* my = ldk + wave * K;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t d = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; d < mm.D; d += wstride) {
+        const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+        if (e == b) continue;
+        for (int k = lane; k < K; k += WAVE) my[k] = 0;
+        LDS_FENCE();
+        for (int64_t i = b + lane; i < e; i += WAVE) { int zz = mm.z[m][i]; if (zz >= 0) atomicAdd(&my[zz], 1); }
+        LDS_FENCE();
+        for (int k = lane; k < K; k += WAVE) {
+            int c = my[k];
+            if (c > 0 && c < hist_len && hist) atomicAdd(&hist[(int64_t)k * hist_len + c], 1);
+        }
+        if (lane == 0) {
+            atomicAdd(docs_with_view, 1);
+            if (doc_len_counts && e - b < len_len) atomicAdd(&doc_len_counts[e - b], 1);
+        }
+        LDS_FENCE();
+    }
+}
+
+__global__ void hist_bucket0_kernel(int32_t* hist, int32_t hist_len, int K, const int32_t* docs_with_view)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    long long s = 0;
+    for (int c = 1; c < hist_len; c++) s += hist[(int64_t)k * hist_len + c];
+    hist[(int64_t)k * hist_len] = (int32_t)(*docs_with_view - s);
+}
+
+hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
+                                       int32_t* doc_len_counts, int32_t len_len, hipStream_t s)
+{
+    int32_t* dwv = nullptr;
+    hipError_t e = hipMalloc(&dwv, sizeof(int32_t));
+    if (e != hipSuccess) return e;
+    hipMemsetAsync(dwv, 0, sizeof(int32_t), s);
+    if (hist) hipMemsetAsync(hist, 0, (size_t)mm.K * hist_len * sizeof(int32_t), s);
+    if (doc_len_counts) hipMemsetAsync(doc_len_counts, 0, (size_t)len_len * sizeof(int32_t), s);
+    int wpb = 4;
+    while (wpb > 1 && (size_t)wpb * mm.K * sizeof(int) > 60000) wpb >>= 1;
+    int64_t blocks = (mm.D + wpb - 1) / wpb;
+    int grid = (int)(blocks < 4096 ? (blocks < 1 ? 1 : blocks) : 4096);
+    hipLaunchKernelGGL(doc_topic_hist_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * mm.K * sizeof(int), s,
+                       mm, m, hist, hist_len, doc_len_counts, len_len, dwv);
+    if (hist) hipLaunchKernelGGL(hist_bucket0_kernel, dim3((mm.K + 63) / 64), dim3(64), 0, s, hist, hist_len, mm.K, dwv);
+    e = hipGetLastError();
+    hipStreamSynchronize(s);
+    hipFree(dwv);
+    return e;
+}
+

@@ -1,0 +1,244 @@
+"""NativeSampler — Python mirror of the JNI host class
+``org.madgik.MVTopicModel.NativeSampler`` shown in INTEGRATION.md: a thin,
+numpy-typed wrapper over the C ABI (include/mvhdp.h).  One instance = one model
+shard on one MI355X.  All compute happens in libmvhdp.so on the GPU.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._lib import (MAX_M, Config, DebugC, HyperC, MvhdpError, SweepStatsC, load_library)
+
+SWEEP_REUSE_TREES = 0x1
+SWEEP_NO_APPLY = 0x2
+SWEEP_EXACT_CHAIN = 0x4
+
+BUF_COUNTS = 0
+BUF_DELTA = 1
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Hyper:
+    """The hyper-parameters the sampler reads (PTM:79-83,95,130-131)."""
+    alpha: np.ndarray          # [M][K+1]
+    alpha_sum: np.ndarray      # [M]
+    beta: np.ndarray           # [M]
+    beta_sum: np.ndarray       # [M]
+    gamma: np.ndarray          # [M]
+    p_a: np.ndarray            # [M][M]
+    p_b: np.ndarray            # [M][M]
+    inactive: np.ndarray = None  # [K] uint8 or None
+
+    @staticmethod
+    def defaults(K, V, alpha=0.1, beta=0.01, p_a=0.31, p_b=1.0, inactive=None):
+        """PTM:207-214 (alpha[m][.]=alpha, alphaSum=K*alpha, gamma=1, beta) + betaSum=beta*V_m PTM:420.
+        p_a = 0.31 is iteration 1 of the burn-in schedule PTM:1168."""
+        M = len(V)
+        return Hyper(alpha=np.full((M, K + 1), alpha, dtype=np.float64),
+                     alpha_sum=np.full(M, K * alpha, dtype=np.float64),
+                     beta=np.full(M, beta, dtype=np.float64),
+                     beta_sum=np.array([beta * v for v in V], dtype=np.float64),
+                     gamma=np.ones(M, dtype=np.float64),
+                     p_a=np.full((M, M), p_a, dtype=np.float64),
+                     p_b=np.full((M, M), p_b, dtype=np.float64),
+                     inactive=None if inactive is None else np.asarray(inactive, dtype=np.uint8))
+
+
+@dataclass
+class SweepStats:
+    tokens: int = 0
+    changed: int = 0
+    new_mass_cnt: int = 0
+    topic_doc_mass_cnt: int = 0
+    word_ftree_mass_cnt: int = 0
+    oov_skipped: int = 0
+    aborted_docs: int = 0
+    exact_fallbacks: int = 0
+    activated_topic: int = -1
+    activated_modality: int = -1
+    activation_key: int = 0
+    sweep_kernel_ms: float = 0.0
+    total_ms: float = 0.0
+    dbg: list = field(default=None, repr=False)
+    trace: np.ndarray = field(default=None, repr=False)
+
+
+class NativeSampler:
+    def __init__(self, K, V, device=0, doc_id_base=0):
+        self.L = load_library()
+        self.K = int(K)
+        self.V = [int(v) for v in V]
+        self.M = len(self.V)
+        if self.M > MAX_M:
+            raise ValueError("too many modalities")
+        cfg = Config()
+        cfg.num_topics = self.K
+        cfg.num_modalities = self.M
+        for m, v in enumerate(self.V):
+            cfg.num_types[m] = v
+        cfg.device = int(device)
+        cfg.doc_id_base = int(doc_id_base)
+        self.h = C.c_void_p()
+        rc = self.L.mvhdp_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.mvhdp_last_error(None).decode()
+            self.h = None
+            raise MvhdpError(rc, msg)
+        self.N = [0] * self.M
+        self.D = 0
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mvhdp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MvhdpError(rc, self.L.mvhdp_last_error(self.h).decode())
+
+    # -- corpus / assignments ----------------------------------------------
+    def set_corpus(self, m, doc_off, tokens):
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        if doc_off.ndim != 1 or len(doc_off) < 1 or len(tokens) != int(doc_off[-1]):
+            raise ValueError("doc_off/tokens shape mismatch")
+        self._ck(self.L.mvhdp_set_corpus(self.h, m, len(doc_off) - 1, _ptr(doc_off), _ptr(tokens)))
+        self.D = len(doc_off) - 1
+        self.N[m] = int(doc_off[-1])
+
+    def set_assignments(self, m, z):
+        z = np.ascontiguousarray(z, dtype=np.int32)
+        if len(z) != self.N[m]:
+            raise ValueError("z length mismatch")
+        self._ck(self.L.mvhdp_set_assignments(self.h, m, _ptr(z)))
+
+    def get_assignments(self, m):
+        z = np.empty(self.N[m], dtype=np.int32)
+        self._ck(self.L.mvhdp_get_assignments(self.h, m, _ptr(z)))
+        return z
+
+    # -- model state --------------------------------------------------------
+    def set_hyper(self, hy: Hyper):
+        M, K = self.M, self.K
+        hc = HyperC()
+        self._alpha_keep = np.ascontiguousarray(hy.alpha, dtype=np.float64).reshape(M, K + 1)
+        hc.alpha = self._alpha_keep.ctypes.data
+        for m in range(M):
+            hc.alpha_sum[m] = float(hy.alpha_sum[m]); hc.beta[m] = float(hy.beta[m])
+            hc.beta_sum[m] = float(hy.beta_sum[m]); hc.gamma[m] = float(hy.gamma[m])
+            for j in range(M):
+                hc.p_a[m][j] = float(hy.p_a[m][j]); hc.p_b[m][j] = float(hy.p_b[m][j])
+        self._inactive_keep = None
+        if hy.inactive is not None:
+            self._inactive_keep = np.ascontiguousarray(hy.inactive, dtype=np.uint8).reshape(K)
+            hc.inactive = self._inactive_keep.ctypes.data
+        self._ck(self.L.mvhdp_set_hyper(self.h, C.byref(hc)))
+
+    def get_alpha(self):
+        a = np.empty((self.M, self.K + 1), dtype=np.float64)
+        ina = np.empty(self.K, dtype=np.uint8)
+        self._ck(self.L.mvhdp_get_alpha(self.h, _ptr(a), _ptr(ina)))
+        return a, ina
+
+    def build_counts(self):
+        self._ck(self.L.mvhdp_build_counts(self.h))
+
+    def build_trees(self):
+        self._ck(self.L.mvhdp_build_trees(self.h))
+
+    def get_counts(self, m):
+        nwk = np.empty((self.V[m], self.K), dtype=np.int32)
+        nk = np.empty(self.K, dtype=np.int32)
+        self._ck(self.L.mvhdp_get_counts(self.h, m, _ptr(nwk), _ptr(nk)))
+        return nwk, nk
+
+    def set_counts(self, m, nwk, nk):
+        nwk = np.ascontiguousarray(nwk, dtype=np.int32)
+        nk = np.ascontiguousarray(nk, dtype=np.int32)
+        assert nwk.shape == (self.V[m], self.K) and nk.shape == (self.K,)
+        self._ck(self.L.mvhdp_set_counts(self.h, m, _ptr(nwk), _ptr(nk)))
+
+    def get_tree(self, m, w):
+        t = np.empty(2 * self.K, dtype=np.float64)
+        self._ck(self.L.mvhdp_get_tree(self.h, m, w, _ptr(t)))
+        return t
+
+    def get_doc_topic_hist(self, m, hist_len, len_len=0):
+        hist = np.empty((self.K, hist_len), dtype=np.int32)
+        dl = np.empty(max(len_len, 1), dtype=np.int32) if len_len > 0 else None
+        self._ck(self.L.mvhdp_get_doc_topic_hist(self.h, m, _ptr(hist), hist_len, _ptr(dl), len_len))
+        return hist, (dl[:len_len] if dl is not None else None)
+
+    # -- the hot path ---------------------------------------------------------
+    def sweep(self, sweep_idx, seed, flags=0, p=None, want_dbg=False, trace=None) -> SweepStats:
+        st = SweepStatsC()
+        if p is not None:
+            p = np.ascontiguousarray(p, dtype=np.float64)
+            if p.shape != (self.D, self.M, self.M):
+                raise ValueError("p override must be [D][M][M]")
+        dbgc = None
+        dbg_arrays = None
+        tout = None
+        keep = []
+        if want_dbg or trace:
+            dbgc = DebugC()
+            if want_dbg:
+                dbg_arrays = [np.zeros((max(self.N[m], 1), 4), dtype=np.float64) for m in range(self.M)]
+                for m in range(self.M):
+                    dbgc.tok_dbg[m] = dbg_arrays[m].ctypes.data
+            if trace:
+                td = np.ascontiguousarray([t[0] for t in trace], dtype=np.int64)
+                tv = np.ascontiguousarray([t[1] for t in trace], dtype=np.int32)
+                tp = np.ascontiguousarray([t[2] for t in trace], dtype=np.int32)
+                tout = np.zeros((len(trace), self.K + 1), dtype=np.float64)
+                keep += [td, tv, tp]
+                dbgc.n_trace = len(trace)
+                dbgc.trace_doc = td.ctypes.data; dbgc.trace_view = tv.ctypes.data
+                dbgc.trace_pos = tp.ctypes.data; dbgc.trace_out = tout.ctypes.data
+        rc = self.L.mvhdp_sweep(self.h, int(sweep_idx), int(seed), int(flags), _ptr(p),
+                                C.byref(dbgc) if dbgc is not None else None, C.byref(st))
+        self._ck(rc)
+        out = SweepStats(**{f: getattr(st, f) for f, _ in SweepStatsC._fields_})
+        if dbg_arrays is not None:
+            out.dbg = [a[: self.N[m]] for m, a in enumerate(dbg_arrays)]
+        out.trace = tout
+        return out
+
+    def apply_delta(self, activated_topic=-1, activated_modality=-1):
+        self._ck(self.L.mvhdp_apply_delta(self.h, int(activated_topic), int(activated_modality)))
+
+    def get_view_weights(self):
+        p = np.empty((self.D, self.M, self.M), dtype=np.float64)
+        self._ck(self.L.mvhdp_get_view_weights(self.h, _ptr(p)))
+        return p
+
+    # -- interop ----------------------------------------------------------------
+    def device_buffer(self, which):
+        ptr = C.c_void_p()
+        nbytes = C.c_size_t()
+        self._ck(self.L.mvhdp_device_buffer(self.h, int(which), C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def set_stream(self, hip_stream):
+        self._ck(self.L.mvhdp_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self._ck(self.L.mvhdp_synchronize(self.h))

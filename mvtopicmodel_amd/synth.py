@@ -1,0 +1,161 @@
+"""Deterministic synthetic multi-view corpora: no files, no
+global RNG state — every draw is splitmix64(seed, stream, index).
+
+K_true = K/2 latent topics.  Entity d: T_d = 1+Poisson(3) topics chosen
+uniformly, weights theta_d ~ Dirichlet(1) shared by all views.  View v, latent
+topic t: word = (r*A[v][t] + B[v][t]) mod V_v with rank r log-uniform over
+[0, V_v) (~Zipf s=1) and A odd and coprime to V_v.  Side views are present
+with probability 0.8 (an absent view is an empty CSR span = Assignments[m]==null,
+MTA:19).  Lengths are 1+Poisson(lambda_v), or Pareto(1.5) truncated at 2048 for
+the power-law config C5.
+"""
+from dataclasses import dataclass
+from math import gcd
+
+import numpy as np
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix(x):
+    x = x.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def rand_u64(seed, stream, start, n):
+    """n values of the counter-based generator for counters start..start+n-1."""
+    with np.errstate(over="ignore"):
+        base = _mix(np.array([np.uint64(seed) ^ (np.uint64(stream) * np.uint64(0xD1B54A32D192ED03))], dtype=np.uint64))[0]
+        idx = np.arange(start, start + n, dtype=np.uint64)
+        return _mix(base + (idx + np.uint64(1)) * _GOLD)
+
+
+def rand_unit(seed, stream, start, n):
+    return (rand_u64(seed, stream, start, n) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
+def _poisson_from_unit(u, lam):
+    """Inverse-CDF Poisson (table up to lam + 12 sqrt(lam) + 20)."""
+    kmax = int(lam + 12 * np.sqrt(lam) + 20)
+    k = np.arange(kmax + 1, dtype=np.float64)
+    from math import lgamma
+    logp = -lam + k * np.log(lam) - np.array([lgamma(x + 1.0) for x in k])
+    cdf = np.cumsum(np.exp(logp))
+    cdf[-1] = 1.0
+    return np.searchsorted(cdf, u, side="right").astype(np.int64)
+
+
+@dataclass
+class Corpus:
+    K: int
+    V: list                 # vocabulary size per view
+    doc_off: list           # per view int64[D+1]
+    tokens: list            # per view int32[N_m]
+    name: str = ""
+
+    @property
+    def M(self):
+        return len(self.V)
+
+    @property
+    def D(self):
+        return len(self.doc_off[0]) - 1
+
+    @property
+    def total_tokens(self):
+        return int(sum(int(o[-1]) for o in self.doc_off))
+
+    def slice_docs(self, lo, hi):
+        """Contiguous entity range [lo,hi) as its own corpus (document shards)."""
+        offs, toks = [], []
+        for m in range(self.M):
+            o = self.doc_off[m]
+            offs.append((o[lo:hi + 1] - o[lo]).astype(np.int64))
+            toks.append(self.tokens[m][o[lo]:o[hi]].copy())
+        return Corpus(self.K, list(self.V), offs, toks, f"{self.name}[{lo}:{hi}]")
+
+
+def generate(K, V, D, lam, seed, presence=None, power_law_text=False, chunk_docs=8192, name=""):
+    """Generate a corpus.  lam[v] = Poisson mean of the length of view v."""
+    M = len(V)
+    if presence is None:
+        presence = [1.0] + [0.8] * (M - 1)
+    K_true = max(1, K // 2)
+    # per (view, latent topic) affine permutations
+    A = np.zeros((M, K_true), dtype=np.int64)
+    B = np.zeros((M, K_true), dtype=np.int64)
+    for v in range(M):
+        a = (rand_u64(seed, 100 + v, 0, K_true) % np.uint64(V[v])).astype(np.int64)
+        b = (rand_u64(seed, 200 + v, 0, K_true) % np.uint64(V[v])).astype(np.int64)
+        for t in range(K_true):
+            x = int(a[t]) | 1
+            while gcd(x, V[v]) != 1:
+                x += 2
+            A[v, t] = x % V[v] if V[v] > 1 else 0
+        B[v] = b
+    doc_off = [np.zeros(D + 1, dtype=np.int64) for _ in range(M)]
+    tok_chunks = [[] for _ in range(M)]
+    tok_counter = [0] * M
+    TMAX = 24
+    for c0 in range(0, D, chunk_docs):
+        c1 = min(D, c0 + chunk_docs)
+        n = c1 - c0
+        T = 1 + _poisson_from_unit(rand_unit(seed, 1, c0, n), 3.0)
+        T = np.minimum(T, TMAX)
+        tmax = int(T.max())
+        # latent topics and Dirichlet(1) weights of each entity
+        tt = (rand_u64(seed, 2, c0 * TMAX, n * TMAX).reshape(n, TMAX)[:, :tmax] % np.uint64(K_true)).astype(np.int64)
+        e = -np.log(1.0 - rand_unit(seed, 3, c0 * TMAX, n * TMAX).reshape(n, TMAX)[:, :tmax])
+        e[np.arange(tmax)[None, :] >= T[:, None]] = 0.0
+        cum = np.cumsum(e, axis=1)
+        cum /= cum[:, -1:]
+        for v in range(M):
+            pres = rand_unit(seed, 10 + v, c0, n) < presence[v]
+            if power_law_text and v == 0:
+                u = 1.0 - rand_unit(seed, 20 + v, c0, n)
+                L = np.minimum(2048, np.floor(32.0 * u ** (-1.0 / 1.5))).astype(np.int64)
+            else:
+                L = 1 + _poisson_from_unit(rand_unit(seed, 20 + v, c0, n), float(lam[v]))
+            L = np.where(pres, L, 0)
+            doc_off[v][c0 + 1:c1 + 1] = L
+            nt = int(L.sum())
+            if nt == 0:
+                continue
+            doc_of = np.repeat(np.arange(n), L)
+            ut = rand_unit(seed, 30 + v, tok_counter[v], nt)
+            j = (cum[doc_of] < ut[:, None]).sum(axis=1)
+            j = np.minimum(j, T[doc_of] - 1)
+            t = tt[doc_of, j]
+            ur = rand_unit(seed, 40 + v, tok_counter[v], nt)
+            r = np.floor(np.exp(ur * np.log(V[v] + 1.0))).astype(np.int64) - 1
+            r = np.clip(r, 0, V[v] - 1)
+            w = (r * A[v, t] + B[v, t]) % V[v]
+            tok_chunks[v].append(w.astype(np.int32))
+            tok_counter[v] += nt
+    tokens = []
+    for v in range(M):
+        np.cumsum(doc_off[v], out=doc_off[v])
+        tokens.append(np.concatenate(tok_chunks[v]) if tok_chunks[v] else np.zeros(0, dtype=np.int32))
+    return Corpus(K, list(V), doc_off, tokens, name)
+
+
+# BASELINE.json configs; `scale` shrinks the entity count for tests.
+CONFIGS = {
+    "C2": dict(K=100, V=[20000], D=50_000, lam=[127], seed=0x5EED0002),
+    "C3": dict(K=200, V=[50000, 5000, 5000], D=200_000, lam=[127, 7, 15], seed=0x5EED0003),
+    "C4": dict(K=400, V=[50000, 5000, 5000], D=1_000_000, lam=[127, 7, 15], seed=0x5EED0004),
+    "C5": dict(K=1000, V=[50000, 5000, 5000, 5000, 5000], D=1_000_000, lam=[96, 7, 7, 7, 7],
+               seed=0x5EED0005, power_law_text=True),
+}
+
+
+def make_config(name, D=None):
+    c = dict(CONFIGS[name])
+    if D is not None:
+        c["D"] = int(D)
+    return generate(c["K"], c["V"], c["D"], c["lam"], c["seed"],
+                    power_law_text=c.get("power_law_text", False), name=name)

@@ -1,0 +1,776 @@
+/*
+ * mvhdp_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ * See mvhdp_oracle.h for the scope statement.  Plain C; build with
+ * -ffp-contract=off so that no a*b+c is fused (Java never fuses).
+ *
+ * Reference aliases (all under /root/reference/src/main/java/org/madgik/):
+ *   WRK = MVTopicModel/FastQMVWVWorkerRunnable.java
+ *   UPD = MVTopicModel/FastQMVWVUpdaterRunnable.java
+ *   PTM = MVTopicModel/FastQMVWVParallelTopicModel.java
+ *   FT  = utils/FTree.java      QD = utils/FastQDelta.java
+ * Third-party arithmetic (cc.mallet:mallet:2.0.8, class files only in the
+ * reference) is restated from its published algorithm: Randoms.nextUniform /
+ * nextGaussian / nextBeta, and java.util.Random from its documented contract.
+ */
+#include "mvhdp_oracle.h"
+#include "mvhdp_oracle_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================== */
+/* Philox4x32-10 (Random123)                                                 */
+/* ======================================================================== */
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline double bits_to_unit(uint32_t hi, uint32_t lo)
+{
+    /* same 53-bit shape as ThreadLocalRandom.nextDouble() (WRK:517,534) */
+    uint64_t x = ((uint64_t)hi << 32) | lo;
+    return (double)(x >> 11) * 0x1.0p-53;
+}
+
+void orc_token_uniforms(uint64_t seed, uint32_t sweep, int64_t doc, int view, uint32_t pos,
+                        double* u1, double* u2)
+{
+    uint32_t ctr[4] = { pos, (uint32_t)view, (uint32_t)doc, sweep };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)((uint64_t)doc >> 32) };
+    uint32_t x[4];
+    orc_philox4x32_10(ctr, key, x);
+    *u1 = bits_to_unit(x[0], x[1]);
+    *u2 = bits_to_unit(x[2], x[3]);
+}
+
+/* ======================================================================== */
+/* java.util.Random + MALLET Randoms                                         */
+/* ======================================================================== */
+
+void orc_jrand_seed(orc_jrand* r, int64_t seed)
+{
+    r->s = ((uint64_t)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1);
+    r->have_gauss = 0;
+    r->next_gauss = 0.0;
+}
+
+int32_t orc_jrand_next(orc_jrand* r, int bits)
+{
+    r->s = (r->s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+    return (int32_t)(uint32_t)(r->s >> (48 - bits));
+}
+
+int32_t orc_jrand_next_int(orc_jrand* r, int32_t bound)
+{
+    /* java.util.Random.nextInt(int), used by PTM:500,503,506 */
+    int32_t rr = orc_jrand_next(r, 31);
+    int32_t m = bound - 1;
+    if ((bound & m) == 0) {
+        rr = (int32_t)(((int64_t)bound * (int64_t)rr) >> 31);
+    } else {
+        int32_t u = rr;
+        for (;;) {
+            rr = u % bound;
+            /* Java int arithmetic wraps */
+            int32_t chk = (int32_t)((uint32_t)u - (uint32_t)rr + (uint32_t)m);
+            if (chk >= 0) break;
+            u = orc_jrand_next(r, 31);
+        }
+    }
+    return rr;
+}
+
+double orc_mallet_next_uniform(orc_jrand* r)
+{
+    int64_t hi = orc_jrand_next(r, 26);
+    int64_t lo = orc_jrand_next(r, 27);
+    int64_t l = (hi << 27) + lo;
+    return (double)l / (double)(1LL << 53);
+}
+
+double orc_mallet_next_gaussian(orc_jrand* r)
+{
+    if (!r->have_gauss) {
+        double v1 = orc_mallet_next_uniform(r), v2 = orc_mallet_next_uniform(r);
+        double x1 = sqrt(-2 * log(v1)) * cos(2 * M_PI * v2);
+        double x2 = sqrt(-2 * log(v1)) * sin(2 * M_PI * v2);
+        r->next_gauss = x2;
+        r->have_gauss = 1;
+        return x1;
+    } else {
+        r->have_gauss = 0;
+        return r->next_gauss;
+    }
+}
+
+/* Generic over the uniform source so that the LCG stream (reference worker)
+ * and the Philox stream (device contract) run the very same algorithm. */
+typedef struct {
+    int kind;               /* 0 = LCG, 1 = Philox */
+    orc_jrand* lcg;
+    uint32_t ctr1, ctr2, ctr3; uint32_t key[2];
+    uint32_t n;             /* Philox: next uniform index */
+    int have_gauss; double next_gauss;
+} usrc;
+
+static double usrc_uniform(usrc* s)
+{
+    if (s->kind == 0) return orc_mallet_next_uniform(s->lcg);
+    uint32_t ctr[4] = { s->n >> 1, s->ctr1, s->ctr2, s->ctr3 };
+    uint32_t x[4];
+    orc_philox4x32_10(ctr, s->key, x);
+    double u = (s->n & 1) ? bits_to_unit(x[2], x[3]) : bits_to_unit(x[0], x[1]);
+    s->n++;
+    return u;
+}
+
+static double usrc_gaussian(usrc* s)
+{
+    if (s->kind == 0) return orc_mallet_next_gaussian(s->lcg);
+    if (!s->have_gauss) {
+        double v1 = usrc_uniform(s), v2 = usrc_uniform(s);
+        double x1 = sqrt(-2 * log(v1)) * cos(2 * M_PI * v2);
+        double x2 = sqrt(-2 * log(v1)) * sin(2 * M_PI * v2);
+        s->next_gauss = x2;
+        s->have_gauss = 1;
+        return x1;
+    } else {
+        s->have_gauss = 0;
+        return s->next_gauss;
+    }
+}
+
+/* MALLET Randoms.nextBeta(alpha, beta).  Note the reference quirk kept here:
+ * for alpha>=1, beta==1 the term B*log((1-x)/B) is 0*inf = NaN, the rejection
+ * comparison is false, and the first in-range Gaussian proposal is returned. */
+static double usrc_beta(usrc* s, double alpha, double beta)
+{
+    if (alpha == 1 && beta == 1) {
+        return usrc_uniform(s);
+    } else if (alpha >= 1 && beta >= 1) {
+        double A = alpha - 1, B = beta - 1, C = A + B, L = C * log(C),
+               mu = A / C, sigma = 0.5 / sqrt(C);
+        double y = usrc_gaussian(s), x = sigma * y + mu;
+        while (x < 0 || x > 1) {
+            y = usrc_gaussian(s);
+            x = sigma * y + mu;
+        }
+        double u = usrc_uniform(s);
+        while (log(u) >= A * log(x / A) + B * log((1 - x) / B) + L + 0.5 * y * y) {
+            y = usrc_gaussian(s);
+            x = sigma * y + mu;
+            while (x < 0 || x > 1) {
+                y = usrc_gaussian(s);
+                x = sigma * y + mu;
+            }
+            u = usrc_uniform(s);
+        }
+        return x;
+    } else {
+        double v1 = pow(usrc_uniform(s), 1 / alpha), v2 = pow(usrc_uniform(s), 1 / beta);
+        while (v1 + v2 > 1) {
+            v1 = pow(usrc_uniform(s), 1 / alpha);
+            v2 = pow(usrc_uniform(s), 1 / beta);
+        }
+        return v1 / (v1 + v2);
+    }
+}
+
+double orc_mallet_next_beta(orc_jrand* r, double a, double b)
+{
+    usrc s; memset(&s, 0, sizeof s); s.kind = 0; s.lcg = r;
+    return usrc_beta(&s, a, b);
+}
+
+int64_t orc_java_round(double x)
+{
+    /* Java 8 Math.round: floor(x + 1/2) computed without the double-rounding bug */
+    if (isnan(x)) return 0;
+    double f = floor(x);
+    double d = x - f;
+    if (d >= 0.5) f += 1.0;
+    return (int64_t)f;
+}
+
+/* ======================================================================== */
+/* FTree (FT)                                                                */
+/* ======================================================================== */
+
+void orc_ftree_construct(double* tree, int size, const double* weights)
+{
+    /* FT:96-109 */
+    for (int i = 0; i < 2 * size; i++) tree[i] = 0;
+    for (int i = 2 * size - 1; i > 0; --i) {
+        if (i >= size) tree[i] = weights[i - size];
+        else tree[i] = tree[2 * i] + tree[2 * i + 1];
+    }
+}
+
+int orc_ftree_sample(const double* tree, int size, double u)
+{
+    /* FT:111-136 */
+    if (u > 1) return -2; /* IllegalArgumentException */
+    int i = 1;
+    u = u * tree[i];
+    while (i < size) {
+        if (u < tree[2 * i]) {
+            i = 2 * i;
+        } else {
+            u = u - tree[2 * i];
+            i = 2 * i + 1;
+        }
+    }
+    return i - size;
+}
+
+void orc_ftree_update(double* tree, int size, int topic, double new_value)
+{
+    /* FT:138-147 */
+    int i = topic + size;
+    double delta = new_value - tree[i];
+    while (i > 0) {
+        tree[i] += delta;
+        i = i / 2;
+    }
+}
+
+int orc_lower_bound(const double* arr, double key, int len)
+{
+    /* WRK:257-277 (note: reads arr[mid] with mid = (0 + -1)/2 = 0 when len==0,
+     * exactly like the Java, callers never pass len==0 on the live path) */
+    int lo = 0;
+    int hi = len - 1;
+    int mid = (lo + hi) / 2;
+    for (;;) {
+        if (arr[mid] >= key) {
+            hi = mid - 1;
+            if (hi < lo) return mid;
+        } else {
+            lo = mid + 1;
+            if (hi < lo) return mid < len - 1 ? mid + 1 : -1;
+        }
+        mid = (lo + hi) / 2;
+    }
+}
+
+/* ======================================================================== */
+/* model                                                                     */
+/* ======================================================================== */
+
+/* struct orc_model lives in mvhdp_oracle_internal.h (shared with ref_threaded.c) */
+
+orc_model* orc_create(int K, int M, const int32_t* V)
+{
+    if (K <= 0 || M <= 0 || M > ORC_MAX_M) return NULL;
+    orc_model* o = (orc_model*)calloc(1, sizeof *o);
+    o->K = K; o->M = M;
+    o->rowbase[0] = 0;
+    for (int m = 0; m < M; m++) { o->V[m] = V[m]; o->rowbase[m + 1] = o->rowbase[m] + V[m]; }
+    int64_t sumV = o->rowbase[M];
+    o->nwk = (int32_t*)calloc((size_t)sumV * K, sizeof(int32_t));
+    o->nk = (int32_t*)calloc((size_t)M * K, sizeof(int32_t));
+    o->trees = (double*)calloc((size_t)sumV * 2 * K, sizeof(double));
+    o->alpha = (double*)calloc((size_t)M * (K + 1), sizeof(double));
+    o->inactive = (uint8_t*)calloc((size_t)K, 1);
+    /* PTM:207-214 defaults are set by the caller through orc_set_hyper */
+    return o;
+}
+
+void orc_destroy(orc_model* o)
+{
+    if (!o) return;
+    for (int m = 0; m < o->M; m++) { free(o->doc_off[m]); free(o->tokens[m]); free(o->z[m]); }
+    free(o->nwk); free(o->nk); free(o->trees); free(o->alpha); free(o->inactive);
+    free(o);
+}
+
+int orc_set_corpus(orc_model* o, int m, int64_t D, const int64_t* doc_off, const int32_t* tokens)
+{
+    if (m < 0 || m >= o->M) return -1;
+    if (m > 0 && o->doc_off[0] && D != o->D) return -2;
+    o->D = D;
+    free(o->doc_off[m]); free(o->tokens[m]); free(o->z[m]);
+    int64_t N = doc_off[D];
+    o->N[m] = N;
+    o->doc_off[m] = (int64_t*)malloc((size_t)(D + 1) * sizeof(int64_t));
+    memcpy(o->doc_off[m], doc_off, (size_t)(D + 1) * sizeof(int64_t));
+    o->tokens[m] = (int32_t*)malloc((size_t)(N > 0 ? N : 1) * sizeof(int32_t));
+    memcpy(o->tokens[m], tokens, (size_t)N * sizeof(int32_t));
+    o->z[m] = (int32_t*)malloc((size_t)(N > 0 ? N : 1) * sizeof(int32_t));
+    for (int64_t i = 0; i < N; i++) o->z[m][i] = -1; /* UNASSIGNED_TOPIC PTM:63 */
+    return 0;
+}
+
+int orc_set_assignments(orc_model* o, int m, const int32_t* z)
+{
+    if (m < 0 || m >= o->M || !o->z[m]) return -1;
+    memcpy(o->z[m], z, (size_t)o->N[m] * sizeof(int32_t));
+    return 0;
+}
+
+int orc_get_assignments(const orc_model* o, int m, int32_t* z)
+{
+    if (m < 0 || m >= o->M || !o->z[m]) return -1;
+    memcpy(z, o->z[m], (size_t)o->N[m] * sizeof(int32_t));
+    return 0;
+}
+
+void orc_set_hyper(orc_model* o, const double* alpha, const double* alpha_sum,
+                   const double* beta, const double* beta_sum, const double* gamma,
+                   const double* p_a, const double* p_b, const uint8_t* inactive)
+{
+    int M = o->M, K = o->K;
+    memcpy(o->alpha, alpha, (size_t)M * (K + 1) * sizeof(double));
+    for (int m = 0; m < M; m++) {
+        o->alpha_sum[m] = alpha_sum[m]; o->beta[m] = beta[m];
+        o->beta_sum[m] = beta_sum[m];   o->gamma[m] = gamma[m];
+        for (int j = 0; j < M; j++) { o->p_a[m][j] = p_a[m * M + j]; o->p_b[m][j] = p_b[m * M + j]; }
+    }
+    if (inactive) memcpy(o->inactive, inactive, (size_t)K);
+    else memset(o->inactive, 0, (size_t)K);
+}
+
+void orc_get_alpha(const orc_model* o, double* alpha)
+{
+    memcpy(alpha, o->alpha, (size_t)o->M * (o->K + 1) * sizeof(double));
+}
+
+void orc_get_inactive(const orc_model* o, uint8_t* inactive)
+{
+    memcpy(inactive, o->inactive, (size_t)o->K);
+}
+
+void orc_init_assignments(orc_model* o, int64_t seed)
+{
+    /* PTM:465-515 with previousModel == null; `random` = Randoms(randomSeed) PTM:404-408 */
+    orc_jrand r; orc_jrand_seed(&r, seed);
+    int K = o->K, M = o->M;
+    int32_t* active = NULL; int64_t cap = 0, n_active = 0;
+    for (int64_t d = 0; d < o->D; d++) {
+        for (int m = 0; m < M; m++) {
+            if (m == 0) n_active = 0;                                /* PTM:470-472 */
+            if (!o->doc_off[m]) continue;
+            int64_t b = o->doc_off[m][d], e = o->doc_off[m][d + 1];
+            for (int64_t i = b; i < e; i++) {
+                int topic;
+                if (m == 0) {
+                    topic = orc_jrand_next_int(&r, K);               /* PTM:500 */
+                    if (n_active == cap) { cap = cap ? 2 * cap : 256; active = (int32_t*)realloc(active, (size_t)cap * sizeof(int32_t)); }
+                    active[n_active++] = topic;                      /* PTM:501 */
+                } else if (n_active > 0) {
+                    int ind = orc_jrand_next_int(&r, (int32_t)n_active); /* PTM:503 */
+                    topic = active[ind];
+                } else {
+                    topic = orc_jrand_next_int(&r, K);               /* PTM:506 */
+                }
+                o->z[m][i] = topic;
+            }
+        }
+    }
+    free(active);
+}
+
+void orc_build_counts(orc_model* o)
+{
+    /* PTM:600-652 */
+    int K = o->K, M = o->M;
+    memset(o->nwk, 0, (size_t)o->rowbase[M] * K * sizeof(int32_t));
+    memset(o->nk, 0, (size_t)M * K * sizeof(int32_t));
+    for (int m = 0; m < M; m++) {
+        if (!o->doc_off[m]) continue;
+        for (int64_t i = 0; i < o->N[m]; i++) {
+            int topic = o->z[m][i];
+            if (topic == -1) continue;                               /* PTM:634 */
+            o->nk[(size_t)m * K + topic]++;                          /* PTM:640 */
+            int type = o->tokens[m][i];
+            o->nwk[(size_t)(o->rowbase[m] + type) * K + topic]++;    /* PTM:643 */
+        }
+    }
+}
+
+void orc_build_trees(orc_model* o)
+{
+    /* PTM:2660-2696 (useVectorsLambda == 0 path) */
+    int K = o->K, M = o->M;
+    double* temp = (double*)malloc((size_t)K * sizeof(double));
+    int any_inactive = 0;
+    for (int k = 0; k < K; k++) any_inactive |= o->inactive[k];
+    for (int m = 0; m < M; m++) {
+        for (int w = 0; w < o->V[m]; ++w) {
+            const int32_t* cnt = o->nwk + (size_t)(o->rowbase[m] + w) * K;
+            for (int t = 0; t < K; t++) {
+                if (any_inactive && o->inactive[t]) {
+                    temp[t] = 0;
+                } else {
+                    double p_wt = (cnt[t] + o->beta[m]) / (o->nk[(size_t)m * K + t] + o->beta_sum[m]);
+                    temp[t] = o->gamma[m] * o->alpha[(size_t)m * (K + 1) + t] * p_wt;
+                }
+            }
+            orc_ftree_construct(o->trees + (size_t)(o->rowbase[m] + w) * 2 * K, K, temp);
+        }
+    }
+    free(temp);
+}
+
+void orc_get_counts(const orc_model* o, int m, int32_t* nwk, int32_t* nk)
+{
+    int K = o->K;
+    if (nwk) memcpy(nwk, o->nwk + (size_t)o->rowbase[m] * K, (size_t)o->V[m] * K * sizeof(int32_t));
+    if (nk) memcpy(nk, o->nk + (size_t)m * K, (size_t)K * sizeof(int32_t));
+}
+
+void orc_set_counts(orc_model* o, int m, const int32_t* nwk, const int32_t* nk)
+{
+    int K = o->K;
+    if (nwk) memcpy(o->nwk + (size_t)o->rowbase[m] * K, nwk, (size_t)o->V[m] * K * sizeof(int32_t));
+    if (nk) memcpy(o->nk + (size_t)m * K, nk, (size_t)K * sizeof(int32_t));
+}
+
+void orc_get_tree(const orc_model* o, int m, int w, double* tree2K)
+{
+    memcpy(tree2K, o->trees + (size_t)(o->rowbase[m] + w) * 2 * o->K, (size_t)2 * o->K * sizeof(double));
+}
+
+void orc_get_doc_topic_hist(const orc_model* o, int m, int32_t* hist, int32_t hist_len,
+                            int32_t* doc_len_counts, int32_t len_len)
+{
+    /* PTM:620-651: for every entity that has view m (here: non-empty span),
+     * docLengthCounts[m][len]++ and topicDocCounts[m][k][n_dk]++ for ALL k. */
+    int K = o->K;
+    if (hist) memset(hist, 0, (size_t)K * hist_len * sizeof(int32_t));
+    if (doc_len_counts) memset(doc_len_counts, 0, (size_t)len_len * sizeof(int32_t));
+    int32_t* local = (int32_t*)calloc((size_t)K, sizeof(int32_t));
+    for (int64_t d = 0; d < o->D; d++) {
+        int64_t b = o->doc_off[m][d], e = o->doc_off[m][d + 1];
+        if (e == b) continue;
+        if (doc_len_counts && e - b < len_len) doc_len_counts[e - b]++;
+        memset(local, 0, (size_t)K * sizeof(int32_t));
+        for (int64_t i = b; i < e; i++) if (o->z[m][i] != -1) local[o->z[m][i]]++;
+        if (hist) for (int k = 0; k < K; k++) if (local[k] < hist_len) hist[(size_t)k * hist_len + local[k]]++;
+    }
+    free(local);
+}
+
+/* ------------------------------------------------------------------------ */
+/* view weights p (WRK:327-337)                                              */
+/* ------------------------------------------------------------------------ */
+
+static void fill_p_for_doc(const orc_model* o, usrc* s_lcg, uint64_t seed, uint32_t sweep,
+                           int64_t doc_global, double* p /* M*M */)
+{
+    int M = o->M;
+    for (int m = 0; m < M; m++) {
+        for (int j = m; j < M; j++) {
+            double pRand;
+            if (m == j) pRand = 1.0;
+            else if (o->p_a[m][j] == 0) pRand = 0;
+            else {
+                double b;
+                if (s_lcg) {
+                    b = usrc_beta(s_lcg, o->p_a[m][j], o->p_b[m][j]);
+                } else {
+                    usrc s; memset(&s, 0, sizeof s); s.kind = 1;
+                    s.ctr1 = 0x100u + (uint32_t)(m * M + j);
+                    s.ctr2 = (uint32_t)doc_global; s.ctr3 = sweep;
+                    s.key[0] = (uint32_t)seed;
+                    s.key[1] = (uint32_t)(seed >> 32) ^ (uint32_t)((uint64_t)doc_global >> 32);
+                    b = usrc_beta(&s, o->p_a[m][j], o->p_b[m][j]);
+                }
+                pRand = (double)orc_java_round(1000 * b) / (double)1000;   /* WRK:333 */
+            }
+            p[m * M + j] = (j != 0 && o->beta[j] == 0.0001) ? 0 : pRand;   /* WRK:335 */
+            p[j * M + m] = (m != 0 && o->beta[m] == 0.0001) ? 0 : pRand;   /* WRK:336 */
+        }
+    }
+}
+
+void orc_draw_p_mallet(const orc_model* o, orc_jrand* r, double* p)
+{
+    usrc s; memset(&s, 0, sizeof s); s.kind = 0; s.lcg = r;
+    for (int64_t d = 0; d < o->D; d++) fill_p_for_doc(o, &s, 0, 0, d, p + (size_t)d * o->M * o->M);
+}
+
+void orc_draw_p_philox(const orc_model* o, uint64_t seed, uint32_t sweep, int64_t doc_id_base, double* p)
+{
+    for (int64_t d = 0; d < o->D; d++)
+        fill_p_for_doc(o, NULL, seed, sweep, doc_id_base + d, p + (size_t)d * o->M * o->M);
+}
+
+/* ------------------------------------------------------------------------ */
+/* the sweep                                                                 */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { int32_t oldT, newT, type, mod; int64_t key; } delta_t; /* QD:12-36 (doc counts not needed: histograms are recomputed) */
+
+typedef struct {
+    delta_t* v; size_t n, cap;
+} delta_vec;
+
+static void dv_push(delta_vec* dv, delta_t d)
+{
+    if (dv->n == dv->cap) { dv->cap = dv->cap ? 2 * dv->cap : 1024; dv->v = (delta_t*)realloc(dv->v, dv->cap * sizeof(delta_t)); }
+    dv->v[dv->n++] = d;
+}
+
+/* WRK:301-601 for one entity against the snapshot (n_wk, n_k, trees).
+ * Returns 0, or 1 if the Java would have thrown inside the doc (Q11). */
+static int sample_one_doc(orc_model* o, int64_t d, int64_t doc_global, uint32_t sweep, uint64_t seed,
+                          const double* p /* M*M */, int first_inactive, orc_stats* st, delta_vec* dv,
+                          double* const* tok_dbg,
+                          int n_trace, const int64_t* trace_doc, const int32_t* trace_view,
+                          const int32_t* trace_pos, double* trace_out,
+                          /* scratch, all sized K / M*K: */
+                          int32_t* localTopicCounts, int32_t* localTopicIndex,
+                          double* topicDocWordMasses, double* totalMassOtherModalities)
+{
+    const int K = o->K, M = o->M;
+    int docLength[ORC_MAX_M];
+    memset(localTopicCounts, 0, (size_t)M * K * sizeof(int32_t));
+
+    for (int m = 0; m < M; m++) {                                            /* WRK:327-361 */
+        docLength[m] = 0;
+        if (o->doc_off[m]) {
+            int64_t b = o->doc_off[m][d], e = o->doc_off[m][d + 1];
+            docLength[m] = (int)(e - b);
+            for (int64_t i = b; i < e; i++) {
+                if (o->z[m][i] == -1) continue;
+                localTopicCounts[(size_t)m * K + o->z[m][i]]++;
+            }
+        }
+    }
+
+    int denseIndex = 0;                                                       /* WRK:376-391 */
+    for (int topic = 0; topic < K; topic++) {
+        int i = 0, found = 0;
+        while (i < M && !found) {
+            if (localTopicCounts[(size_t)i * K + topic] != 0) {
+                localTopicIndex[denseIndex] = topic;
+                denseIndex++;
+                found = 1;
+            }
+            i++;
+        }
+    }
+    int nonZeroTopics = denseIndex;
+
+    for (int m = 0; m < M; m++) {                                             /* WRK:393 */
+        for (int k = 0; k < K; k++) totalMassOtherModalities[k] = 0;          /* WRK:395 */
+        for (denseIndex = 0; denseIndex < nonZeroTopics; denseIndex++) {      /* WRK:399-410 */
+            int topic = localTopicIndex[denseIndex];
+            for (int i = 0; i < M; i++) {
+                if (i != m && docLength[i] != 0) {
+                    totalMassOtherModalities[topic] += p[m * M + i]
+                        * (localTopicCounts[(size_t)i * K + topic] + o->gamma[i] * o->alpha[(size_t)i * (K + 1) + topic])
+                        / (docLength[i] + (double)o->gamma[i] * o->alpha_sum[i]);
+                }
+            }
+            totalMassOtherModalities[topic] = totalMassOtherModalities[topic]
+                * (docLength[m] + (double)o->gamma[m] * o->alpha_sum[m]);
+        }
+        double newTopicMassAllModalities = 0;                                 /* WRK:413-418 */
+        for (int i = 0; i < M; i++) {
+            newTopicMassAllModalities += p[m * M + i] * (o->gamma[i] * o->alpha[(size_t)i * (K + 1) + K])
+                / (docLength[i] + (double)o->gamma[i] * o->alpha_sum[i]);
+        }
+        newTopicMassAllModalities = newTopicMassAllModalities * (docLength[m] + (double)o->gamma[m] * o->alpha_sum[m]);
+
+        if (docLength[m] == 0) continue;
+        const int64_t base = o->doc_off[m][d];
+        for (int position = 0; position < docLength[m]; position++) {         /* WRK:425 */
+            int type = o->tokens[m][base + position];
+            if (type >= o->V[m]) { st->oov_skipped++; continue; }             /* WRK:427-428 */
+            int oldTopic = o->z[m][base + position];
+            const int32_t* currentTypeTopicCounts = o->nwk + (size_t)(o->rowbase[m] + type) * K;
+            const double* currentTree = o->trees + (size_t)(o->rowbase[m] + type) * 2 * K;
+
+            if (oldTopic != -1) {                                             /* WRK:434-471 */
+                localTopicCounts[(size_t)m * K + oldTopic]--;
+                int isDeletedTopic = localTopicCounts[(size_t)m * K + oldTopic] == 0;
+                int jj = 0;
+                while (isDeletedTopic && jj < M) {
+                    isDeletedTopic = localTopicCounts[(size_t)jj * K + oldTopic] == 0;
+                    jj++;
+                }
+                if (isDeletedTopic) {
+                    denseIndex = 0;
+                    while (localTopicIndex[denseIndex] != oldTopic) {
+                        denseIndex++;
+                        if (denseIndex >= K) return 1; /* ArrayIndexOutOfBounds -> Q11 */
+                    }
+                    while (denseIndex < nonZeroTopics) {
+                        if (denseIndex < K - 1) localTopicIndex[denseIndex] = localTopicIndex[denseIndex + 1];
+                        denseIndex++;
+                    }
+                    nonZeroTopics--;
+                }
+            }
+
+            int newTopic = -1;
+            double topicDocWordMass = 0.0;                                    /* WRK:496-513 */
+            for (denseIndex = 0; denseIndex < nonZeroTopics; denseIndex++) {
+                int topic = localTopicIndex[denseIndex];
+                int n = localTopicCounts[(size_t)m * K + topic];
+                double p_wt = (currentTypeTopicCounts[topic] + o->beta[m]) / (o->nk[(size_t)m * K + topic] + o->beta_sum[m]);
+                topicDocWordMass += (p[m * M + m] * n + totalMassOtherModalities[topic]) * p_wt;
+                topicDocWordMasses[denseIndex] = topicDocWordMass;
+            }
+            double newTopicMass = (first_inactive < 0) ? 0 : newTopicMassAllModalities / K; /* WRK:515 */
+
+            double nextUniform, nextUniform2;
+            orc_token_uniforms(seed, sweep, doc_global, m, (uint32_t)position, &nextUniform, &nextUniform2);
+            double sample = nextUniform * (newTopicMass + topicDocWordMass + currentTree[1]); /* WRK:519 */
+
+            if (tok_dbg && tok_dbg[m]) {
+                double* g = tok_dbg[m] + (size_t)(base + position) * 4;
+                g[0] = newTopicMass; g[1] = topicDocWordMass; g[2] = currentTree[1]; g[3] = sample;
+            }
+            for (int t = 0; t < n_trace; t++) {
+                if (trace_doc[t] == d && trace_view[t] == m && trace_pos[t] == position) {
+                    /* full conditional: P(k) ∝ [k==firstInactive]*newMass
+                     *   + 1[k in dense]*term_k + leaf_k ; slot K holds newMass itself. */
+                    double* out = trace_out + (size_t)t * (K + 1);
+                    double tot = newTopicMass + topicDocWordMass + currentTree[1];
+                    for (int k = 0; k < K; k++) out[k] = currentTree[K + k] / tot;
+                    double prev = 0;
+                    for (int di = 0; di < nonZeroTopics; di++) {
+                        out[localTopicIndex[di]] += (topicDocWordMasses[di] - prev) / tot;
+                        prev = topicDocWordMasses[di];
+                    }
+                    out[K] = newTopicMass / tot;
+                }
+            }
+
+            if (sample < newTopicMass) {                                      /* WRK:522-526 */
+                st->new_mass_cnt++;
+                newTopic = first_inactive;
+            } else {
+                sample -= newTopicMass;
+                if (sample < topicDocWordMass) {                              /* WRK:529-531 */
+                    st->topic_doc_mass_cnt++;
+                    int lb = orc_lower_bound(topicDocWordMasses, sample, nonZeroTopics);
+                    if (lb < 0) return 1; /* localTopicIndex[-1] throws -> Q11 */
+                    newTopic = localTopicIndex[lb];
+                } else {                                                      /* WRK:533-535 */
+                    st->word_ftree_mass_cnt++;
+                    newTopic = orc_ftree_sample(currentTree, K, nextUniform2);
+                    if (newTopic == -2) return 1;
+                }
+            }
+            if (newTopic == -1) newTopic = K - 1;                             /* WRK:549-552 */
+
+            o->z[m][base + position] = newTopic;                              /* WRK:557 */
+            localTopicCounts[(size_t)m * K + newTopic]++;                     /* WRK:560 */
+            /* WRK:563-584: isNewTopic is evaluated after the increment, hence
+             * always false (Q1): the dense list never grows. */
+            st->tokens++;
+            if (newTopic != oldTopic) {                                       /* WRK:587-589 */
+                st->changed++;
+                delta_t dl = { oldTopic, newTopic, type, m, 0 };
+                dv_push(dv, dl);
+            }
+        }
+    }
+    return 0;
+}
+
+static void apply_deltas(orc_model* o, const delta_vec* dv, orc_stats* st, int32_t* delta_nwk, int32_t* delta_nk, int apply)
+{
+    /* UPD:181-272 as one updater draining one FIFO queue, minus the two
+     * FTree.update calls (trees are rebuilt from the counts at the next sweep
+     * start; DESIGN.md "tree freshness") and minus the doc-topic histogram
+     * (recomputed on demand by orc_get_doc_topic_hist). */
+    const int K = o->K, M = o->M;
+    for (size_t i = 0; i < dv->n; i++) {
+        const delta_t* dl = &dv->v[i];
+        size_t row = (size_t)(o->rowbase[dl->mod] + dl->type) * K;
+        if (dl->oldT != -1) {
+            if (apply) { o->nwk[row + dl->oldT]--; o->nk[(size_t)dl->mod * K + dl->oldT]--; }   /* UPD:199-216 */
+            if (delta_nwk) delta_nwk[row + dl->oldT]--;
+            if (delta_nk) delta_nk[(size_t)dl->mod * K + dl->oldT]--;
+        }
+        if (apply) { o->nwk[row + dl->newT]++; o->nk[(size_t)dl->mod * K + dl->newT]++; }       /* UPD:207,218 */
+        if (delta_nwk) delta_nwk[row + dl->newT]++;
+        if (delta_nk) delta_nk[(size_t)dl->mod * K + dl->newT]++;
+        if (o->inactive[dl->newT]) {                                                              /* UPD:263-270 */
+            if (st->activated_topic < 0) { st->activated_topic = dl->newT; st->activated_modality = dl->mod; }
+            if (apply) {
+                o->inactive[dl->newT] = 0;
+                o->alpha[(size_t)dl->mod * (K + 1) + dl->newT] = o->alpha[(size_t)dl->mod * (K + 1) + K];
+            }
+        }
+    }
+    (void)M;
+}
+
+int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base,
+              const double* p_in, uint32_t flags, orc_stats* st,
+              int32_t* delta_nwk, int32_t* delta_nk,
+              double* const* tok_dbg,
+              int n_trace, const int64_t* trace_doc, const int32_t* trace_view,
+              const int32_t* trace_pos, double* trace_out)
+{
+    const int K = o->K, M = o->M;
+    orc_stats local; memset(&local, 0, sizeof local);
+    local.activated_topic = -1; local.activated_modality = -1;
+
+    if (!(flags & ORC_SWEEP_REUSE_TREES)) orc_build_trees(o);
+
+    int first_inactive = -1;                      /* inActiveTopicIndex.first() WRK:525 */
+    for (int k = 0; k < K; k++) if (o->inactive[k]) { first_inactive = k; break; }
+
+    double* p_own = NULL;
+    const double* p = p_in;
+    if (!p) {
+        p_own = (double*)malloc((size_t)(o->D > 0 ? o->D : 1) * M * M * sizeof(double));
+        orc_draw_p_philox(o, seed, sweep_idx, doc_id_base, p_own);
+        p = p_own;
+    }
+    if (delta_nwk) memset(delta_nwk, 0, (size_t)o->rowbase[M] * K * sizeof(int32_t));
+    if (delta_nk) memset(delta_nk, 0, (size_t)M * K * sizeof(int32_t));
+
+    int32_t* localTopicCounts = (int32_t*)malloc((size_t)M * K * sizeof(int32_t));
+    int32_t* localTopicIndex = (int32_t*)malloc((size_t)(K + 1) * sizeof(int32_t));
+    double* topicDocWordMasses = (double*)malloc((size_t)(K + 1) * sizeof(double));
+    double* totalMassOtherModalities = (double*)malloc((size_t)K * sizeof(double));
+    delta_vec dv = { NULL, 0, 0 };
+
+    for (int64_t d = 0; d < o->D; d++) {
+        memset(localTopicIndex, 0, (size_t)(K + 1) * sizeof(int32_t));
+        topicDocWordMasses[0] = 0;
+        int rc = sample_one_doc(o, d, doc_id_base + d, sweep_idx, seed, p + (size_t)d * M * M,
+                                first_inactive, &local, &dv, tok_dbg,
+                                n_trace, trace_doc, trace_view, trace_pos, trace_out,
+                                localTopicCounts, localTopicIndex, topicDocWordMasses, totalMassOtherModalities);
+        if (rc) local.aborted_docs++;
+    }
+
+    apply_deltas(o, &dv, &local, delta_nwk, delta_nk, !(flags & ORC_SWEEP_NO_APPLY));
+
+    free(dv.v); free(localTopicCounts); free(localTopicIndex);
+    free(topicDocWordMasses); free(totalMassOtherModalities); free(p_own);
+    if (st) *st = local;
+    return 0;
+}
+
+void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk)
+{
+    const int K = o->K, M = o->M;
+    size_t n = (size_t)o->rowbase[M] * K;
+    for (size_t i = 0; i < n; i++) o->nwk[i] += delta_nwk[i];
+    for (size_t i = 0; i < (size_t)M * K; i++) o->nk[i] += delta_nk[i];
+}

@@ -1,0 +1,59 @@
+"""The C-ABI library loads and exports every symbol include/mvhdp.h declares.
+No compute calls (no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "mvhdp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvhdp_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mvtopicmodel_amd import _lib
+    L = _lib.load_library()
+    declared = _declared_symbols()
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.ABI_SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.mvhdp_version()
+
+
+def test_create_rejects_bad_config_without_touching_a_device():
+    import ctypes as C
+    from mvtopicmodel_amd import _lib
+    L = _lib.load_library()
+    cfg = _lib.Config()
+    cfg.num_topics = 0
+    cfg.num_modalities = 1
+    h = C.c_void_p()
+    assert L.mvhdp_create(C.byref(cfg), C.byref(h)) == -1     # MVHDP_ERR_INVALID_ARG
+    assert b"num_topics" in L.mvhdp_last_error(None)
+    assert L.mvhdp_create(None, C.byref(h)) == -1
+    assert L.mvhdp_destroy(None) == 0
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    """Without a gfx950 device the product refuses to run; it never routes to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mvtopicmodel_amd import NativeSampler, MvhdpError
+    with pytest.raises(MvhdpError) as e:
+        NativeSampler(10, [100])
+    assert e.value.code == -4                                   # MVHDP_ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mvtopicmodel_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in src.lower(), (dp, f)

@@ -1,0 +1,226 @@
+"""Parity proper: the HIP sweep (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bar (BASELINE.json north_star): integer topic-word /
+doc-topic counts and assignments bit-exact after a sweep under the identical RNG
+stream; per-token conditional probabilities within 1e-6."""
+import numpy as np
+import pytest
+
+from mvtopicmodel_amd.native import (Hyper, SWEEP_EXACT_CHAIN, SWEEP_NO_APPLY, SWEEP_REUSE_TREES)
+from tests.helpers import assert_same_state, make_native, make_oracle, small_corpus
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-6     # north_star: per-token conditional probabilities within 1e-6
+
+CASES = [
+    # K, V, D, lam, corpus seed     (K deliberately not powers of two, plus one that is)
+    (5, [40], 64, [12], 11),
+    (20, [300, 40, 50], 64, [30, 4, 6], 12),
+    (100, [2000], 96, [127], 13),
+    (64, [500, 60], 64, [40, 5], 14),
+    (200, [3000, 300, 300], 80, [127, 7, 15], 15),
+    (400, [5000, 500, 500], 48, [127, 7, 15], 16),
+]
+
+
+@pytest.mark.parametrize("K,V,D,lam,cseed", CASES)
+def test_one_sweep_bit_exact(K, V, D, lam, cseed):
+    c = small_corpus(K, V, D, lam, cseed)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    s = make_native(c, hy, z0)
+    assert_same_state(o, s, c.M)                     # build_counts parity
+    ro = o.sweep(0, 0xC0FFEE, want_dbg=True)
+    rs = s.sweep(0, 0xC0FFEE, want_dbg=True)
+    for f in ("tokens", "changed", "new_mass_cnt", "topic_doc_mass_cnt", "word_ftree_mass_cnt", "oov_skipped", "aborted_docs"):
+        assert ro["stats"][f] == getattr(rs, f), f
+    assert rs.tokens == c.total_tokens
+    assert_same_state(o, s, c.M)
+    if c.M > 1:
+        assert np.array_equal(o.draw_p_philox(0xC0FFEE, 0), s.get_view_weights())
+    for m in range(c.M):
+        # masses: newTopicMass / tree root bit-exact; topicDocWordMass within the scan's reordering error
+        a, b = ro["dbg"][m], rs.dbg[m]
+        assert np.array_equal(a[:, 0], b[:, 0])
+        assert np.array_equal(a[:, 2], b[:, 2])
+        assert np.allclose(a[:, 1], b[:, 1], rtol=1e-12, atol=0)
+        assert np.allclose(a[:, 3], b[:, 3], rtol=1e-12, atol=0)
+    s.close()
+
+
+@pytest.mark.parametrize("K,V,D,lam,cseed", CASES[1:5])
+def test_three_sweeps_bit_exact_and_exact_chain_mode(K, V, D, lam, cseed):
+    """Several sweeps (state carried on the device), and the forced sequential-sum
+    mode (the certified scan's fallback path) must give the very same integers."""
+    c = small_corpus(K, V, D, lam, cseed)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    s = make_native(c, hy, z0)
+    s2 = make_native(c, hy, z0)
+    for it in range(3):
+        ro = o.sweep(it, 42, want_dbg=True)
+        s.sweep(it, 42)
+        r2 = s2.sweep(it, 42, flags=SWEEP_EXACT_CHAIN, want_dbg=True)
+        assert_same_state(o, s, c.M)
+        assert_same_state(o, s2, c.M)
+        for m in range(c.M):
+            # in exact-chain mode every mass is bit-identical to the oracle's
+            assert np.array_equal(ro["dbg"][m], r2.dbg[m])
+    s.close(); s2.close()
+
+
+def test_trees_match_oracle_bitwise():
+    K, V = 200, [700, 90]
+    c = small_corpus(K, V, 50, [60, 6], 21)
+    hy = Hyper.defaults(K, V)
+    hy.alpha[:] = np.linspace(0.01, 0.3, K + 1)[None, :]       # asymmetric alpha
+    hy.alpha_sum[:] = hy.alpha[:, :K].sum(axis=1)
+    hy.gamma[:] = [1.0, 0.7]
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    o.build_trees(); s.build_trees()
+    for m, w in [(0, 0), (0, 1), (0, 699), (1, 0), (1, 89), (0, 345)]:
+        assert np.array_equal(o.get_tree(m, w), s.get_tree(m, w)), (m, w)
+    s.close()
+
+
+def test_token_conditionals_within_1e6():
+    K, V = 100, [1500, 200, 200]
+    c = small_corpus(K, V, 40, [60, 6, 9], 31)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(3)])
+    trace = []
+    for d in range(0, 40, 3):
+        for m in range(3):
+            L = int(c.doc_off[m][d + 1] - c.doc_off[m][d])
+            for pos in {0, L // 2, L - 1}:
+                if 0 <= pos < L:
+                    trace.append((d, m, pos))
+    ro = o.sweep(0, 5, trace=trace)
+    rs = s.sweep(0, 5, trace=trace)
+    assert ro["trace"].shape == rs.trace.shape
+    assert np.allclose(ro["trace"].sum(axis=1), 1.0, atol=1e-9)
+    assert np.max(np.abs(ro["trace"] - rs.trace)) < PROB_TOL
+    assert_same_state(o, s, 3)
+    s.close()
+
+
+def test_p_override_from_mallet_stream_and_reuse_trees():
+    """Host-drawn view weights (the reference worker's own MALLET Randoms, WRK:327-337) passed as an override."""
+    K, V = 50, [800, 100, 100]
+    c = small_corpus(K, V, 60, [40, 5, 8], 41)
+    hy = Hyper.defaults(K, V, p_a=1.1)                          # exercises the a>=1,b==1 quirk branch too
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(3)])
+    p = o.draw_p_mallet(seed=1)
+    o.sweep(0, 9, p=p)
+    s.sweep(0, 9, p=p)
+    assert_same_state(o, s, 3)
+    assert np.array_equal(s.get_view_weights(), p)
+    # stale trees on request: the counts moved, the trees did not
+    s.build_trees(); o.build_trees()
+    from oracle.binding import SWEEP_REUSE_TREES as ORT
+    o.sweep(1, 9, p=p, flags=ORT)
+    s.sweep(1, 9, p=p, flags=SWEEP_REUSE_TREES)
+    assert_same_state(o, s, 3)
+    s.close()
+
+
+def test_ragged_empty_unassigned_oov():
+    """Edge cases the reference handles: entities missing a view (null), empty entities,
+    UNASSIGNED topics (-1, PTM:63), out-of-vocabulary types (WRK:427-428)."""
+    K, V = 30, [100, 20]
+    rng = np.random.RandomState(0)
+    lens0 = np.array([0, 5, 1, 0, 70, 3, 0, 9, 2, 65], dtype=np.int64)
+    lens1 = np.array([0, 0, 4, 2, 0, 1, 0, 3, 0, 10], dtype=np.int64)
+    off0 = np.concatenate([[0], np.cumsum(lens0)]); off1 = np.concatenate([[0], np.cumsum(lens1)])
+    t0 = rng.randint(0, 100, off0[-1]).astype(np.int32); t1 = rng.randint(0, 20, off1[-1]).astype(np.int32)
+    t0[[3, 20]] = 100                                           # OOV: type == V (inference-only path)
+    t1[2] = 25
+    from mvtopicmodel_amd.synth import Corpus
+    c = Corpus(K, V, [off0, off1], [t0, t1])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(2)]
+    z0[0][[0, 7, 30]] = -1; z0[1][[1, 5]] = -1                  # UNASSIGNED
+    for m in range(2):
+        o.set_assignments(m, z0[m])
+    # the OOV tokens must not be counted by build_counts either: give them UNASSIGNED like a fresh inference doc
+    z0[0][[3, 20]] = -1; z0[1][2] = -1
+    for m in range(2):
+        o.set_assignments(m, z0[m])
+    o.build_counts()
+    s = make_native(c, hy, z0)
+    ro = o.sweep(0, 77); rs = s.sweep(0, 77)
+    assert ro["stats"]["oov_skipped"] == rs.oov_skipped == 3
+    assert rs.tokens == c.total_tokens - 3
+    assert_same_state(o, s, 2)
+    assert (s.get_assignments(0)[[3, 20]] == -1).all()
+    for it in range(1, 3):
+        o.sweep(it, 77); s.sweep(it, 77)
+        assert_same_state(o, s, 2)
+    s.close()
+
+
+def test_inactive_topic_activation():
+    """Truncated-HDP branch: a non-empty inActiveTopicIndex gives newTopicMass>0 (WRK:515-526);
+    the first delta that lands on the inactive topic activates it (UPD:263-270)."""
+    K, V = 40, [300, 50]
+    c = small_corpus(K, V, 80, [30, 5], 51)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[33, 36, 39]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive)
+    hy.alpha[:, K] = 25.0                                         # make the new-topic branch likely
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(2)]
+    for m in range(2):                                            # inactive topics hold no tokens
+        z0[m][np.isin(z0[m], [33, 36, 39])] = 1
+        o.set_assignments(m, z0[m])
+    o.build_counts()
+    s = make_native(c, hy, z0)
+    ro = o.sweep(0, 3, want_dbg=True); rs = s.sweep(0, 3, want_dbg=True)
+    assert ro["stats"]["new_mass_cnt"] == rs.new_mass_cnt > 0
+    assert (ro["stats"]["activated_topic"], ro["stats"]["activated_modality"]) == (rs.activated_topic, rs.activated_modality)
+    assert rs.activated_topic == 33
+    assert_same_state(o, s, 2)
+    a_s, ina_s = s.get_alpha()
+    assert np.array_equal(o.get_alpha(), a_s) and np.array_equal(o.get_inactive(), ina_s)
+    assert ina_s[33] == 0 and ina_s[36] == 1
+    assert a_s[rs.activated_modality, 33] == 25.0
+    ro = o.sweep(1, 3); rs = s.sweep(1, 3)
+    assert rs.activated_topic == 36
+    assert_same_state(o, s, 2)
+    s.close()
+
+
+def test_doc_topic_hist_matches():
+    K, V = 60, [500, 60]
+    c = small_corpus(K, V, 70, [50, 6], 61)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    o.sweep(0, 1); s.sweep(0, 1)
+    for m in range(2):
+        ho, lo = o.get_doc_topic_hist(m, 128, 128)
+        hs, ls = s.get_doc_topic_hist(m, 128, 128)
+        assert np.array_equal(ho, hs) and np.array_equal(lo, ls)
+    s.close()
+
+
+def test_no_apply_then_apply_equals_apply():
+    K, V = 50, [400, 60]
+    c = small_corpus(K, V, 64, [40, 6], 71)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(2)]
+    s = make_native(c, hy, z0)
+    before = [s.get_counts(m) for m in range(2)]
+    st = s.sweep(0, 8, flags=SWEEP_NO_APPLY)
+    for m in range(2):
+        assert np.array_equal(before[m][0], s.get_counts(m)[0])
+    s.apply_delta(st.activated_topic, st.activated_modality)
+    o.sweep(0, 8)
+    assert_same_state(o, s, 2)
+    s.close()

@@ -1,0 +1,223 @@
+"""Known-answer tests pinning the CPU oracle (SURVEY.md §8c KAT-1..6 and the
+documented third-party contracts).  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from oracle.binding import JRand
+
+
+def _tree(L, w):
+    w = np.asarray(w, dtype=np.float64)
+    t = np.zeros(2 * len(w), dtype=np.float64)
+    L.orc_ftree_construct(t.ctypes.data, len(w), w.ctypes.data)
+    return t
+
+
+def test_kat1_ftree_power_of_two(oracle_lib):
+    L = oracle_lib
+    t = _tree(L, [1, 2, 3, 4])                      # FT:158-161
+    assert list(t[1:]) == [10, 3, 7, 1, 2, 3, 4]
+    s = lambda u: L.orc_ftree_sample(t.ctypes.data, 4, u)
+    assert s(0.4) == 2 and s(0.0) == 0 and s(0.1) == 1 and s(0.29) == 1
+    assert s(0.3) == 2        # 0.3*10 == 3.0 exactly; 3.0 < tree[2]=3 is false -> right child (Q8)
+    assert s(1.0) == 3
+    assert s(1.0000001) == -2  # IllegalArgumentException FT:112-114
+
+
+def test_kat2_ftree_rotation(oracle_lib):
+    L = oracle_lib
+    t = _tree(L, [1, 2, 3, 4, 5])
+    assert t[4] == 9 and t[3] == 5 and t[2] == 10 and t[1] == 15
+    s = lambda x: L.orc_ftree_sample(t.ctypes.data, 5, x / 15.0)
+    # in-order leaves are topics 3,4,0,1,2
+    for x, k in [(0.5, 3), (3.9, 3), (4.5, 4), (8.9, 4), (9.5, 0), (10.5, 1), (11.9, 1), (12.5, 2), (14.9, 2)]:
+        assert s(x) == k, (x, k)
+    # general rule: rotation by P-K; K=400 -> leaves 112..399 then 0..111
+    K = 400
+    w = np.ones(K)
+    t = _tree(L, w)
+    order = [L.orc_ftree_sample(t.ctypes.data, K, (i + 0.5) / K) for i in range(K)]
+    assert order == list(range(112, 400)) + list(range(0, 112))
+
+
+def test_kat3_ftree_update(oracle_lib):
+    L = oracle_lib
+    w = np.array([0.5, 1.25, 2.0, 0.75, 3.5, 1.0, 0.25])
+    t = _tree(L, w)
+    root0 = t[1]
+    L.orc_ftree_update(t.ctypes.data, len(w), 4, 1.5)
+    assert t[len(w) + 4] == 1.5
+    assert t[1] == root0 + (1.5 - 3.5)
+    assert t[0] == (1.5 - 3.5) * 0 + t[0]   # tree[0] untouched by the loop's i>0 guard... (i/2 reaches 0 and stops)
+    assert t[0] == 0.0
+
+
+def test_kat4_lower_bound(oracle_lib):
+    L = oracle_lib
+    a = np.array([1.0, 3.0, 6.0])
+    lb = lambda x: L.orc_lower_bound(a.ctypes.data, x, 3)
+    assert [lb(0.5), lb(1.0), lb(1.0001), lb(6.0), lb(6.1)] == [0, 0, 1, 2, -1]
+
+
+def test_kat5_thread_split():
+    # numThreads=9 -> nst=6, nut=2 (PTM:1036-1037); delta for word w from worker t -> queue 6*(w%2)+t (WRK:589)
+    T = 9
+    nst, nut = 3 * T // 4, T // 4
+    assert (nst, nut) == (6, 2)
+    assert nst * (7 % nut) + 3 == 9
+    assert [1 * nst + st for st in range(nst)] == list(range(6, 12))   # updater 1 reads queues 6..11 (UPD:187)
+
+
+def test_philox_known_answers(oracle_lib):
+    """Random123 kat_vectors for philox4x32_10."""
+    L = oracle_lib
+    def ph(ctr, key):
+        c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+        L.orc_philox4x32_10(c, k, o)
+        return [x for x in o]
+    assert ph([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xffffffff
+    assert ph([f, f, f, f], [f, f]) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_java_util_random_contract(oracle_lib):
+    """new Random(42).nextInt() sequence is a published constant of the JDK LCG."""
+    L = oracle_lib
+    r = JRand()
+    L.orc_jrand_seed(C.byref(r), 42)
+    got = [L.orc_jrand_next(C.byref(r), 32) for _ in range(3)]
+    assert got == [-1170105035, 234785527, -1360544799]
+    L.orc_jrand_seed(C.byref(r), 42)
+    assert [L.orc_jrand_next_int(C.byref(r), 10) for _ in range(5)] == [0, 3, 8, 4, 0]
+    # nextDouble of Random(42): 0.7275636800328681 (== MALLET nextUniform: same next(26)/next(27) recipe)
+    L.orc_jrand_seed(C.byref(r), 42)
+    assert L.orc_mallet_next_uniform(C.byref(r)) == 0.7275636800328681
+
+
+def test_java_round(oracle_lib):
+    L = oracle_lib
+    assert L.orc_java_round(2.5) == 3 and L.orc_java_round(-2.5) == -2
+    assert L.orc_java_round(0.49999999999999994) == 0      # the JDK-6 bug value; Java 8 gives 0
+    assert L.orc_java_round(310.5) == 311
+
+
+def test_mallet_next_beta_shapes(oracle_lib):
+    L = oracle_lib
+    r = JRand()
+    L.orc_jrand_seed(C.byref(r), 7)
+    # a<1, b=1: Joehnk; Beta(a,1) has mean a/(a+1)
+    xs = np.array([L.orc_mallet_next_beta(C.byref(r), 0.31, 1.0) for _ in range(20000)])
+    assert np.all((xs >= 0) & (xs <= 1))
+    assert abs(xs.mean() - 0.31 / 1.31) < 0.01
+    # a>1, b=1: the NaN quirk returns the first in-range N(1, 0.25/(a-1)) proposal -> all values <= 1, clustered near 1
+    ys = np.array([L.orc_mallet_next_beta(C.byref(r), 1.1, 1.0) for _ in range(5000)])
+    assert np.all((ys >= 0) & (ys <= 1))
+    sigma = 0.5 / np.sqrt(0.1)
+    # half-normal truncated to [0,1]: mean of 1-|g|*sigma restricted to >=0 is well above Beta(1.1,1)'s 0.52
+    assert ys.mean() > 0.45
+    # a==b==1 -> plain uniform
+    L.orc_jrand_seed(C.byref(r), 42)
+    assert L.orc_mallet_next_beta(C.byref(r), 1.0, 1.0) == 0.7275636800328681
+
+
+def test_kat6_single_view_conditional():
+    """M=1: p[0][0]=1, other==0, no nextBeta call; conditional = (1[k in dense] n_dk + gamma alpha_k)(n_wk+beta)/(n_k+betaSum)
+    with the token's own count included (Q5) and the indicator only through Q1/Q2."""
+    from tests.helpers import small_corpus, make_oracle
+    from mvtopicmodel_amd.native import Hyper
+    K, V = 5, [11]
+    c = small_corpus(K, V, 6, [9], seed=123)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy, init_seed=3)
+    z0 = o.get_assignments(0).copy()
+    nwk, nk = o.get_counts(0)
+    d = 2
+    b, e = int(c.doc_off[0][d]), int(c.doc_off[0][d + 1])
+    assert e - b >= 2
+    res = o.sweep(0, 99, flags=binding.SWEEP_NO_APPLY, trace=[(d, 0, 0)])
+    w = int(c.tokens[0][b])
+    ndk = np.bincount(z0[b:e], minlength=K).astype(np.float64)
+    old = z0[b]
+    in_dense = ndk > 0
+    ndk[old] -= 1
+    if ndk[old] == 0:
+        in_dense[old] = False
+    phi = (nwk[w] + 0.01) / (nk + 0.01 * V[0])
+    want = (in_dense * ndk + 1.0 * 0.1) * phi
+    want = want / want.sum()
+    got = res["trace"][0]
+    assert got[K] == 0.0
+    assert np.allclose(got[:K], want, rtol=0, atol=1e-12)
+
+
+def test_invariants_after_sweeps():
+    from tests.helpers import small_corpus, make_oracle
+    from mvtopicmodel_amd.native import Hyper
+    K, V = 20, [300, 40, 50]
+    c = small_corpus(K, V, 64, [30, 4, 6], seed=5)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    for it in range(3):
+        st = o.sweep(it, 1234)["stats"]
+        assert st["tokens"] == c.total_tokens
+        assert st["new_mass_cnt"] == 0
+        assert st["topic_doc_mass_cnt"] + st["word_ftree_mass_cnt"] == st["tokens"]
+        for m in range(3):
+            nwk, nk = o.get_counts(m)
+            z = o.get_assignments(m)
+            assert nk.sum() == len(z)
+            assert np.array_equal(nwk.sum(axis=0), nk)
+            tt = np.bincount(c.tokens[m], minlength=V[m])
+            assert np.array_equal(nwk.sum(axis=1), tt)
+            ref = np.zeros_like(nwk); np.add.at(ref, (c.tokens[m], z), 1)
+            assert np.array_equal(ref, nwk)
+            hist, dl = o.get_doc_topic_hist(m, 64, 64)
+            assert np.array_equal((hist * np.arange(64)[None, :]).sum(axis=1), nk)
+            lens = np.diff(c.doc_off[m])
+            assert hist.sum(axis=1).tolist() == [int((lens > 0).sum())] * K
+            assert np.array_equal(dl, np.bincount(lens[lens > 0], minlength=64))
+
+
+def test_init_assignments_rule():
+    """PTM:499-507: view 0 uniform over K; view m>0 picks among the topics drawn for the entity's view 0."""
+    from tests.helpers import small_corpus, make_oracle
+    from mvtopicmodel_amd.native import Hyper
+    K, V = 50, [200, 30]
+    c = small_corpus(K, V, 40, [12, 5], seed=9)
+    o = make_oracle(c, Hyper.defaults(K, V), init_seed=1)
+    z0, z1 = o.get_assignments(0), o.get_assignments(1)
+    assert z0.min() >= 0 and z0.max() < K
+    for d in range(c.D):
+        a = set(z0[c.doc_off[0][d]:c.doc_off[0][d + 1]].tolist())
+        b = set(z1[c.doc_off[1][d]:c.doc_off[1][d + 1]].tolist())
+        if a:
+            assert b <= a
+    # the stream is java.util.Random(1): first draw nextInt(50)
+    r = JRand(); L = binding.lib()
+    L.orc_jrand_seed(C.byref(r), 1)
+    assert z0[0] == L.orc_jrand_next_int(C.byref(r), K)
+
+
+def test_philox_p_matches_contract():
+    """Device contract for the view weights: per-(doc,pair) Philox stream, 3-decimal rounding, symmetric."""
+    from tests.helpers import small_corpus, make_oracle
+    from mvtopicmodel_amd.native import Hyper
+    K, V = 8, [50, 10, 10]
+    c = small_corpus(K, V, 30, [10, 3, 3], seed=2)
+    o = make_oracle(c, Hyper.defaults(K, V))
+    p = o.draw_p_philox(77, 3)
+    assert p.shape == (30, 3, 3)
+    assert np.all(p[:, [0, 1, 2], [0, 1, 2]] == 1.0)
+    assert np.array_equal(p, p.transpose(0, 2, 1))
+    assert np.all(np.abs(p * 1000 - np.round(p * 1000)) < 1e-9)
+    assert np.array_equal(p, o.draw_p_philox(77, 3))
+    assert not np.array_equal(p, o.draw_p_philox(77, 4))
+    # shard invariance: entity ids are global
+    sub = c.slice_docs(10, 20)
+    o2 = make_oracle(sub, Hyper.defaults(K, V))
+    assert np.array_equal(o2.draw_p_philox(77, 3, doc_id_base=10), p[10:20])
