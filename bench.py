@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — Gibbs tokens sampled per second per sweep (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--workload C4] [--docs D]
+
+A "step" is one full Gibbs sweep (mvhdp_sweep: view weights + F+tree rebuild +
+the sweep kernel + count update) over the synthetic corpus, inputs resident in
+HBM before the timed region.  N=1 runs BASELINE config C4 (1M entities x 3 views,
+K=400, ~150M tokens: the configuration the metric is quoted on; it fits one
+MI355X).  N>1 (launched by torch.distributed.run, one rank per GPU) shards the
+same corpus by token count and adds the per-sweep RCCL all-reduce of the count
+deltas: total work is fixed, so "scaling" is "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_token(K):
+    """one int32 n_wk row + token id + old assignment."""
+    return 4 * K + 8
+
+
+def cpu_baseline(workload, sample_docs, iters, seed):
+    """The reference's thread topology restated in C (oracle/ref_threaded.c), timed on the
+    host cores of this box on a bounded sample of the same workload.  Reported, not a target."""
+    from oracle.binding import Oracle
+    from mvtopicmodel_amd import synth
+    from mvtopicmodel_amd.native import Hyper
+    c = synth.make_config(workload, doc_lo=0, doc_hi=sample_docs)
+    hy = Hyper.defaults(c.K, c.V)
+    o = Oracle(c.K, c.V)
+    for m in range(c.M):
+        o.set_corpus(m, c.doc_off[m], c.tokens[m])
+    o.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, None)
+    o.init_assignments(1)
+    o.build_counts()
+    cores = os.cpu_count() or 4
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    T = max(4, min(cores, 16))     # the GPU box's CPU share for one GPU is 16 cores
+    secs, st = o.threaded_estimate(T, iters, seed)
+    o.close()
+    return {"value": st["tokens"] / secs, "unit": "tokens/s", "cores": T, "kind": "port",
+            "sample": f"first {sample_docs} entities of {workload} ({c.total_tokens} tokens) x {iters} iterations, "
+                      f"{3 * T // 4} sampler + {T // 4} updater threads (PTM:1036-1037 topology)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C4")
+    ap.add_argument("--docs", type=int, default=None, help="override the entity count (smoke runs)")
+    ap.add_argument("--seed", type=int, default=20260101)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-docs", type=int, default=60000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+    from mvtopicmodel_amd import NativeSampler, synth
+    from mvtopicmodel_amd.dist import GpuShard, build_counts_all_reduce, sweep_all_reduce
+    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.native import Hyper
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the sweep has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+
+    cfg = dict(synth.CONFIGS[args.workload])
+    D_total = args.docs or cfg["D"]
+    K, V = cfg["K"], cfg["V"]
+    M = len(V)
+
+    # ---- document shard of this rank, balanced by token count ----
+    t_setup = time.time()
+    doc_tokens = synth.config_doc_token_counts(args.workload, D=D_total)
+    lo, hi = synth.shard_bounds(doc_tokens, world)[rank]
+    corpus = synth.make_config(args.workload, D=D_total, doc_lo=lo, doc_hi=hi)
+    total_tokens = int(doc_tokens.sum())
+    # initial assignments: the addInstances draw order over the whole corpus (it depends on
+    # entity lengths only), of which this rank keeps its slice
+    if lo == 0:
+        z0 = init_assignments(K, corpus.doc_off, seed=1)
+    else:
+        lens = synth._doc_lengths(V, 0, hi, cfg["lam"], cfg["seed"], [1.0] + [0.8] * (M - 1), cfg.get("power_law_text", False))
+        offs = [np.concatenate([[0], np.cumsum(L)]).astype(np.int64) for L in lens]
+        zfull = init_assignments(K, offs, seed=1)
+        z0 = [zfull[m][offs[m][lo]:offs[m][hi]] for m in range(M)]
+        del zfull, lens, offs
+
+    s = NativeSampler(K, V, device=local_rank, doc_id_base=lo)
+    for m in range(M):
+        s.set_corpus(m, corpus.doc_off[m], corpus.tokens[m])
+        s.set_assignments(m, z0[m])
+    s.set_hyper(Hyper.defaults(K, V))
+    shard = GpuShard(s, device)
+    build_counts_all_reduce(shard)
+    local_tokens = corpus.total_tokens
+    del z0
+    setup_s = time.time() - t_setup
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        sweep_all_reduce(shard, w, args.seed)
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    last = None
+    for k in range(args.steps):
+        last = sweep_all_reduce(shard, args.warmup + k, args.seed)
+        kernel_ms.append(last.sweep_kernel_ms)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    value = total_tokens * args.steps / dt
+    # roofline of the dominant kernel (sweep_kernel) on this rank: algorithmic bytes per launch /
+    # its average duration, measured with hipEvents on the library's stream
+    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    bpt = algorithmic_bytes_per_token(K)
+    achieved = local_tokens * bpt / avg_kernel_s / 1e9
+    out = {
+        "metric": "gibbs_tokens_per_sec", "value": value, "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {D_total} entities x {M} views, K={K}, vocab {V}, "
+                               f"{total_tokens} tokens; doc-sharded across {world} GPU(s)",
+                   "topics": K, "views": M, "tokens": total_tokens, "entities": D_total,
+                   "sharding": f"documents/{world}, per-sweep int32 all-reduce of n_wk,n_k deltas" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "sweep_kernel", "bytes_per_token": bpt, "tokens_per_launch": local_tokens,
+                     "avg_kernel_ms": avg_kernel_s * 1e3},
+        "sweep": {"changed_frac": last.changed / max(1, last.tokens),
+                  "branch_frac": {"new": last.new_mass_cnt / max(1, last.tokens),
+                                  "doc": last.topic_doc_mass_cnt / max(1, last.tokens),
+                                  "tree": last.word_ftree_mass_cnt / max(1, last.tokens)},
+                  "exact_fallbacks": last.exact_fallbacks, "total_ms_last": last.total_ms},
+        "setup_s": setup_s,
+    }
+    s.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample_docs, D_total), 2, args.seed)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,384 @@
+// FastQMVWVParallelTopicModel.cpp — see the header.  Host logic only; every
+// per-token operation happens in libmvhdp's kernels.
+#include "FastQMVWVParallelTopicModel.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "java_random.h"
+
+namespace mvtm {
+
+FastQMVWVParallelTopicModel::FastQMVWVParallelTopicModel(int numberOfTopics, int8_t numModalities_, double alpha_, double beta_,
+                                                         bool useCycleProposals, const std::string& SQLConnectionString,
+                                                         bool useTypeVectors, double vectorsLambda, bool trainTypeVectors)
+    : numTopics(numberOfTopics), numModalities(numModalities_)
+{
+    if (numberOfTopics < 1 || numberOfTopics > MVHDP_MAX_TOPICS) throw std::invalid_argument("numberOfTopics out of range");
+    if (numModalities_ < 1 || numModalities_ > MVHDP_MAX_MODALITIES) throw std::invalid_argument("numModalities out of range");
+    if (useTypeVectors || trainTypeVectors)
+        throw std::invalid_argument("the embedding mix (useTypeVectors/trainTypeVectors) is outside the accelerated path");
+    (void)useCycleProposals; (void)SQLConnectionString; (void)vectorsLambda;
+    const int M = numModalities, K = numTopics;
+    alphaSum.assign(M, 0); beta.assign(M, 0); betaSum.assign(M, 0); gamma.assign(M, 0);
+    alpha.assign(M, std::vector<double>(K + 1, 0.0));
+    totalTokens.assign(M, 0); totalDocsPerModality.assign(M, 0); numTypes.assign(M, 0);
+    tokensPerTopic.assign(M, std::vector<int32_t>(K, 0));
+    for (int m = 0; m < M; m++) {                       // PTM:207-214
+        alphaSum[m] = K * alpha_;
+        std::fill(alpha[m].begin(), alpha[m].end(), alpha_);
+        beta[m] = beta_;
+        gamma[m] = 1;
+    }
+    p_a.assign(M, std::vector<double>(M, 0.0));        // PTM:228-229
+    p_b.assign(M, std::vector<double>(M, 0.0));
+}
+
+FastQMVWVParallelTopicModel::~FastQMVWVParallelTopicModel()
+{
+    if (h_) mvhdp_destroy(h_);
+}
+
+void FastQMVWVParallelTopicModel::check(int rc, const char* what)
+{
+    if (rc != MVHDP_OK)
+        throw std::runtime_error(std::string(what) + ": " + mvhdp_last_error(h_) + " (code " + std::to_string(rc) + ")");
+}
+
+void FastQMVWVParallelTopicModel::addInstances(const std::vector<InstanceList>& training, const std::string& batchId, int vectorSize)
+{
+    (void)batchId; (void)vectorSize;
+    const int M = numModalities, K = numTopics;
+    if ((int)training.size() != M) throw std::invalid_argument("addInstances: one InstanceList per modality");
+    std::unordered_map<std::string, int> entityPosition;             // PTM:398
+    typeTotals.assign(M, {});
+    data.clear();
+
+    for (int m = 0; m < M; m++) {                                     // PTM:410-463
+        numTypes[m] = training[m].alphabetSize;                       // PTM:413
+        if (numTypes[m] < 1) throw std::invalid_argument("addInstances: empty alphabet");
+        typeTotals[m].assign(numTypes[m], 0);
+        betaSum[m] = beta[m] * numTypes[m];                           // PTM:420
+        for (const Instance& instance : training[m].instances) {
+            TopicAssignment t;
+            t.present = true;
+            t.tokens = instance.features;
+            t.topics.assign(instance.features.size(), 0);             // new int[tokens.size()] PTM:430
+            const std::string& entityId = instance.name;              // PTM:437
+            auto it = entityPosition.find(entityId);
+            if (m != 0 && it != entityPosition.end()) {               // PTM:443-447
+                data[it->second].Assignments[m] = std::move(t);
+            } else {                                                  // PTM:449-455
+                MixTopicModelTopicAssignment mt;
+                mt.EntityId = entityId;
+                mt.Assignments.assign(M, TopicAssignment());
+                mt.Assignments[m] = std::move(t);
+                data.push_back(std::move(mt));
+                entityPosition[entityId] = (int)data.size() - 1;
+            }
+        }
+    }
+
+    // PTM:403-408, 465-515: random initial assignments from MALLET Randoms(randomSeed)
+    int64_t seed = randomSeed;
+    if (randomSeed == -1) seed = (int64_t)std::random_device{}();
+    Randoms random(seed);
+    std::vector<int32_t> activeTopics;
+    for (MixTopicModelTopicAssignment& entity : data) {
+        for (int m = 0; m < M; m++) {
+            if (m == 0) activeTopics.clear();                         // PTM:470-472
+            TopicAssignment& document = entity.Assignments[m];
+            if (!document.present) continue;
+            for (size_t position = 0; position < document.tokens.size(); position++) {
+                int type = document.tokens[position];
+                int topic;
+                if (m == 0) {                                         // PTM:499-501
+                    topic = random.nextInt(K);
+                    activeTopics.push_back(topic);
+                } else if (!activeTopics.empty()) {                   // PTM:502-504
+                    int ind = random.nextInt((int32_t)activeTopics.size());
+                    topic = activeTopics[ind];
+                } else {                                              // PTM:505-507
+                    topic = random.nextInt(K);
+                }
+                document.topics[position] = topic;
+                if (type >= 0 && type < numTypes[m]) typeTotals[m][type]++;   // PTM:511
+            }
+        }
+    }
+
+    initializeHistograms();                                           // PTM:527
+    // initSpace PTM:575-598: the model arrays live on the device
+    maxTypeCount.assign(M, 0);
+    for (int m = 0; m < M; m++)
+        for (int c : typeTotals[m]) maxTypeCount[m] = std::max(maxTypeCount[m], c);
+
+    if (h_) { mvhdp_destroy(h_); h_ = nullptr; }
+    mvhdp_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.num_topics = K; cfg.num_modalities = M; cfg.device = device_; cfg.doc_id_base = docIdBase_;
+    for (int m = 0; m < M; m++) cfg.num_types[m] = numTypes[m];
+    int rc = mvhdp_create(&cfg, &h_);
+    if (rc != MVHDP_OK) throw std::runtime_error(std::string("mvhdp_create: ") + mvhdp_last_error(nullptr));
+
+    // flatten MixTopicModelTopicAssignment -> CSR per view
+    const int64_t D = (int64_t)data.size();
+    for (int m = 0; m < M; m++) {
+        std::vector<int64_t> off(D + 1, 0);
+        for (int64_t d = 0; d < D; d++) off[d + 1] = off[d] + (int64_t)data[d].Assignments[m].tokens.size();
+        std::vector<int32_t> tok((size_t)off[D]), z((size_t)off[D]);
+        for (int64_t d = 0; d < D; d++) {
+            const TopicAssignment& ta = data[d].Assignments[m];
+            std::copy(ta.tokens.begin(), ta.tokens.end(), tok.begin() + off[d]);
+            std::copy(ta.topics.begin(), ta.topics.end(), z.begin() + off[d]);
+        }
+        check(mvhdp_set_corpus(h_, m, D, off.data(), tok.data()), "mvhdp_set_corpus");
+        check(mvhdp_set_assignments(h_, m, z.data()), "mvhdp_set_assignments");
+    }
+    pushHyper();
+    check(mvhdp_build_counts(h_), "mvhdp_build_counts");              // PTM:529
+    check(mvhdp_build_trees(h_), "mvhdp_build_trees");                // PTM:531
+    syncFromDevice(true);
+}
+
+void FastQMVWVParallelTopicModel::initializeHistograms()
+{
+    const int M = numModalities;                                      // PTM:849-897
+    histogramSize.assign(M, 0);
+    std::fill(totalTokens.begin(), totalTokens.end(), 0);
+    std::fill(totalDocsPerModality.begin(), totalDocsPerModality.end(), 0);
+    for (const auto& entity : data)
+        for (int i = 0; i < M; i++) {
+            const TopicAssignment& document = entity.Assignments[i];
+            if (document.present) {
+                int seqLen = (int)document.tokens.size();
+                histogramSize[i] = std::max(histogramSize[i], seqLen);
+                totalTokens[i] += seqLen;
+                totalDocsPerModality[i]++;                            // PTM:624
+            }
+        }
+    docLengthCounts.assign(M, {});
+    topicDocCounts.assign(M, {});
+    for (int m = 0; m < M; m++) docLengthCounts[m].assign(histogramSize[m] + 1, 0);
+}
+
+void FastQMVWVParallelTopicModel::pushHyper()
+{
+    const int M = numModalities, K = numTopics;
+    std::vector<double> a((size_t)M * (K + 1));
+    std::vector<uint8_t> ina((size_t)K, 0);
+    for (int m = 0; m < M; m++) std::copy(alpha[m].begin(), alpha[m].end(), a.begin() + (size_t)m * (K + 1));
+    for (int t : inActiveTopicIndex) if (t >= 0 && t < K) ina[t] = 1;
+    mvhdp_hyper hy;
+    std::memset(&hy, 0, sizeof hy);
+    hy.alpha = a.data();
+    hy.inactive = ina.data();
+    for (int m = 0; m < M; m++) {
+        hy.alpha_sum[m] = alphaSum[m]; hy.beta[m] = beta[m]; hy.beta_sum[m] = betaSum[m]; hy.gamma[m] = gamma[m];
+        for (int j = 0; j < M; j++) { hy.p_a[m][j] = p_a[m][j]; hy.p_b[m][j] = p_b[m][j]; }
+    }
+    check(mvhdp_set_hyper(h_, &hy), "mvhdp_set_hyper");
+}
+
+void FastQMVWVParallelTopicModel::syncFromDevice(bool histograms)
+{
+    const int M = numModalities, K = numTopics;
+    const int64_t D = (int64_t)data.size();
+    typeTopicCounts.resize(M);
+    for (int m = 0; m < M; m++) {
+        typeTopicCounts[m].resize((size_t)numTypes[m] * K);
+        check(mvhdp_get_counts(h_, m, typeTopicCounts[m].data(), tokensPerTopic[m].data()), "mvhdp_get_counts");
+        int64_t N = 0;
+        for (int64_t d = 0; d < D; d++) N += (int64_t)data[d].Assignments[m].tokens.size();
+        std::vector<int32_t> z((size_t)std::max<int64_t>(N, 1));
+        check(mvhdp_get_assignments(h_, m, z.data()), "mvhdp_get_assignments");
+        int64_t o = 0;
+        for (int64_t d = 0; d < D; d++) {                             // back into the very arrays getFeatures() returns
+            TopicAssignment& ta = data[d].Assignments[m];
+            std::copy(z.begin() + o, z.begin() + o + (int64_t)ta.topics.size(), ta.topics.begin());
+            o += (int64_t)ta.topics.size();
+        }
+        if (histograms) {
+            topicDocCounts[m].assign((size_t)K * (histogramSize[m] + 1), 0);
+            check(mvhdp_get_doc_topic_hist(h_, m, topicDocCounts[m].data(), histogramSize[m] + 1,
+                                           docLengthCounts[m].data(), histogramSize[m] + 1), "mvhdp_get_doc_topic_hist");
+        }
+    }
+    // a topic activation (UPD:263-270) may have changed alpha / inActiveTopicIndex
+    std::vector<double> a((size_t)M * (K + 1));
+    std::vector<uint8_t> ina((size_t)K);
+    check(mvhdp_get_alpha(h_, a.data(), ina.data()), "mvhdp_get_alpha");
+    for (int m = 0; m < M; m++) std::copy(a.begin() + (size_t)m * (K + 1), a.begin() + (size_t)(m + 1) * (K + 1), alpha[m].begin());
+    inActiveTopicIndex.clear();
+    for (int k = 0; k < K; k++) if (ina[k]) inActiveTopicIndex.insert(k);
+}
+
+void FastQMVWVParallelTopicModel::estimate()
+{
+    if (!h_) throw std::runtime_error("estimate() before addInstances()");
+    const int M = numModalities;
+    // PTM:1036-1037: nst = 3T/4 sampler threads and nut = T/4 updater threads become one kernel launch.
+    for (int i = 0; i < M; i++) {                                     // PTM:1055-1058
+        std::fill(p_a[i].begin(), p_a[i].end(), 0.2);
+        std::fill(p_b[i].begin(), p_b[i].end(), 1.0);
+    }
+    uint64_t seed = (randomSeed == -1) ? (uint64_t)std::random_device{}() : (uint64_t)(int64_t)randomSeed;
+    iterationLog.clear();
+    for (int iteration = 1; iteration <= numIterations; iteration++) {   // PTM:1146
+        auto t0 = std::chrono::steady_clock::now();
+        if (iteration < burninPeriod && M > 1) {                      // PTM:1166-1171
+            double v = std::min((double)iteration / 100 + 0.3, 1.1);
+            for (int i = 0; i < M; i++) std::fill(p_a[i].begin(), p_a[i].end(), v);
+        } else if (iteration > burninPeriod && optimizeInterval != 0 && iteration % optimizeInterval == 0) {
+            // PTM:1173-1210 optimizeP/optimizeDP/optimizeGamma/optimizeBeta + buildFTrees(false):
+            // SURVEY §8f next #1, not part of this build.  The trees are rebuilt from the
+            // counts at the start of every sweep anyway (DESIGN.md "tree freshness").
+        }
+        pushHyper();
+        mvhdp_sweep_stats st;
+        check(mvhdp_sweep(h_, (uint32_t)iteration, seed, 0, nullptr, nullptr, &st), "mvhdp_sweep");  // PTM:1213-1239
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        iterationLog.push_back({iteration, ms, st});
+        if (st.activated_topic >= 0) {                                // keep the host copy of alpha / inActiveTopicIndex current
+            std::vector<double> a((size_t)M * (numTopics + 1));
+            std::vector<uint8_t> ina((size_t)numTopics);
+            check(mvhdp_get_alpha(h_, a.data(), ina.data()), "mvhdp_get_alpha");
+            for (int m = 0; m < M; m++) std::copy(a.begin() + (size_t)m * (numTopics + 1), a.begin() + (size_t)(m + 1) * (numTopics + 1), alpha[m].begin());
+            inActiveTopicIndex.clear();
+            for (int k = 0; k < numTopics; k++) if (ina[k]) inActiveTopicIndex.insert(k);
+        }
+    }
+    syncFromDevice(true);
+}
+
+}  // namespace mvtm
+
+// ---------------------------------------------------------------------------
+// extern "C" hooks so that the Python test/bench harness can drive the C++
+// host class through ctypes (entity names are passed as int64 ids).
+// ---------------------------------------------------------------------------
+using mvtm::FastQMVWVParallelTopicModel;
+
+static thread_local std::string g_host_err;
+
+extern "C" {
+
+const char* mvtm_last_error(void) { return g_host_err.c_str(); }
+
+void* mvtm_model_new(int K, int M, double alpha, double beta)
+{
+    try { return new FastQMVWVParallelTopicModel(K, (int8_t)M, alpha, beta); }
+    catch (const std::exception& e) { g_host_err = e.what(); return nullptr; }
+}
+
+void mvtm_model_delete(void* p) { delete (FastQMVWVParallelTopicModel*)p; }
+
+int mvtm_model_configure(void* p, int numIterations, int burninPeriod, int optimizeInterval, int randomSeed, int device, int64_t docIdBase)
+{
+    auto* m = (FastQMVWVParallelTopicModel*)p;
+    m->setNumIterations(numIterations); m->setBurninPeriod(burninPeriod);
+    m->setOptimizeInterval(optimizeInterval); m->setRandomSeed(randomSeed);
+    m->setDevice(device); m->setDocIdBase(docIdBase);
+    return 0;
+}
+
+// per view v: n_inst[v] instances with names name_ids[v][i], features tokens[v][off[v][i]..off[v][i+1])
+int mvtm_model_add_instances(void* p, int M, const int64_t* n_inst, const int64_t* const* name_ids,
+                             const int64_t* const* off, const int32_t* const* tokens, const int32_t* alphabet)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    try {
+        std::vector<mvtm::InstanceList> training(M);
+        for (int v = 0; v < M; v++) {
+            training[v].alphabetSize = alphabet[v];
+            training[v].instances.resize((size_t)n_inst[v]);
+            for (int64_t i = 0; i < n_inst[v]; i++) {
+                training[v].instances[i].name = std::to_string(name_ids[v][i]);
+                training[v].instances[i].features.assign(tokens[v] + off[v][i], tokens[v] + off[v][i + 1]);
+            }
+        }
+        model->addInstances(training);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_model_estimate(void* p)
+{
+    try { ((FastQMVWVParallelTopicModel*)p)->estimate(); return 0; }
+    catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int64_t mvtm_model_num_entities(void* p) { return (int64_t)((FastQMVWVParallelTopicModel*)p)->data.size(); }
+
+int64_t mvtm_model_view_tokens(void* p, int m)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    int64_t n = 0;
+    for (auto& e : model->data) n += (int64_t)e.Assignments[m].tokens.size();
+    return n;
+}
+
+// entity names (as ids), CSR offsets, tokens and topics of view m in `data` order
+int mvtm_model_get_view(void* p, int m, int64_t* entity_ids, int64_t* off, int32_t* tokens, int32_t* topics)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    int64_t o = 0, d = 0;
+    if (off) off[0] = 0;
+    for (auto& e : model->data) {
+        const auto& ta = e.Assignments[m];
+        if (entity_ids) entity_ids[d] = std::stoll(e.EntityId);
+        if (tokens) std::copy(ta.tokens.begin(), ta.tokens.end(), tokens + o);
+        if (topics) std::copy(ta.topics.begin(), ta.topics.end(), topics + o);
+        o += (int64_t)ta.tokens.size();
+        d++;
+        if (off) off[d] = o;
+    }
+    return 0;
+}
+
+int mvtm_model_get_counts(void* p, int m, int32_t* typeTopicCounts, int32_t* tokensPerTopic)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    if (typeTopicCounts) std::copy(model->typeTopicCounts[m].begin(), model->typeTopicCounts[m].end(), typeTopicCounts);
+    if (tokensPerTopic) std::copy(model->tokensPerTopic[m].begin(), model->tokensPerTopic[m].end(), tokensPerTopic);
+    return 0;
+}
+
+int mvtm_model_get_log(void* p, int i, double* ms, mvhdp_sweep_stats* st)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    if (i < 0 || i >= (int)model->iterationLog.size()) return -1;
+    if (ms) *ms = model->iterationLog[i].ms;
+    if (st) *st = model->iterationLog[i].stats;
+    return 0;
+}
+
+void* mvtm_model_native_handle(void* p) { return ((FastQMVWVParallelTopicModel*)p)->nativeHandle(); }
+
+// PTM:465-515 on a flattened corpus: the same draw order as addInstances (for harnesses that
+// already hold CSR arrays, e.g. bench.py on a 1M-entity synthetic corpus).
+int mvtm_init_assignments(int K, int M, int64_t D, const int64_t* const* doc_off, int64_t seed, int32_t* const* z_out)
+{
+    mvtm::Randoms random(seed);
+    std::vector<int32_t> activeTopics;
+    for (int64_t d = 0; d < D; d++) {
+        for (int m = 0; m < M; m++) {
+            if (m == 0) activeTopics.clear();
+            for (int64_t i = doc_off[m][d]; i < doc_off[m][d + 1]; i++) {
+                int topic;
+                if (m == 0) { topic = random.nextInt(K); activeTopics.push_back(topic); }
+                else if (!activeTopics.empty()) topic = activeTopics[random.nextInt((int32_t)activeTopics.size())];
+                else topic = random.nextInt(K);
+                z_out[m][i] = topic;
+            }
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

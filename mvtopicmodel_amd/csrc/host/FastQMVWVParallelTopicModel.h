@@ -1,0 +1,121 @@
+// FastQMVWVParallelTopicModel.h — C++ host-side mirror of the hot subset of
+// org.madgik.MVTopicModel.FastQMVWVParallelTopicModel (PTM).  The reference's
+// host language (Java) has no toolchain in the build image, so the host side
+// above the C ABI is written in C++ with the reference's names, argument
+// meaning and call order: ctor PTM:183, setters PTM:273-335, addInstances
+// PTM:396, estimate PTM:1033.  The iteration body of estimate()
+// ("submit updaters + submit workers + barrier.await()", PTM:1213-1239) is one
+// mvhdp_sweep() call on the GPU.  The Java/JNI form of the same class is in
+// INTEGRATION.md.
+#pragma once
+#include <cstdint>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../../include/mvhdp.h"
+
+namespace mvtm {
+
+// MALLET Instance restricted to what the path reads: getName() (PTM:437) and the
+// FeatureSequence indices of getData() (PTM:427).
+struct Instance {
+    std::string name;
+    std::vector<int32_t> features;
+};
+
+// MALLET InstanceList: instances + getDataAlphabet().size() (PTM:412-413).
+struct InstanceList {
+    std::vector<Instance> instances;
+    int32_t alphabetSize = 0;
+};
+
+// cc.mallet.topics.TopicAssignment: instance + topicSequence (LabelSequence features).
+struct TopicAssignment {
+    bool present = false;                 // false == null (MTA:19)
+    std::vector<int32_t> tokens;          // instance.getData()
+    std::vector<int32_t> topics;          // topicSequence.getFeatures(), sized by getLength()
+};
+
+// org.madgik.utils.MixTopicModelTopicAssignment (MTA:11-43)
+struct MixTopicModelTopicAssignment {
+    std::string EntityId;
+    std::vector<TopicAssignment> Assignments;   // [numModalities]
+};
+
+struct IterationLog {
+    int iteration;
+    double ms;                                   // PTM:1272-1277
+    mvhdp_sweep_stats stats;
+};
+
+class FastQMVWVParallelTopicModel {
+public:
+    static constexpr int UNASSIGNED_TOPIC = -1;  // PTM:63
+
+    // PTM:183.  useCycleProposals / SQLConnectionString / useTypeVectors / vectorsLambda /
+    // trainTypeVectors belong to subsystems outside the hot path; they are accepted for
+    // signature compatibility and must be false/empty/0 (embedding mix off, FLOW:68-69).
+    FastQMVWVParallelTopicModel(int numberOfTopics, int8_t numModalities, double alpha, double beta,
+                                bool useCycleProposals = false, const std::string& SQLConnectionString = "",
+                                bool useTypeVectors = false, double vectorsLambda = 0, bool trainTypeVectors = false);
+    ~FastQMVWVParallelTopicModel();
+    FastQMVWVParallelTopicModel(const FastQMVWVParallelTopicModel&) = delete;
+    FastQMVWVParallelTopicModel& operator=(const FastQMVWVParallelTopicModel&) = delete;
+
+    // PTM:273-335
+    void setNumIterations(int n) { numIterations = n; }
+    void setBurninPeriod(int n) { burninPeriod = n; }
+    void setRandomSeed(int seed) { randomSeed = seed; }
+    void setOptimizeInterval(int interval) { optimizeInterval = interval; }
+    void setNumThreads(int threads) { numThreads = threads; }   // a hint only: parallelism is the GPU's
+    void setDevice(int device) { device_ = device; }
+    void setDocIdBase(int64_t base) { docIdBase_ = base; }      // document shards: global id of entity 0
+
+    // PTM:396.  batchId / vectorSize / previousModel are outside the hot path (previousModel must be null).
+    void addInstances(const std::vector<InstanceList>& training, const std::string& batchId = "", int vectorSize = 0);
+
+    // PTM:1033.  Blocks until numIterations sweeps are done.  Throws std::runtime_error on a device error.
+    void estimate();
+
+    // state the reference exposes as public fields
+    std::vector<MixTopicModelTopicAssignment> data;             // PTM:67
+    int numTopics;                                              // PTM:72
+    int8_t numModalities;                                       // PTM:71
+    std::vector<int> numTypes;                                  // PTM:78
+    std::vector<std::vector<double>> alpha;                     // PTM:79  [M][K+1]
+    std::vector<double> alphaSum, beta, betaSum, gamma;         // PTM:80-83
+    std::vector<std::vector<int32_t>> typeTopicCounts;          // PTM:86  per view, [V_m*K] row-major
+    std::vector<std::vector<int32_t>> tokensPerTopic;           // PTM:87  [M][K]
+    std::vector<int> totalTokens;                               // PTM:89
+    std::vector<int> totalDocsPerModality;                      // PTM:90
+    std::vector<std::vector<int32_t>> docLengthCounts;          // PTM:107
+    std::vector<std::vector<int32_t>> topicDocCounts;           // PTM:108 per view, [K*(histogramSize+1)]
+    std::vector<int> histogramSize;                             // PTM:109
+    std::set<int> inActiveTopicIndex;                           // PTM:95
+    std::vector<std::vector<double>> p_a, p_b;                  // PTM:130-131
+    std::vector<std::vector<int>> typeTotals;                   // PTM:169
+    std::vector<int> maxTypeCount;                              // PTM:171
+    int numIterations = 1000;                                   // PTM:111
+    int burninPeriod = 200;                                     // PTM:112
+    int optimizeInterval = 50;                                  // PTM:114
+    int randomSeed = -1;                                        // PTM:126
+    int numThreads = 1;                                         // PTM:173
+
+    // what the log lines of PTM:1272-1310 would have shown
+    std::vector<IterationLog> iterationLog;
+    mvhdp_handle nativeHandle() const { return h_; }
+
+    // refresh typeTopicCounts / tokensPerTopic / topicDocCounts / data[].topics from the device
+    void syncFromDevice(bool histograms = true);
+
+private:
+    void initializeHistograms();          // PTM:849-897
+    void pushHyper();
+    void check(int rc, const char* what);
+    mvhdp_handle h_ = nullptr;
+    int device_ = 0;
+    int64_t docIdBase_ = 0;
+};
+
+}  // namespace mvtm

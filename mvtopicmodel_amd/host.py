@@ -1,0 +1,138 @@
+"""ctypes view of the C++ host mirror of FastQMVWVParallelTopicModel
+(csrc/host/, hooks declared in include/mvtm_host.h)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import SweepStatsC, load_library
+
+HOST_SYMBOLS = [
+    "mvtm_last_error", "mvtm_model_new", "mvtm_model_delete", "mvtm_model_configure",
+    "mvtm_model_add_instances", "mvtm_model_estimate", "mvtm_model_num_entities",
+    "mvtm_model_view_tokens", "mvtm_model_get_view", "mvtm_model_get_counts",
+    "mvtm_model_get_log", "mvtm_model_native_handle", "mvtm_init_assignments",
+]
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    L = load_library()
+    if not _ready:
+        vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+        L.mvtm_last_error.restype = C.c_char_p
+        L.mvtm_model_new.argtypes = [i32, i32, dbl, dbl]; L.mvtm_model_new.restype = vp
+        L.mvtm_model_delete.argtypes = [vp]; L.mvtm_model_delete.restype = None
+        L.mvtm_model_configure.argtypes = [vp, i32, i32, i32, i32, i32, i64]
+        L.mvtm_model_add_instances.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        L.mvtm_model_estimate.argtypes = [vp]
+        L.mvtm_model_num_entities.argtypes = [vp]; L.mvtm_model_num_entities.restype = i64
+        L.mvtm_model_view_tokens.argtypes = [vp, i32]; L.mvtm_model_view_tokens.restype = i64
+        L.mvtm_model_get_view.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.mvtm_model_get_counts.argtypes = [vp, i32, vp, vp]
+        L.mvtm_model_get_log.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(SweepStatsC)]
+        L.mvtm_model_native_handle.argtypes = [vp]; L.mvtm_model_native_handle.restype = vp
+        L.mvtm_init_assignments.argtypes = [i32, i32, i64, vp, i64, vp]
+        _ready = True
+    return L
+
+
+def init_assignments(K, doc_off, seed):
+    """PTM:465-515 draw order on CSR arrays (java.util.Random(seed)); returns z per view."""
+    L = _lib()
+    M = len(doc_off)
+    offs = [np.ascontiguousarray(o, dtype=np.int64) for o in doc_off]
+    D = len(offs[0]) - 1
+    z = [np.empty(int(o[-1]), dtype=np.int32) for o in offs]
+    op = (C.c_void_p * M)(*[o.ctypes.data for o in offs])
+    zp = (C.c_void_p * M)(*[a.ctypes.data for a in z])
+    rc = L.mvtm_init_assignments(int(K), M, D, C.cast(op, C.c_void_p), int(seed), C.cast(zp, C.c_void_p))
+    if rc:
+        raise RuntimeError("mvtm_init_assignments failed")
+    return z
+
+
+class FastQMVWVParallelTopicModel:
+    """Same verbs as the reference class: ctor, set*, addInstances, estimate."""
+
+    def __init__(self, numberOfTopics, numModalities, alpha, beta):
+        self.L = _lib()
+        self.K, self.M = int(numberOfTopics), int(numModalities)
+        self.p = self.L.mvtm_model_new(self.K, self.M, float(alpha), float(beta))
+        if not self.p:
+            raise ValueError(self.L.mvtm_last_error().decode())
+        self._cfg = dict(numIterations=1000, burninPeriod=200, optimizeInterval=50, randomSeed=-1, device=0, docIdBase=0)
+        self.V = None
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.mvtm_model_delete(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _push_cfg(self):
+        c = self._cfg
+        self.L.mvtm_model_configure(self.p, c["numIterations"], c["burninPeriod"], c["optimizeInterval"],
+                                    c["randomSeed"], c["device"], c["docIdBase"])
+
+    def setNumIterations(self, n): self._cfg["numIterations"] = int(n)
+    def setBurninPeriod(self, n): self._cfg["burninPeriod"] = int(n)
+    def setOptimizeInterval(self, n): self._cfg["optimizeInterval"] = int(n)
+    def setRandomSeed(self, s): self._cfg["randomSeed"] = int(s)
+    def setNumThreads(self, n): pass
+    def setDevice(self, d): self._cfg["device"] = int(d)
+
+    def addInstances(self, training):
+        """training: per view (name_ids int64[n], off int64[n+1], tokens int32[N], alphabetSize)."""
+        M = self.M
+        assert len(training) == M
+        self._push_cfg()
+        names = [np.ascontiguousarray(t[0], dtype=np.int64) for t in training]
+        offs = [np.ascontiguousarray(t[1], dtype=np.int64) for t in training]
+        toks = [np.ascontiguousarray(t[2], dtype=np.int32) for t in training]
+        n_inst = np.array([len(n) for n in names], dtype=np.int64)
+        alphabet = np.array([int(t[3]) for t in training], dtype=np.int32)
+        self.V = [int(a) for a in alphabet]
+        arr = lambda xs: C.cast((C.c_void_p * M)(*[x.ctypes.data for x in xs]), C.c_void_p)
+        rc = self.L.mvtm_model_add_instances(self.p, M, n_inst.ctypes.data_as(C.c_void_p), arr(names), arr(offs), arr(toks),
+                                             alphabet.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+
+    def estimate(self):
+        self._push_cfg()
+        if self.L.mvtm_model_estimate(self.p):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+
+    def num_entities(self):
+        return int(self.L.mvtm_model_num_entities(self.p))
+
+    def get_view(self, m):
+        D = self.num_entities()
+        N = int(self.L.mvtm_model_view_tokens(self.p, m))
+        ids = np.empty(D, dtype=np.int64); off = np.empty(D + 1, dtype=np.int64)
+        tok = np.empty(N, dtype=np.int32); top = np.empty(N, dtype=np.int32)
+        self.L.mvtm_model_get_view(self.p, m, ids.ctypes.data, off.ctypes.data, tok.ctypes.data, top.ctypes.data)
+        return ids, off, tok, top
+
+    def get_counts(self, m):
+        nwk = np.empty((self.V[m], self.K), dtype=np.int32); nk = np.empty(self.K, dtype=np.int32)
+        self.L.mvtm_model_get_counts(self.p, m, nwk.ctypes.data, nk.ctypes.data)
+        return nwk, nk
+
+    def iteration_log(self):
+        out = []
+        i = 0
+        while True:
+            ms = C.c_double(); st = SweepStatsC()
+            if self.L.mvtm_model_get_log(self.p, i, C.byref(ms), C.byref(st)):
+                break
+            out.append((ms.value, {f: getattr(st, f) for f, _ in SweepStatsC._fields_}))
+            i += 1
+        return out

@@ -38,6 +38,14 @@ def rand_unit(seed, stream, start, n):
     return (rand_u64(seed, stream, start, n) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
 
 
+def rand_unit_at(seed, stream, idx):
+    """Uniforms for arbitrary counters idx (int64 array)."""
+    with np.errstate(over="ignore"):
+        base = _mix(np.array([np.uint64(seed) ^ (np.uint64(stream) * np.uint64(0xD1B54A32D192ED03))], dtype=np.uint64))[0]
+        x = _mix(base + (idx.astype(np.uint64) + np.uint64(1)) * _GOLD)
+    return (x >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
 def _poisson_from_unit(u, lam):
     """Inverse-CDF Poisson (table up to lam + 12 sqrt(lam) + 20)."""
     kmax = int(lam + 12 * np.sqrt(lam) + 20)
@@ -79,9 +87,46 @@ class Corpus:
         return Corpus(self.K, list(self.V), offs, toks, f"{self.name}[{lo}:{hi}]")
 
 
-def generate(K, V, D, lam, seed, presence=None, power_law_text=False, chunk_docs=8192, name=""):
-    """Generate a corpus.  lam[v] = Poisson mean of the length of view v."""
+def _doc_lengths(V, lo, hi, lam, seed, presence, power_law_text):
+    """Per-view lengths of entities [lo,hi): depends only on (seed, entity id)."""
+    n = hi - lo
+    out = []
+    for v in range(len(V)):
+        pres = rand_unit(seed, 10 + v, lo, n) < presence[v]
+        if power_law_text and v == 0:
+            u = 1.0 - rand_unit(seed, 20 + v, lo, n)
+            L = np.minimum(2048, np.floor(32.0 * u ** (-1.0 / 1.5))).astype(np.int64)
+        else:
+            L = 1 + _poisson_from_unit(rand_unit(seed, 20 + v, lo, n), float(lam[v]))
+        out.append(np.where(pres, L, 0))
+    return out
+
+
+def doc_token_counts(K, V, D, lam, seed, presence=None, power_law_text=False):
+    """Total tokens of every entity (all views) without generating the tokens: used to
+    cut document shards balanced by token count."""
     M = len(V)
+    if presence is None:
+        presence = [1.0] + [0.8] * (M - 1)
+    tot = np.zeros(D, dtype=np.int64)
+    for c0 in range(0, D, 1 << 18):
+        c1 = min(D, c0 + (1 << 18))
+        for L in _doc_lengths(V, c0, c1, lam, seed, presence, power_law_text):
+            tot[c0:c1] += L
+    return tot
+
+
+_POS_BITS = 12   # per-token draws are indexed by (entity << 12 | position); lengths are <= 2048
+
+
+def generate(K, V, D, lam, seed, presence=None, power_law_text=False, chunk_docs=8192, name="",
+             doc_lo=0, doc_hi=None):
+    """Generate entities [doc_lo, doc_hi) of the D-entity corpus (default: all).  Every draw
+    is a function of (seed, entity id, position), so any shard can be generated alone and
+    equals the same slice of the full corpus.  lam[v] = Poisson mean of the length of view v."""
+    M = len(V)
+    if doc_hi is None:
+        doc_hi = D
     if presence is None:
         presence = [1.0] + [0.8] * (M - 1)
     K_true = max(1, K // 2)
@@ -97,12 +142,12 @@ def generate(K, V, D, lam, seed, presence=None, power_law_text=False, chunk_docs
                 x += 2
             A[v, t] = x % V[v] if V[v] > 1 else 0
         B[v] = b
-    doc_off = [np.zeros(D + 1, dtype=np.int64) for _ in range(M)]
+    nd = doc_hi - doc_lo
+    doc_off = [np.zeros(nd + 1, dtype=np.int64) for _ in range(M)]
     tok_chunks = [[] for _ in range(M)]
-    tok_counter = [0] * M
     TMAX = 24
-    for c0 in range(0, D, chunk_docs):
-        c1 = min(D, c0 + chunk_docs)
+    for c0 in range(doc_lo, doc_hi, chunk_docs):
+        c1 = min(doc_hi, c0 + chunk_docs)
         n = c1 - c0
         T = 1 + _poisson_from_unit(rand_unit(seed, 1, c0, n), 3.0)
         T = np.minimum(T, TMAX)
@@ -113,29 +158,26 @@ def generate(K, V, D, lam, seed, presence=None, power_law_text=False, chunk_docs
         e[np.arange(tmax)[None, :] >= T[:, None]] = 0.0
         cum = np.cumsum(e, axis=1)
         cum /= cum[:, -1:]
+        lens = _doc_lengths(V, c0, c1, lam, seed, presence, power_law_text)
         for v in range(M):
-            pres = rand_unit(seed, 10 + v, c0, n) < presence[v]
-            if power_law_text and v == 0:
-                u = 1.0 - rand_unit(seed, 20 + v, c0, n)
-                L = np.minimum(2048, np.floor(32.0 * u ** (-1.0 / 1.5))).astype(np.int64)
-            else:
-                L = 1 + _poisson_from_unit(rand_unit(seed, 20 + v, c0, n), float(lam[v]))
-            L = np.where(pres, L, 0)
-            doc_off[v][c0 + 1:c1 + 1] = L
+            L = lens[v]
+            doc_off[v][c0 - doc_lo + 1:c1 - doc_lo + 1] = L
             nt = int(L.sum())
             if nt == 0:
                 continue
             doc_of = np.repeat(np.arange(n), L)
-            ut = rand_unit(seed, 30 + v, tok_counter[v], nt)
+            starts = np.cumsum(L) - L
+            pos = np.arange(nt, dtype=np.int64) - np.repeat(starts, L)
+            idx = ((doc_of.astype(np.int64) + c0) << _POS_BITS) | pos
+            ut = rand_unit_at(seed, 30 + v, idx)
             j = (cum[doc_of] < ut[:, None]).sum(axis=1)
             j = np.minimum(j, T[doc_of] - 1)
             t = tt[doc_of, j]
-            ur = rand_unit(seed, 40 + v, tok_counter[v], nt)
+            ur = rand_unit_at(seed, 40 + v, idx)
             r = np.floor(np.exp(ur * np.log(V[v] + 1.0))).astype(np.int64) - 1
             r = np.clip(r, 0, V[v] - 1)
             w = (r * A[v, t] + B[v, t]) % V[v]
             tok_chunks[v].append(w.astype(np.int32))
-            tok_counter[v] += nt
     tokens = []
     for v in range(M):
         np.cumsum(doc_off[v], out=doc_off[v])
@@ -153,9 +195,27 @@ CONFIGS = {
 }
 
 
-def make_config(name, D=None):
+def make_config(name, D=None, doc_lo=0, doc_hi=None):
     c = dict(CONFIGS[name])
     if D is not None:
         c["D"] = int(D)
     return generate(c["K"], c["V"], c["D"], c["lam"], c["seed"],
-                    power_law_text=c.get("power_law_text", False), name=name)
+                    power_law_text=c.get("power_law_text", False), name=name, doc_lo=doc_lo, doc_hi=doc_hi)
+
+
+def config_doc_token_counts(name, D=None):
+    c = dict(CONFIGS[name])
+    if D is not None:
+        c["D"] = int(D)
+    return doc_token_counts(c["K"], c["V"], c["D"], c["lam"], c["seed"], power_law_text=c.get("power_law_text", False))
+
+
+def shard_bounds(doc_tokens, n_shards):
+    """Contiguous entity ranges balanced by token count."""
+    cs = np.concatenate([[0], np.cumsum(doc_tokens)])
+    total = cs[-1]
+    cuts = [0]
+    for r in range(1, n_shards):
+        cuts.append(int(np.searchsorted(cs, total * r / n_shards, side="left")))
+    cuts.append(len(doc_tokens))
+    return [(cuts[r], cuts[r + 1]) for r in range(n_shards)]
