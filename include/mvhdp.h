@@ -101,6 +101,7 @@ typedef struct {
 #define MVHDP_SWEEP_REUSE_TREES 0x1u  /* do not rebuild the F+trees from the counts first (PTM:1209 cadence is the host's) */
 #define MVHDP_SWEEP_NO_APPLY    0x2u  /* leave the deltas unapplied (multi-GPU: all-reduce MVHDP_BUF_DELTA, then mvhdp_apply_delta) */
 #define MVHDP_SWEEP_EXACT_CHAIN 0x4u  /* always use the sequential WRK:501-513 sum (test mode for the certified scan) */
+#define MVHDP_SWEEP_GENERIC_KERNEL 0x8u /* force the LDS-resident kernel even when the register-resident one applies (test mode) */
 
 /* device buffers a host may hand to a collective (RCCL through torch.distributed or directly) */
 typedef enum {

@@ -42,6 +42,8 @@ struct mvhdp_ctx {
 
     unsigned long long* d_stats = nullptr;   // [ST_COUNT]
     long long* d_act_key = nullptr;
+    unsigned long long* d_doc_counter = nullptr;
+    int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
     size_t lds_attr_set = 0;
 };
 
@@ -109,6 +111,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMemset(h->d_inactive, 0, (size_t)K));
     CREATE_HIP(hipMalloc(&h->d_stats, ST_COUNT * sizeof(unsigned long long)));
     CREATE_HIP(hipMalloc(&h->d_act_key, sizeof(long long)));
+    CREATE_HIP(hipMalloc(&h->d_doc_counter, sizeof(unsigned long long)));
     mm.alpha = h->d_alpha;
     mm.inactive = h->d_inactive;
     h->h_alpha.assign((size_t)M * (K + 1), 0.0);
@@ -136,6 +139,8 @@ extern "C" int mvhdp_destroy(mvhdp_handle h)
     if (h->d_inactive) hipFree(h->d_inactive);
     if (h->d_stats) hipFree(h->d_stats);
     if (h->d_act_key) hipFree(h->d_act_key);
+    if (h->d_doc_counter) hipFree(h->d_doc_counter);
+    if (h->d_doc_order) hipFree(h->d_doc_order);
     for (auto& e : h->ev) if (e) hipEventDestroy(e);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -196,6 +201,7 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     h->N[m] = N;
     h->have_corpus[m] = true;
     h->max_doc_tokens = -1;
+    if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
     mm.D = D;
     mm.doc_off[m] = (const int64_t*)h->d_doc_off[m];
     mm.tok[m] = (const int32_t*)h->d_tok[m];
@@ -355,15 +361,31 @@ extern "C" int mvhdp_get_doc_topic_hist(mvhdp_handle h, int32_t m, int32_t* hist
     return MVHDP_OK;
 }
 
+// Largest entity (sizes the slot list) and the work-queue order: longest entities first,
+// so that the tail of the sweep is made of short ones (power-law lengths).
 static int64_t compute_max_doc_tokens(mvhdp_ctx* h)
 {
     if (h->max_doc_tokens >= 0) return h->max_doc_tokens;
-    int64_t mx = 0;
+    int64_t mx = 0, mn = INT64_MAX;
     const MvModel& mm = h->mm;
+    std::vector<int64_t> tot((size_t)mm.D);
     for (int64_t d = 0; d < mm.D; d++) {
         int64_t t = 0;
         for (int m = 0; m < mm.M; m++) t += h->h_doc_off[m][d + 1] - h->h_doc_off[m][d];
-        mx = std::max(mx, t);
+        tot[d] = t;
+        mx = std::max(mx, t); mn = std::min(mn, t);
+    }
+    if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
+    if (mm.D > 0 && mx > 4 * std::max<int64_t>(mn, 16) && mm.D < (1LL << 31)) {
+        // counting sort by decreasing length (stable: ties keep entity order)
+        std::vector<int64_t> start((size_t)mx + 2, 0);
+        for (int64_t d = 0; d < mm.D; d++) start[(size_t)(mx - tot[d]) + 1]++;
+        for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
+        std::vector<int32_t> order((size_t)mm.D);
+        for (int64_t d = 0; d < mm.D; d++) order[(size_t)start[(size_t)(mx - tot[d])]++] = (int32_t)d;
+        if (hipMalloc(&h->d_doc_order, (size_t)mm.D * sizeof(int32_t)) == hipSuccess)
+            hipMemcpy(h->d_doc_order, order.data(), (size_t)mm.D * sizeof(int32_t), hipMemcpyHostToDevice);
+        else h->d_doc_order = nullptr;
     }
     h->max_doc_tokens = mx;
     return mx;
@@ -405,7 +427,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "sweep before set_hyper");
     if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "sweep before build_counts/set_counts");
     if ((flags & MVHDP_SWEEP_REUSE_TREES) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES without trees");
-    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
     const int K = mm.K, M = mm.M;
     HIPC(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -418,22 +440,28 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
     sl.flags = flags; sl.S_cap = S_cap;
     sl.block_shared_bytes = (uint32_t)(((size_t)M * K * sizeof(int) + 15) & ~(size_t)15);
-    sl.wave_bytes = (uint32_t)mvhdp_sweep_wave_bytes(M, S_cap);
+    const bool debug = dbg != nullptr;
+    const bool fast = (S_cap <= 256) && !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
+    const int rmax = S_cap / 64;
+    sl.wave_bytes = (uint32_t)(fast ? mvhdp_sweep_fast_wave_bytes(M, S_cap) : mvhdp_sweep_wave_bytes(M, S_cap));
     int wpb = 4;
     while (wpb > 1 && sl.block_shared_bytes + (size_t)wpb * sl.wave_bytes > h->max_lds) wpb >>= 1;
     size_t lds = sl.block_shared_bytes + (size_t)wpb * sl.wave_bytes;
     if (lds > h->max_lds) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB (K * modalities too large)");
     sl.waves_per_block = wpb;
-    if (lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
-    int blocks_per_cu = (int)std::min<size_t>(h->max_lds / lds, (size_t)(32 / wpb));
-    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
-    int64_t need = (mm.D + wpb - 1) / wpb;
+    if (!fast && lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
+    // persistent grid = what is resident at once; the work queue balances the rest
+    int blocks_per_cu = fast ? mvhdp_sweep_fast_occupancy(rmax, debug, 64 * wpb, lds)
+                             : mvhdp_sweep_generic_occupancy(debug, 64 * wpb, lds);
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    int64_t need = (mm.D + (int64_t)wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)wpb * MVHDP_DOC_BATCH);
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * blocks_per_cu));
     sl.stats = h->d_stats;
     sl.act_key = h->d_act_key;
+    sl.doc_counter = h->d_doc_counter;
+    sl.doc_order = h->d_doc_order;
 
     // debug buffers
-    const bool debug = dbg != nullptr;
     std::vector<void*> to_free;
     auto cleanup = [&]() { for (void* p : to_free) hipFree(p); };
     if (debug) {
@@ -480,8 +508,10 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     step(hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
     const long long kmax = LLONG_MAX;
     step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
+    step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
     step(hipEventRecord(h->ev[1], s));
-    if (e == hipSuccess && mm.D > 0) step(mvhdp_launch_sweep(mm, sl, grid, debug, s));
+    if (e == hipSuccess && mm.D > 0)
+        step(fast ? mvhdp_launch_sweep_fast(mm, sl, rmax, grid, debug, s) : mvhdp_launch_sweep(mm, sl, grid, debug, s));
     step(hipEventRecord(h->ev[2], s));
     unsigned long long hs[ST_COUNT] = {0};
     long long act = LLONG_MAX;

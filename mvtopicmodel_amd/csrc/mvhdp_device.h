@@ -40,6 +40,8 @@ struct SweepLaunch {
     uint32_t wave_bytes;               // per-wave LDS region
     unsigned long long* stats;         // [16] device counters
     long long* act_key;                // activation key (atomicMin)
+    unsigned long long* doc_counter;   // work queue head: waves pull entities in batches
+    const int32_t* doc_order;          // optional permutation (longest entities first), or nullptr
     // debug
     double* tok_dbg[MVHDP_MAXM];
     int32_t n_trace;
@@ -61,3 +63,9 @@ hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats
 hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
                                        int32_t* doc_len_counts, int32_t len_len, hipStream_t s);
 hipError_t mvhdp_sweep_set_max_lds(size_t bytes);
+size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap);
+hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);
+int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes);
+int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes);
+
+#define MVHDP_DOC_BATCH 2

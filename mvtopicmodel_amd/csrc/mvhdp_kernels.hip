@@ -15,75 +15,7 @@
 #include "mvhdp_device.h"
 #include "../../include/mvhdp.h"
 
-#define WAVE 64
-// LDS accesses of one wave execute in issue order, so within a wave only the
-// compiler has to be kept from reordering / caching LDS traffic.
-#define LDS_FENCE() asm volatile("" ::: "memory")
-
-// ---------------------------------------------------------------------------
-// small wave-level helpers
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
-
-__device__ __forceinline__ int bcast_i(int v, int src_lane)
-{
-    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_lane));
-}
-
-__device__ __forceinline__ double bcast_d(double v, int src_lane)
-{
-    int s = __builtin_amdgcn_readfirstlane(src_lane);
-    long long b = __double_as_longlong(v);
-    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), s);
-    int hi = __builtin_amdgcn_readlane((int)(b >> 32), s);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// inclusive prefix sums across the 64 lanes (any association order is fine:
-// the fp64 one is only used under the certified-scan tolerance, see below)
-__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
-{
-#pragma unroll
-    for (int s = 1; s < WAVE; s <<= 1) {
-        int o = __shfl_up(v, s, WAVE);
-        if (lane >= s) v += o;
-    }
-    return v;
-}
-
-__device__ __forceinline__ double wave_incl_scan_d(double v, int lane)
-{
-#pragma unroll
-    for (int s = 1; s < WAVE; s <<= 1) {
-        double o = __shfl_up(v, s, WAVE);
-        if (lane >= s) v += o;
-    }
-    return v;
-}
-
-// ---------------------------------------------------------------------------
-// Philox4x32-10 (Random123); the stream contract is in DESIGN.md §RNG
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4])
-{
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ double bits_to_unit(uint32_t hi, uint32_t lo)
-{
-    // the 53-bit shape of ThreadLocalRandom.nextDouble() (WRK:517,534)
-    unsigned long long x = ((unsigned long long)hi << 32) | lo;
-    return (double)(x >> 11) * 0x1.0p-53;
-}
+#include "mvhdp_wave.h"
 
 // ---------------------------------------------------------------------------
 // build_counts: PTM:600-652.  One thread per token, int32 atomics.
@@ -276,39 +208,6 @@ hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t s
 }
 
 // ---------------------------------------------------------------------------
-// FTree.sample (FT:111-136) against the stored tree of one (view,type).
-// The descent reads whole sub-trees per round: the 62 nodes of the five levels
-// below the current node sit in 5 contiguous runs of the tree array, one node
-// per lane, so a K<=2048 descent needs at most 3 dependent load rounds instead
-// of log2(K) of them.  All lanes walk the same path (u is wave-uniform).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ int tree_sample(const double* __restrict__ tree, int K, double u2, double root, int lane)
-{
-    int i = 1;
-    double u = u2 * root;                                  // FT:120  u = u * tree[1]
-    const int j = lane + 2;
-    const int t = 31 - __clz(j);                           // 1..6 (6 only for lanes 62,63: unused)
-    const int o = j - (1 << t);
-    while (i < K) {                                        // FT:122
-        long long idx = ((long long)i << t) + o;
-        double v = (lane < 62 && idx < 2LL * K) ? tree[idx] : 0.0;
-        int rel_t = 0, rel_o = 0;
-#pragma unroll
-        for (int step = 0; step < 5; step++) {
-            if (i < K) {
-                int src = (2 << rel_t) + 2 * rel_o - 2;   // lane holding tree[2*i]
-                double l = bcast_d(v, src);
-                if (u < l) { i = 2 * i; rel_o = 2 * rel_o; }               // FT:124-125
-                else { u = u - l; i = 2 * i + 1; rel_o = 2 * rel_o + 1; }  // FT:127-128
-                rel_t++;
-            }
-        }
-        i = uniform_i(i);
-    }
-    return i - K;                                          // FT:132
-}
-
-// ---------------------------------------------------------------------------
 // The sweep.  Per wave (one entity at a time), LDS holds the "dense index" of
 // WRK:376-391 in slot form:
 //   bitmap[ceil(K/32)]  topics present in the entity (any view) at entry
@@ -363,8 +262,15 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
 
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
 
-    const int64_t wstride = (int64_t)gridDim.x * sl.waves_per_block;
-    for (int64_t d = (int64_t)blockIdx.x * sl.waves_per_block + wave; d < mm.D; d += wstride) {
+    // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
+    for (;;) {
+      long long q0 = 0;
+      if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)MVHDP_DOC_BATCH);
+      q0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)q0);
+      if (q0 >= mm.D) break;
+      const long long q1 = (q0 + MVHDP_DOC_BATCH < mm.D) ? q0 + MVHDP_DOC_BATCH : mm.D;
+      for (long long q = q0; q < q1; q++) {
+        const int64_t d = sl.doc_order ? (int64_t)sl.doc_order[q] : (int64_t)q;
         const int64_t dg = mm.doc_id_base + d;
 
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
@@ -643,6 +549,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
         }
         if (aborted) n_abort++;
         LDS_FENCE();
+      }
     }
 
     __syncthreads();
@@ -666,6 +573,14 @@ hipError_t mvhdp_sweep_set_max_lds(size_t bytes)
     hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes)
+{
+    int nb = 0;
+    hipError_t e = debug ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_kernel<true>, block_threads, lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_kernel<false>, block_threads, lds_bytes);
+    return e == hipSuccess ? nb : 0;
 }
 
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s)

@@ -1,0 +1,456 @@
+// mvhdp_sweep_fast.hip — the register-resident form of the sweep kernel for
+// entities whose topic list fits 64*RMAX slots (RMAX <= 4: every BASELINE
+// config except the K=1000 power-law one, which takes the generic LDS kernel
+// of mvhdp_kernels.hip).  Same arithmetic, same order, same results as the
+// generic kernel; what changes is where the per-entity state lives:
+//
+//   slot i = r*64 + lane  (r < RMAX)      -> lane registers
+//     skr[r]  topic of the slot, sign bit = removed from the list (WRK:451-468)
+//     cn[r]   localTopicCounts[m][topic] of the view being sampled (WRK:357,437,560)
+//     oth[r]  totalMassOtherModalities[topic]                       (WRK:399-410)
+//     den[r]  tokensPerTopic[m][topic] + betaSum[m]                 (WRK:507)
+//     onz     bit r: some other view still holds the topic (for WRK:441-448)
+//   g[r]/gn[r] the n_wk values of the listed topics for this token / the next one:
+//     the gather for token t+1 is issued before token t is sampled, so its HBM/L2
+//     latency hides behind a whole token of work (legal because the sweep reads a
+//     snapshot of n_wk: the deltas go to a separate buffer).
+//   topicDocWordMasses (WRK:511) = RMAX DPP prefix scans, never stored.
+//
+// LDS per wave shrinks to bitmap + prefix + slot->topic + per-view counts
+// (~3.6 KB at K=400, M=3), so occupancy is bound by VGPRs, not LDS.
+#include "mvhdp_device.h"
+#include "../../include/mvhdp.h"
+#include "mvhdp_wave.h"
+
+size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap)
+{
+    size_t b = (size_t)(64 + 64 + 16 + S_cap + M * S_cap) * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int RMAX, bool DEBUG>
+__global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i(threadIdx.x >> 6);
+    const int K = mm.K, M = mm.M, S = sl.S_cap;
+    const int NW = (K + 31) >> 5;
+    const bool exact_only = (sl.flags & MVHDP_SWEEP_EXACT_CHAIN) != 0;
+
+    int* nkd = (int*)smem;                                  // [M*K] n_k deltas of this block
+    for (int i = threadIdx.x; i < M * K; i += blockDim.x) nkd[i] = 0;
+    __syncthreads();
+
+    unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
+    uint32_t* bitmap = (uint32_t*)wb;
+    uint32_t* prefix = bitmap + 64;
+    int* wlen = (int*)(prefix + 64);
+    int* sk = wlen + 16;
+    int* sn = sk + S;
+
+    const int32_t* __restrict__ nwk = mm.counts;
+    const int32_t* __restrict__ nk_all = mm.counts + mm.rowbase[M] * K;
+    int32_t* dnwk = mm.delta;
+
+    unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
+
+    // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
+    for (;;) {
+      long long q0 = 0;
+      if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)MVHDP_DOC_BATCH);
+      q0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)q0);
+      if (q0 >= mm.D) break;
+      const long long q1 = (q0 + MVHDP_DOC_BATCH < mm.D) ? q0 + MVHDP_DOC_BATCH : mm.D;
+      for (long long q = q0; q < q1; q++) {
+        const int64_t d = sl.doc_order ? (int64_t)sl.doc_order[q] : (int64_t)q;
+        const int64_t dg = mm.doc_id_base + d;
+
+        // ---- WRK:339-391: gather the entity's topics into the slot list ----
+        bitmap[lane] = 0;
+        LDS_FENCE();
+        for (int m = 0; m < M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            if (lane == 0) wlen[m] = (int)(e - b);
+            for (int64_t i = b + lane; i < e; i += WAVE) {
+                int zz = mm.z[m][i];
+                if (zz >= 0) atomicOr(&bitmap[zz >> 5], 1u << (zz & 31));
+            }
+        }
+        LDS_FENCE();
+        int S_used;
+        {
+            uint32_t wbits = (lane < NW) ? bitmap[lane] : 0u;
+            int cnt = __popc(wbits);
+            int incl = wave_incl_scan_i(cnt, lane);
+            prefix[lane] = (uint32_t)(incl - cnt);
+            S_used = bcast_i(incl, 63);
+        }
+        LDS_FENCE();
+        for (int k0 = 0; k0 < K; k0 += WAVE) {
+            int k = k0 + lane;
+            if (k < K) {
+                uint32_t w = bitmap[k >> 5];
+                if ((w >> (k & 31)) & 1u) sk[prefix[k >> 5] + __popc(w & ((1u << (k & 31)) - 1u))] = k;
+            }
+        }
+        for (int m = 0; m < M; m++)
+            for (int i = lane; i < S_used; i += WAVE) sn[m * S + i] = 0;
+        LDS_FENCE();
+        for (int m = 0; m < M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            for (int64_t i = b + lane; i < e; i += WAVE) {
+                int zz = mm.z[m][i];
+                if (zz >= 0) {
+                    uint32_t w = bitmap[zz >> 5];
+                    int slot = prefix[zz >> 5] + __popc(w & ((1u << (zz & 31)) - 1u));
+                    atomicAdd(&sn[m * S + slot], 1);                       // WRK:357
+                }
+            }
+        }
+        LDS_FENCE();
+        const int R_eff = (S_used + 63) >> 6;                             // <= RMAX (host guarantees S_cap <= 64*RMAX)
+
+        int skr[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            const int i = r * 64 + lane;
+            skr[r] = (i < S_used) ? sk[i] : (int)0x80000000;              // unused slot = removed topic 0
+        }
+
+        const double* pd = (M > 1) ? (mm.p + d * M * M) : nullptr;        // WRK:327-337
+        bool aborted = false;
+
+        for (int m = 0; m < M && !aborted; m++) {                         // WRK:393
+            const int lenm = uniform_i(wlen[m]);
+            if (lenm == 0) continue;
+            const double beta_m = mm.beta[m];
+            const double scale_m = (double)lenm + mm.gamma[m] * mm.alpha_sum[m];
+            const double p_mm = pd ? pd[m * M + m] : 1.0;
+            const int32_t* nk = nk_all + (int64_t)m * K;
+
+            // per-view slot registers; WRK:395-410 totalMassOtherModalities (frozen for this view, Q3)
+            int cn[RMAX];
+            double oth[RMAX], den[RMAX];
+            unsigned int onz = 0;
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) {
+                cn[r] = 0; oth[r] = 0.0; den[r] = 1.0;
+                const int i = r * 64 + lane;
+                if (r < R_eff && i < S_used) {
+                    const int k = skr[r] & 0x7fffffff;
+                    cn[r] = sn[m * S + i];
+                    double acc = 0.0;
+                    for (int j = 0; j < M; j++) {
+                        if (j == m) continue;
+                        const int cj = sn[j * S + i];
+                        if (cj != 0) onz |= 1u << r;
+                        const int lj = wlen[j];
+                        if (lj != 0)
+                            acc += pd[m * M + j] * ((double)cj + mm.gamma[j] * mm.alpha[(int64_t)j * (K + 1) + k])
+                                   / ((double)lj + mm.gamma[j] * mm.alpha_sum[j]);
+                    }
+                    oth[r] = acc * scale_m;
+                    den[r] = (double)nk[k] + mm.beta_sum[m];
+                }
+            }
+            // WRK:413-418 newTopicMassAllModalities
+            double newAll = 0.0;
+            for (int j = 0; j < M; j++) {
+                double pmj = pd ? pd[m * M + j] : 1.0;
+                newAll += pmj * (mm.gamma[j] * mm.alpha[(int64_t)j * (K + 1) + K]) / ((double)wlen[j] + mm.gamma[j] * mm.alpha_sum[j]);
+            }
+            newAll = newAll * scale_m;
+            const double newMass = (mm.first_inactive < 0) ? 0.0 : newAll / (double)K;   // WRK:515
+
+            const int64_t base = mm.doc_off[m][d];
+            const int64_t row0 = mm.rowbase[m];
+            const int Vm = mm.V[m];
+
+            for (int c0 = 0; c0 < lenm && !aborted; c0 += WAVE) {
+                // one lane per token of the chunk: token id, old topic, its slot, RNG, tree root
+                const int ti = c0 + lane;
+                const bool tvalid = ti < lenm;
+                int w_l = tvalid ? mm.tok[m][base + ti] : -1;
+                int z_l = tvalid ? mm.z[m][base + ti] : -1;
+                int so_l = -1;
+                if (z_l >= 0) {
+                    uint32_t w = bitmap[z_l >> 5];
+                    so_l = prefix[z_l >> 5] + __popc(w & ((1u << (z_l & 31)) - 1u));
+                }
+                double u1_l, u2_l;
+                {
+                    uint32_t x[4];
+                    philox4x32_10((uint32_t)ti, (uint32_t)m, (uint32_t)dg, sl.sweep_idx,
+                                  sl.seed_lo, sl.seed_hi ^ (uint32_t)((unsigned long long)dg >> 32), x);
+                    u1_l = bits_to_unit(x[0], x[1]);
+                    u2_l = bits_to_unit(x[2], x[3]);
+                }
+                if (w_l >= Vm) w_l = -1;                                     // WRK:427-428 marks OOV
+                double root_l = (w_l >= 0) ? mm.root[row0 + w_l] : 0.0;
+                int znew_l = z_l;
+                const int nt = min(WAVE, lenm - c0);
+
+                // software pipeline: n_wk values of the listed topics for the next token
+                int gn[RMAX];
+                {
+                    const int w0 = bcast_i(w_l, 0);
+                    const int32_t* __restrict__ c0p = nwk + (row0 + max(w0, 0)) * K;
+#pragma unroll
+                    for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? c0p[skr[r] & 0x7fffffff] : 0;
+                }
+
+                for (int t = 0; t < nt; t++) {                              // WRK:425
+                    int g[RMAX];
+#pragma unroll
+                    for (int r = 0; r < RMAX; r++) g[r] = gn[r];
+                    if (t + 1 < nt) {
+                        const int wn = bcast_i(w_l, t + 1);
+                        const int32_t* __restrict__ cnp = nwk + (row0 + max(wn, 0)) * K;
+#pragma unroll
+                        for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? cnp[skr[r] & 0x7fffffff] : 0;
+                    }
+                    const int w = bcast_i(w_l, t);
+                    if (w < 0) { n_oov++; continue; }                       // WRK:427-428
+                    const int zold = bcast_i(z_l, t);
+                    const int so = bcast_i(so_l, t);
+                    const double u1 = bcast_d(u1_l, t), u2 = bcast_d(u2_l, t);
+                    const double root = bcast_d(root_l, t);
+                    const int64_t row = row0 + w;
+
+                    // WRK:434-468 decrement the local count; drop the topic when it is gone from all views
+                    if (so >= 0) {
+                        const int rs = so >> 6, ls = so & 63;
+                        int csel = 0;
+#pragma unroll
+                        for (int r = 0; r < RMAX; r++)
+                            if (r == rs) { if (lane == ls) cn[r]--; csel = cn[r]; }
+                        const int c = bcast_i(csel, ls);
+                        if (c == 0 && !((bcast_i((int)onz, ls) >> rs) & 1)) {
+#pragma unroll
+                            for (int r = 0; r < RMAX; r++)
+                                if (r == rs && lane == ls) skr[r] |= (int)0x80000000;
+                        }
+                    }
+
+                    // WRK:496-513 topicDocWordMasses.  pass 0: DPP prefix scans (certified below);
+                    // pass 1: the reference's sequential left-to-right sum.
+                    double cum[RMAX], term[RMAX];
+#pragma unroll
+                    for (int r = 0; r < RMAX; r++) {
+                        term[r] = 0.0; cum[r] = 0.0;
+                        if (r < R_eff && skr[r] >= 0) {
+                            double p_wt = ((double)g[r] + beta_m) / den[r];                  // WRK:507
+                            term[r] = (p_mm * (double)cn[r] + oth[r]) * p_wt;                // WRK:509
+                        }
+                    }
+                    double mass = 0.0, s0 = 0.0, s1 = 0.0, total = 0.0;
+                    int branch = 0;          // 0 new-topic, 1 doc, 2 tree
+                    int slot_new = -1;
+                    for (int pass = exact_only ? 1 : 0; pass < 2; pass++) {
+                        if (pass == 0) {
+                            double carry = 0.0;
+#pragma unroll
+                            for (int r = 0; r < RMAX; r++) {
+                                if (r < R_eff) {
+                                    cum[r] = carry + wave_incl_scan_d_dpp(term[r]);
+                                    carry = bcast_d(cum[r], 63);
+                                }
+                            }
+                            mass = carry;
+                        } else {
+                            double c = 0.0;
+#pragma unroll
+                            for (int r = 0; r < RMAX; r++) {
+                                if (r < R_eff) {
+                                    const int lim = min(64, S_used - r * 64);
+                                    for (int l = 0; l < lim; l++) {           // WRK:501-513, dense order
+                                        c += bcast_d(term[r], l);
+                                        if (lane == l) cum[r] = c;
+                                    }
+                                }
+                            }
+                            mass = c;
+                        }
+
+                        total = newMass + mass + root;                       // WRK:519
+                        s0 = u1 * total;
+                        // Certified scan (see mvhdp_kernels.hip / DESIGN.md): decisions are bit-identical to the
+                        // sequential sum unless a comparison is closer than tol, in which case pass 1 runs.
+                        const double tol = (pass == 0) ? total * (double)(4 * S_used + 16) * 0x1.0p-53 : -1.0;
+                        bool unsafe = false;
+                        if (s0 < newMass) {                                  // WRK:522
+                            branch = 0;
+                            if (fabs(s0 - newMass) <= tol) unsafe = true;
+                        } else {
+                            if (newMass != 0.0 && fabs(s0 - newMass) <= tol) unsafe = true;
+                            s1 = s0 - newMass;                               // WRK:528
+                            if (fabs(s1 - mass) <= tol) unsafe = true;
+                            if (s1 < mass) {                                 // WRK:529
+                                branch = 1;
+                                slot_new = -1;
+#pragma unroll
+                                for (int r = 0; r < RMAX; r++) {             // WRK:531 lower_bound over the live list
+                                    if (r < R_eff) {
+                                        const bool live = skr[r] >= 0;
+                                        if (__ballot(live && fabs(cum[r] - s1) <= tol)) unsafe = true;
+                                        unsigned long long hit = __ballot(live && cum[r] >= s1);
+                                        if (hit && slot_new < 0) slot_new = r * 64 + (int)__builtin_ctzll(hit);
+                                    }
+                                }
+                            } else {
+                                branch = 2;
+                            }
+                        }
+                        if (!(pass == 0 && unsafe)) break;
+                        n_fb++;
+                    }
+
+                    if (DEBUG) {
+                        if (sl.tok_dbg[m] && lane == 0) {
+                            double* gdb = sl.tok_dbg[m] + (base + c0 + t) * 4;
+                            gdb[0] = newMass; gdb[1] = mass; gdb[2] = root; gdb[3] = s0;
+                        }
+                        for (int q = 0; q < sl.n_trace; q++) {
+                            if (sl.trace_doc[q] == d && sl.trace_view[q] == m && sl.trace_pos[q] == c0 + t) {
+                                double* out = sl.trace_out + (int64_t)q * (K + 1);
+                                const double* tr = mm.trees + row * 2 * K;
+                                for (int k = lane; k < K; k += WAVE) out[k] = tr[K + k] / total;
+                                __threadfence();
+#pragma unroll
+                                for (int r = 0; r < RMAX; r++)
+                                    if (r < R_eff && skr[r] >= 0) out[skr[r]] += term[r] / total;
+                                if (lane == 0) out[K] = newMass / total;
+                                __threadfence();
+                            }
+                        }
+                    }
+
+                    int znew;
+                    if (branch == 0) {                                       // WRK:523-526
+                        c_new++;
+                        znew = mm.first_inactive;
+                    } else if (branch == 1) {                                // WRK:530-531
+                        c_doc++;
+                        if (slot_new < 0) { aborted = true; break; }         // lower_bound == -1 -> exception, Q11
+                        const int rn = slot_new >> 6, ln = slot_new & 63;
+                        int ksel = 0;
+#pragma unroll
+                        for (int r = 0; r < RMAX; r++) if (r == rn) ksel = skr[r];
+                        znew = bcast_i(ksel, ln);
+                    } else {                                                 // WRK:533-535
+                        c_tree++;
+                        znew = tree_sample(mm.trees + row * 2 * K, K, u2, root, lane);
+                    }
+                    if (znew < 0) znew = K - 1;                              // WRK:549-552
+                    znew = uniform_i(znew);
+
+                    // WRK:557-560
+                    if (lane == t) znew_l = znew;
+                    if (branch != 1) {
+                        uint32_t wbit = bitmap[znew >> 5];
+                        slot_new = ((wbit >> (znew & 31)) & 1u) ? (int)(prefix[znew >> 5] + __popc(wbit & ((1u << (znew & 31)) - 1u))) : -1;
+                        slot_new = uniform_i(slot_new);
+                    }
+                    if (slot_new >= 0) {
+                        const int rn = slot_new >> 6, ln = slot_new & 63;
+#pragma unroll
+                        for (int r = 0; r < RMAX; r++)
+                            if (r == rn && lane == ln) cn[r]++;
+                    }
+                    n_tok++;
+
+                    // WRK:587-589 + UPD:197-218: the FastQDelta becomes integer atomics on the delta arrays
+                    if (znew != zold) {
+                        n_chg++;
+                        if (lane == 0 && zold >= 0) {
+                            atomicAdd(&dnwk[row * K + zold], -1);
+                            atomicAdd(&nkd[m * K + zold], -1);
+                        }
+                        if (lane == 1) {
+                            atomicAdd(&dnwk[row * K + znew], 1);
+                            atomicAdd(&nkd[m * K + znew], 1);
+                        }
+                        if (mm.first_inactive >= 0 && lane == 2 && mm.inactive[znew]) {   // UPD:263
+                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)(c0 + t) << 11) | (long long)znew;
+                            atomicMin(sl.act_key, key);
+                        }
+                    }
+                }
+                if (tvalid) mm.z[m][base + ti] = znew_l;                     // coalesced write-back of the chunk
+            }
+
+            // the view's counts go back to LDS: later views read them (WRK:404) and test them (WRK:445)
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) {
+                const int i = r * 64 + lane;
+                if (r < R_eff && i < S_used) sn[m * S + i] = cn[r];
+            }
+            LDS_FENCE();
+        }
+        if (aborted) n_abort++;
+        LDS_FENCE();
+      }
+    }
+
+    __syncthreads();
+    int32_t* dnk = mm.delta + mm.rowbase[M] * K;
+    for (int i = threadIdx.x; i < M * K; i += blockDim.x)
+        if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
+    if (lane == 0) {
+        if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
+        if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
+        if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
+        if (c_doc) atomicAdd(&sl.stats[ST_DOC], (unsigned long long)c_doc);
+        if (c_tree) atomicAdd(&sl.stats[ST_TREE], (unsigned long long)c_tree);
+        if (n_oov) atomicAdd(&sl.stats[ST_OOV], (unsigned long long)n_oov);
+        if (n_abort) atomicAdd(&sl.stats[ST_ABORT], (unsigned long long)n_abort);
+        if (n_fb) atomicAdd(&sl.stats[ST_FALLBACK], (unsigned long long)n_fb);
+    }
+}
+
+template <int RMAX>
+static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s)
+{
+    size_t lds = sl.block_shared_bytes + (size_t)sl.waves_per_block * sl.wave_bytes;
+    dim3 block(64 * sl.waves_per_block);
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(debug ? (const void*)sweep_fast_kernel<RMAX, true> : (const void*)sweep_fast_kernel<RMAX, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (debug) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else       hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false>), dim3(grid_blocks), block, lds, s, mm, sl);
+    return hipGetLastError();
+}
+
+hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s)
+{
+    switch (rmax) {
+    case 1: return launch_fast<1>(mm, sl, grid_blocks, debug, s);
+    case 2: return launch_fast<2>(mm, sl, grid_blocks, debug, s);
+    case 3:
+    case 4: return launch_fast<4>(mm, sl, grid_blocks, debug, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int RMAX>
+static int occ_fast(bool debug, int threads, size_t lds)
+{
+    int nb = 0;
+    hipError_t e = debug ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_fast_kernel<RMAX, true>, threads, lds)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_fast_kernel<RMAX, false>, threads, lds);
+    return e == hipSuccess ? nb : 0;
+}
+
+int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes)
+{
+    switch (rmax) {
+    case 1: return occ_fast<1>(debug, block_threads, lds_bytes);
+    case 2: return occ_fast<2>(debug, block_threads, lds_bytes);
+    case 3:
+    case 4: return occ_fast<4>(debug, block_threads, lds_bytes);
+    default: return 0;
+    }
+}

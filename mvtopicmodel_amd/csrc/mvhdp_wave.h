@@ -1,0 +1,132 @@
+// mvhdp_wave.h — wave-level (64-lane) device helpers shared by the gfx950 kernels:
+// broadcasts, scans, Philox4x32-10 and FTree.sample on a stored tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+// LDS accesses of one wave execute in issue order, so within a wave only the
+// compiler has to be kept from reordering / caching LDS traffic.
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
+// ---------------------------------------------------------------------------
+// small wave-level helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ int bcast_i(int v, int src_lane)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_lane));
+}
+
+__device__ __forceinline__ double bcast_d(double v, int src_lane)
+{
+    int s = __builtin_amdgcn_readfirstlane(src_lane);
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), s);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), s);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// inclusive prefix sums across the 64 lanes (any association order is fine:
+// the fp64 one is only used under the certified-scan tolerance, see below)
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        int o = __shfl_up(v, s, WAVE);
+        if (lane >= s) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ double wave_incl_scan_d(double v, int lane)
+{
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        double o = __shfl_up(v, s, WAVE);
+        if (lane >= s) v += o;
+    }
+    return v;
+}
+
+// fp64 inclusive scan over the 64 lanes with DPP moves (no LDS crossbar): four row_shr
+// steps scan each 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals across
+// (gfx9 DPP controls; 2 x v_mov_b32_dpp + 1 x v_add_f64 per step).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_src_d(double x)
+{
+    long long b = __double_as_longlong(x);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, BOUND);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, BOUND);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double wave_incl_scan_d_dpp(double v)
+{
+    v += dpp_src_d<0x111, 0xf, true>(v);    // row_shr:1
+    v += dpp_src_d<0x112, 0xf, true>(v);    // row_shr:2
+    v += dpp_src_d<0x114, 0xf, true>(v);    // row_shr:4
+    v += dpp_src_d<0x118, 0xf, true>(v);    // row_shr:8
+    v += dpp_src_d<0x142, 0xa, false>(v);   // row_bcast:15 -> rows 1 and 3
+    v += dpp_src_d<0x143, 0xc, false>(v);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Random123); the stream contract is in DESIGN.md §RNG
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double bits_to_unit(uint32_t hi, uint32_t lo)
+{
+    // the 53-bit shape of ThreadLocalRandom.nextDouble() (WRK:517,534)
+    unsigned long long x = ((unsigned long long)hi << 32) | lo;
+    return (double)(x >> 11) * 0x1.0p-53;
+}
+
+// ---------------------------------------------------------------------------
+// FTree.sample (FT:111-136) against the stored tree of one (view,type).
+// The descent reads whole sub-trees per round: the 62 nodes of the five levels
+// below the current node sit in 5 contiguous runs of the tree array, one node
+// per lane, so a K<=2048 descent needs at most 3 dependent load rounds instead
+// of log2(K) of them.  All lanes walk the same path (u is wave-uniform).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int tree_sample(const double* __restrict__ tree, int K, double u2, double root, int lane)
+{
+    int i = 1;
+    double u = u2 * root;                                  // FT:120  u = u * tree[1]
+    const int j = lane + 2;
+    const int t = 31 - __clz(j);                           // 1..6 (6 only for lanes 62,63: unused)
+    const int o = j - (1 << t);
+    while (i < K) {                                        // FT:122
+        long long idx = ((long long)i << t) + o;
+        double v = (lane < 62 && idx < 2LL * K) ? tree[idx] : 0.0;
+        int rel_t = 0, rel_o = 0;
+#pragma unroll
+        for (int step = 0; step < 5; step++) {
+            if (i < K) {
+                int src = (2 << rel_t) + 2 * rel_o - 2;   // lane holding tree[2*i]
+                double l = bcast_d(v, src);
+                if (u < l) { i = 2 * i; rel_o = 2 * rel_o; }               // FT:124-125
+                else { u = u - l; i = 2 * i + 1; rel_o = 2 * rel_o + 1; }  // FT:127-128
+                rel_t++;
+            }
+        }
+        i = uniform_i(i);
+    }
+    return i - K;                                          // FT:132
+}
+

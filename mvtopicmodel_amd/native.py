@@ -13,6 +13,7 @@ from ._lib import (MAX_M, Config, DebugC, HyperC, MvhdpError, SweepStatsC, load_
 SWEEP_REUSE_TREES = 0x1
 SWEEP_NO_APPLY = 0x2
 SWEEP_EXACT_CHAIN = 0x4
+SWEEP_GENERIC_KERNEL = 0x8
 
 BUF_COUNTS = 0
 BUF_DELTA = 1

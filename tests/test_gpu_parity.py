@@ -5,7 +5,7 @@ stream; per-token conditional probabilities within 1e-6."""
 import numpy as np
 import pytest
 
-from mvtopicmodel_amd.native import (Hyper, SWEEP_EXACT_CHAIN, SWEEP_NO_APPLY, SWEEP_REUSE_TREES)
+from mvtopicmodel_amd.native import (Hyper, SWEEP_EXACT_CHAIN, SWEEP_GENERIC_KERNEL, SWEEP_NO_APPLY, SWEEP_REUSE_TREES)
 from tests.helpers import assert_same_state, make_native, make_oracle, small_corpus
 
 pytestmark = pytest.mark.gpu
@@ -23,8 +23,12 @@ CASES = [
 ]
 
 
+KERNELS = [0, SWEEP_GENERIC_KERNEL]     # register-resident kernel (default) and the generic LDS kernel
+
+
+@pytest.mark.parametrize("kflag", KERNELS)
 @pytest.mark.parametrize("K,V,D,lam,cseed", CASES)
-def test_one_sweep_bit_exact(K, V, D, lam, cseed):
+def test_one_sweep_bit_exact(K, V, D, lam, cseed, kflag):
     c = small_corpus(K, V, D, lam, cseed)
     hy = Hyper.defaults(K, V)
     o = make_oracle(c, hy)
@@ -32,7 +36,7 @@ def test_one_sweep_bit_exact(K, V, D, lam, cseed):
     s = make_native(c, hy, z0)
     assert_same_state(o, s, c.M)                     # build_counts parity
     ro = o.sweep(0, 0xC0FFEE, want_dbg=True)
-    rs = s.sweep(0, 0xC0FFEE, want_dbg=True)
+    rs = s.sweep(0, 0xC0FFEE, flags=kflag, want_dbg=True)
     for f in ("tokens", "changed", "new_mass_cnt", "topic_doc_mass_cnt", "word_ftree_mass_cnt", "oov_skipped", "aborted_docs"):
         assert ro["stats"][f] == getattr(rs, f), f
     assert rs.tokens == c.total_tokens
@@ -49,8 +53,9 @@ def test_one_sweep_bit_exact(K, V, D, lam, cseed):
     s.close()
 
 
+@pytest.mark.parametrize("kflag", KERNELS)
 @pytest.mark.parametrize("K,V,D,lam,cseed", CASES[1:5])
-def test_three_sweeps_bit_exact_and_exact_chain_mode(K, V, D, lam, cseed):
+def test_three_sweeps_bit_exact_and_exact_chain_mode(K, V, D, lam, cseed, kflag):
     """Several sweeps (state carried on the device), and the forced sequential-sum
     mode (the certified scan's fallback path) must give the very same integers."""
     c = small_corpus(K, V, D, lam, cseed)
@@ -61,8 +66,8 @@ def test_three_sweeps_bit_exact_and_exact_chain_mode(K, V, D, lam, cseed):
     s2 = make_native(c, hy, z0)
     for it in range(3):
         ro = o.sweep(it, 42, want_dbg=True)
-        s.sweep(it, 42)
-        r2 = s2.sweep(it, 42, flags=SWEEP_EXACT_CHAIN, want_dbg=True)
+        s.sweep(it, 42, flags=kflag)
+        r2 = s2.sweep(it, 42, flags=SWEEP_EXACT_CHAIN | kflag, want_dbg=True)
         assert_same_state(o, s, c.M)
         assert_same_state(o, s2, c.M)
         for m in range(c.M):
@@ -86,7 +91,8 @@ def test_trees_match_oracle_bitwise():
     s.close()
 
 
-def test_token_conditionals_within_1e6():
+@pytest.mark.parametrize("kflag", KERNELS)
+def test_token_conditionals_within_1e6(kflag):
     K, V = 100, [1500, 200, 200]
     c = small_corpus(K, V, 40, [60, 6, 9], 31)
     hy = Hyper.defaults(K, V)
@@ -100,7 +106,7 @@ def test_token_conditionals_within_1e6():
                 if 0 <= pos < L:
                     trace.append((d, m, pos))
     ro = o.sweep(0, 5, trace=trace)
-    rs = s.sweep(0, 5, trace=trace)
+    rs = s.sweep(0, 5, flags=kflag, trace=trace)
     assert ro["trace"].shape == rs.trace.shape
     assert np.allclose(ro["trace"].sum(axis=1), 1.0, atol=1e-9)
     assert np.max(np.abs(ro["trace"] - rs.trace)) < PROB_TOL
@@ -129,7 +135,8 @@ def test_p_override_from_mallet_stream_and_reuse_trees():
     s.close()
 
 
-def test_ragged_empty_unassigned_oov():
+@pytest.mark.parametrize("kflag", KERNELS)
+def test_ragged_empty_unassigned_oov(kflag):
     """Edge cases the reference handles: entities missing a view (null), empty entities,
     UNASSIGNED topics (-1, PTM:63), out-of-vocabulary types (WRK:427-428)."""
     K, V = 30, [100, 20]
@@ -154,18 +161,19 @@ def test_ragged_empty_unassigned_oov():
         o.set_assignments(m, z0[m])
     o.build_counts()
     s = make_native(c, hy, z0)
-    ro = o.sweep(0, 77); rs = s.sweep(0, 77)
+    ro = o.sweep(0, 77); rs = s.sweep(0, 77, flags=kflag)
     assert ro["stats"]["oov_skipped"] == rs.oov_skipped == 3
     assert rs.tokens == c.total_tokens - 3
     assert_same_state(o, s, 2)
     assert (s.get_assignments(0)[[3, 20]] == -1).all()
     for it in range(1, 3):
-        o.sweep(it, 77); s.sweep(it, 77)
+        o.sweep(it, 77); s.sweep(it, 77, flags=kflag)
         assert_same_state(o, s, 2)
     s.close()
 
 
-def test_inactive_topic_activation():
+@pytest.mark.parametrize("kflag", KERNELS)
+def test_inactive_topic_activation(kflag):
     """Truncated-HDP branch: a non-empty inActiveTopicIndex gives newTopicMass>0 (WRK:515-526);
     the first delta that lands on the inactive topic activates it (UPD:263-270)."""
     K, V = 40, [300, 50]
@@ -180,7 +188,7 @@ def test_inactive_topic_activation():
         o.set_assignments(m, z0[m])
     o.build_counts()
     s = make_native(c, hy, z0)
-    ro = o.sweep(0, 3, want_dbg=True); rs = s.sweep(0, 3, want_dbg=True)
+    ro = o.sweep(0, 3, want_dbg=True); rs = s.sweep(0, 3, flags=kflag, want_dbg=True)
     assert ro["stats"]["new_mass_cnt"] == rs.new_mass_cnt > 0
     assert (ro["stats"]["activated_topic"], ro["stats"]["activated_modality"]) == (rs.activated_topic, rs.activated_modality)
     assert rs.activated_topic == 33
@@ -189,7 +197,7 @@ def test_inactive_topic_activation():
     assert np.array_equal(o.get_alpha(), a_s) and np.array_equal(o.get_inactive(), ina_s)
     assert ina_s[33] == 0 and ina_s[36] == 1
     assert a_s[rs.activated_modality, 33] == 25.0
-    ro = o.sweep(1, 3); rs = s.sweep(1, 3)
+    ro = o.sweep(1, 3); rs = s.sweep(1, 3, flags=kflag)
     assert rs.activated_topic == 36
     assert_same_state(o, s, 2)
     s.close()
@@ -223,4 +231,24 @@ def test_no_apply_then_apply_equals_apply():
     s.apply_delta(st.activated_topic, st.activated_modality)
     o.sweep(0, 8)
     assert_same_state(o, s, 2)
+    s.close()
+
+
+def test_long_entities_take_the_generic_kernel_and_work_queue_order():
+    """Entities with > 256 tokens and K > 256 exceed the register-resident kernel's slot budget;
+    very uneven lengths also switch the work queue to longest-first order."""
+    K, V = 500, [3000, 200]
+    rng = np.random.RandomState(5)
+    lens0 = np.array([900, 3, 40, 700, 1, 0, 350, 12, 5, 1200, 64, 65, 128, 129, 2], dtype=np.int64)
+    lens1 = np.array([10, 0, 4, 30, 0, 2, 6, 0, 1, 25, 3, 3, 0, 7, 1], dtype=np.int64)
+    off0 = np.concatenate([[0], np.cumsum(lens0)]); off1 = np.concatenate([[0], np.cumsum(lens1)])
+    from mvtopicmodel_amd.synth import Corpus
+    c = Corpus(K, V, [off0, off1], [rng.randint(0, 3000, off0[-1]).astype(np.int32), rng.randint(0, 200, off1[-1]).astype(np.int32)])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    for it in range(3):
+        ro = o.sweep(it, 17); rs = s.sweep(it, 17)
+        assert rs.tokens == c.total_tokens
+        assert_same_state(o, s, 2)
     s.close()
