@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                     for (int r = 0; r < RMAX; r++) {
                         term[r] = 0.0; cum[r] = 0.0;
                         if (r < R_eff && skr[r] >= 0) {
-                            double p_wt = ((double)g[r] + beta_m) / den[r];                  // WRK:507
+                            double p_wt = div_inrange((double)g[r] + beta_m, den[r]);
                             term[r] = (p_mm * (double)cn[r] + oth[r]) * p_wt;                // WRK:509
                         }
                     }
@@ -293,8 +293,9 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                                 for (int r = 0; r < RMAX; r++) {             // WRK:531 lower_bound over the live list
                                     if (r < R_eff) {
                                         const bool live = skr[r] >= 0;
-                                        if (__ballot(live && fabs(cum[r] - s1) <= tol)) unsafe = true;
-                                        unsigned long long hit = __ballot(live && cum[r] >= s1);
+                                        const double diff = cum[r] - s1;
+                                        if (__ballot(live && fabs(diff) <= tol)) unsafe = true;
+                                        unsigned long long hit = __ballot(live && diff >= 0.0);
                                         if (hit && slot_new < 0) slot_new = r * 64 + (int)__builtin_ctzll(hit);
                                     }
                                 }
@@ -363,13 +364,13 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                     // WRK:587-589 + UPD:197-218: the FastQDelta becomes integer atomics on the delta arrays
                     if (znew != zold) {
                         n_chg++;
-                        if (lane == 0 && zold >= 0) {
-                            atomicAdd(&dnwk[row * K + zold], -1);
-                            atomicAdd(&nkd[m * K + zold], -1);
-                        }
-                        if (lane == 1) {
-                            atomicAdd(&dnwk[row * K + znew], 1);
-                            atomicAdd(&nkd[m * K + znew], 1);
+                        if (lane < 2) {
+                            const int kk = lane ? znew : zold;
+                            const int vv = lane ? 1 : -1;
+                            if (kk >= 0) {
+                                __hip_atomic_fetch_add(&dnwk[row * K + kk], vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_fetch_add(&nkd[m * K + kk], vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                         if (mm.first_inactive >= 0 && lane == 2 && mm.inactive[znew]) {   // UPD:263
                             long long key = (dg << 34) | ((long long)m << 31) | ((long long)(c0 + t) << 11) | (long long)znew;

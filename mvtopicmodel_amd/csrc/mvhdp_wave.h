@@ -73,6 +73,24 @@ __device__ __forceinline__ double wave_incl_scan_d_dpp(double v)
     return v;
 }
 
+
+// IEEE-754 correctly rounded n/d for operands that need no rescaling: exactly the
+// Newton/fma sequence hipcc emits for an fp64 divide (v_rcp_f64, two refinements,
+// quotient, residual, final fma) without v_div_scale / v_div_fixup, which are the
+// identity when n, d and n/d are normal numbers far from the exponent limits.  Here
+// n = count + beta in [1e-4, 2^31] and d = n_k + betaSum in [1e-4, 2^32].
+__device__ __forceinline__ double div_inrange(double n, double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    e = __builtin_fma(-d, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    double q = n * x;
+    double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, x, q);
+}
+
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Random123); the stream contract is in DESIGN.md §RNG
 // ---------------------------------------------------------------------------
