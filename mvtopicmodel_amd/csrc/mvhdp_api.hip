@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,9 @@ struct mvhdp_ctx {
     long long* d_act_key = nullptr;
     unsigned long long* d_doc_counter = nullptr;
     int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
+    int32_t* d_overflow = nullptr;           // [D] entities handed from the register-resident kernel to the generic one
+    unsigned int* d_ovf_meta = nullptr;      // [0] overflow count, [1..5] entities by ceil(topic list/64) = 1,2,3,4,>4
+    int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
     size_t lds_attr_set = 0;
 };
 
@@ -51,6 +55,27 @@ struct mvhdp_ctx {
 #define HIPC(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
 #define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
+
+// Which register-resident variant (64*r topic slots per entity) should the next sweep use?  A
+// larger r costs registers, i.e. resident waves (measured relative sweep cost per entity below);
+// entities that do not fit are re-run by the generic LDS kernel at about 3x the r=2 cost.
+// Returns 5 when the generic kernel alone is the cheapest.
+static int rmax_from_hist(const unsigned int* hist5)
+{
+    static const double cost_fast[4] = {0.85, 1.0, 1.35, 1.8};
+    const double cost_generic = 3.2;
+    double tot = 0;
+    for (int i = 0; i < 5; i++) tot += hist5[i];
+    if (tot == 0) return 1;
+    int best = 5; double best_cost = cost_generic * tot;
+    double fit = 0;
+    for (int r = 1; r <= 4; r++) {
+        fit += hist5[r - 1];
+        double c = tot * cost_fast[r - 1] * 0.98 + fit * cost_fast[r - 1] * 0.02 + (tot - fit) * cost_generic;
+        if (c < best_cost) { best_cost = c; best = r; }
+    }
+    return best;
+}
 
 static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
 
@@ -112,6 +137,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMalloc(&h->d_stats, ST_COUNT * sizeof(unsigned long long)));
     CREATE_HIP(hipMalloc(&h->d_act_key, sizeof(long long)));
     CREATE_HIP(hipMalloc(&h->d_doc_counter, sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 8 * sizeof(unsigned int)));
     mm.alpha = h->d_alpha;
     mm.inactive = h->d_inactive;
     h->h_alpha.assign((size_t)M * (K + 1), 0.0);
@@ -141,6 +167,8 @@ extern "C" int mvhdp_destroy(mvhdp_handle h)
     if (h->d_act_key) hipFree(h->d_act_key);
     if (h->d_doc_counter) hipFree(h->d_doc_counter);
     if (h->d_doc_order) hipFree(h->d_doc_order);
+    if (h->d_overflow) hipFree(h->d_overflow);
+    if (h->d_ovf_meta) hipFree(h->d_ovf_meta);
     for (auto& e : h->ev) if (e) hipEventDestroy(e);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -202,6 +230,8 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     h->have_corpus[m] = true;
     h->max_doc_tokens = -1;
     if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
+    if (h->d_overflow) { hipFree(h->d_overflow); h->d_overflow = nullptr; }
+    h->rmax_hint = 0;
     mm.D = D;
     mm.doc_off[m] = (const int64_t*)h->d_doc_off[m];
     mm.tok[m] = (const int32_t*)h->d_tok[m];
@@ -229,6 +259,7 @@ extern "C" int mvhdp_set_assignments(mvhdp_handle h, int32_t m, const int32_t* z
     HIPC(h, hipSetDevice(h->device));
     HIPC(h, hipStreamSynchronize(h->stream));
     if (h->N[m] > 0) HIPC(h, hipMemcpy(h->d_z[m], z, (size_t)h->N[m] * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->rmax_hint = 0;
     return MVHDP_OK;
 }
 
@@ -441,25 +472,63 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     sl.flags = flags; sl.S_cap = S_cap;
     sl.block_shared_bytes = (uint32_t)(((size_t)M * K * sizeof(int) + 15) & ~(size_t)15);
     const bool debug = dbg != nullptr;
-    const bool fast = (S_cap <= 256) && !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
-    const int rmax = S_cap / 64;
-    sl.wave_bytes = (uint32_t)(fast ? mvhdp_sweep_fast_wave_bytes(M, S_cap) : mvhdp_sweep_wave_bytes(M, S_cap));
-    int wpb = 4;
-    while (wpb > 1 && sl.block_shared_bytes + (size_t)wpb * sl.wave_bytes > h->max_lds) wpb >>= 1;
-    size_t lds = sl.block_shared_bytes + (size_t)wpb * sl.wave_bytes;
-    if (lds > h->max_lds) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB (K * modalities too large)");
-    sl.waves_per_block = wpb;
-    if (!fast && lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
-    // persistent grid = what is resident at once; the work queue balances the rest
-    int blocks_per_cu = fast ? mvhdp_sweep_fast_occupancy(rmax, debug, 64 * wpb, lds)
-                             : mvhdp_sweep_generic_occupancy(debug, 64 * wpb, lds);
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    int64_t need = (mm.D + (int64_t)wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)wpb * MVHDP_DOC_BATCH);
-    int grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * blocks_per_cu));
+    // Kernel variant.  The register-resident kernel holds 64*rmax topic slots per entity; rmax is
+    // sized from the largest topic list the previous sweep saw (or, first time, from the expected
+    // number of distinct topics of the longest entity), and entities that still exceed it are
+    // handed to the generic LDS kernel through the overflow list.
+    int rmax_cap = S_cap / 64;
+    bool fast = !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
+    int rmax = 0;
+    if (fast) {
+        if (h->rmax_hint <= 0) {
+            // first sweep on these assignments: measure the topic lists (one pass over z)
+            unsigned int hist[8] = {0};
+            HIPC(h, hipMemsetAsync(h->d_ovf_meta, 0, 8 * sizeof(unsigned int), h->stream));
+            HIPC(h, mvhdp_launch_slot_hist(mm, h->d_ovf_meta + 1, h->stream));
+            HIPC(h, hipMemcpyAsync(hist, h->d_ovf_meta, sizeof hist, hipMemcpyDeviceToHost, h->stream));
+            HIPC(h, hipStreamSynchronize(h->stream));
+            h->rmax_hint = rmax_from_hist(hist + 1);
+        }
+        rmax = h->rmax_hint;
+        if (rmax > 4) fast = false;
+        rmax = std::max(1, std::min(rmax, std::max(rmax_cap, 1)));
+    }
+    struct Geo { uint32_t wave_bytes; int wpb; size_t lds; int grid; };
+    auto geometry = [&](bool is_fast, int r, Geo& g) -> int {
+        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, S_cap) : mvhdp_sweep_wave_bytes(M, S_cap));
+        g.wpb = 4;
+        while (g.wpb > 1 && sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes > h->max_lds) g.wpb >>= 1;
+        g.lds = sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes;
+        if (g.lds > h->max_lds) return MVHDP_ERR_UNSUPPORTED;
+        int bpc = is_fast ? mvhdp_sweep_fast_occupancy(r, debug, 64 * g.wpb, g.lds) : mvhdp_sweep_generic_occupancy(debug, 64 * g.wpb, g.lds);
+        if (bpc < 1) bpc = 1;
+        int64_t need = (mm.D + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
+        g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * bpc));
+        return MVHDP_OK;
+    };
+    Geo gen{}, fst{};
+    {
+        // the generic kernel may need > 64 KiB of dynamic LDS
+        uint32_t wb = (uint32_t)mvhdp_sweep_wave_bytes(M, S_cap);
+        int wpb = 4;
+        while (wpb > 1 && sl.block_shared_bytes + (size_t)wpb * wb > h->max_lds) wpb >>= 1;
+        size_t lds = sl.block_shared_bytes + (size_t)wpb * wb;
+        if (lds > h->max_lds) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB (K * modalities too large)");
+        if (lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
+    }
+    if (geometry(false, 0, gen) != MVHDP_OK) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB");
+    if (fast && geometry(true, rmax, fst) != MVHDP_OK) fast = false;
+    if (fast && !h->d_overflow && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow, (size_t)mm.D * sizeof(int32_t)));
+    if (getenv("MVHDP_DEBUG"))
+        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
+                sweep_idx, (int)fast, rmax, h->rmax_hint, S_cap, fst.grid, fst.wpb, fst.lds, gen.grid, gen.wpb, gen.lds);
     sl.stats = h->d_stats;
     sl.act_key = h->d_act_key;
     sl.doc_counter = h->d_doc_counter;
     sl.doc_order = h->d_doc_order;
+    sl.overflow_list = h->d_overflow;
+    sl.overflow_count = h->d_ovf_meta;
+    sl.slot_hist = h->d_ovf_meta + 1;
 
     // debug buffers
     std::vector<void*> to_free;
@@ -509,15 +578,43 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     const long long kmax = LLONG_MAX;
     step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
     step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
+    step(hipMemsetAsync(h->d_ovf_meta, 0, 8 * sizeof(unsigned int), s));
     step(hipEventRecord(h->ev[1], s));
-    if (e == hipSuccess && mm.D > 0)
-        step(fast ? mvhdp_launch_sweep_fast(mm, sl, rmax, grid, debug, s) : mvhdp_launch_sweep(mm, sl, grid, debug, s));
+    unsigned int ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess && mm.D > 0) {
+        if (fast) {
+            sl.wave_bytes = fst.wave_bytes; sl.waves_per_block = fst.wpb;
+            step(mvhdp_launch_sweep_fast(mm, sl, rmax, fst.grid, debug, s));
+            step(hipMemcpyAsync(ovf, h->d_ovf_meta, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+            step(hipStreamSynchronize(s));
+            if (e == hipSuccess && ovf[0] > 0) {
+                // entities whose topic list did not fit: same sweep, generic kernel, over the overflow list
+                MvModel mo = mm;
+                mo.D = (int64_t)ovf[0];
+                SweepLaunch so = sl;
+                so.doc_order = h->d_overflow; so.wave_bytes = gen.wave_bytes; so.waves_per_block = gen.wpb;
+                step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
+                int64_t need = ((int64_t)ovf[0] + (int64_t)gen.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)gen.wpb * MVHDP_DOC_BATCH);
+                step(mvhdp_launch_sweep(mo, so, (int)std::min<int64_t>(need, gen.grid), debug, s));
+            }
+        } else {
+            sl.wave_bytes = gen.wave_bytes; sl.waves_per_block = gen.wpb;
+            step(mvhdp_launch_sweep(mm, sl, gen.grid, debug, s));
+        }
+    }
     step(hipEventRecord(h->ev[2], s));
     unsigned long long hs[ST_COUNT] = {0};
     long long act = LLONG_MAX;
     step(hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, s));
     step(hipMemcpyAsync(&act, h->d_act_key, sizeof act, hipMemcpyDeviceToHost, s));
+    step(hipMemcpyAsync(ovf, h->d_ovf_meta, sizeof ovf, hipMemcpyDeviceToHost, s));
     step(hipStreamSynchronize(s));
+    if (e == hipSuccess && mm.D > 0) {
+        // next sweep: the smallest variant that leaves at most 0.5% of the entities to the overflow pass
+        // (topic lists change slowly between sweeps); entities counted twice (overflow re-run) only
+        // make the choice more conservative
+        h->rmax_hint = rmax_from_hist(ovf + 1);
+    }
     if (e != hipSuccess) { cleanup(); HIPC(h, e); }
 
     if (debug) {

@@ -42,6 +42,9 @@ struct SweepLaunch {
     long long* act_key;                // activation key (atomicMin)
     unsigned long long* doc_counter;   // work queue head: waves pull entities in batches
     const int32_t* doc_order;          // optional permutation (longest entities first), or nullptr
+    int32_t* overflow_list;            // entities whose topic list exceeds the register-resident kernel's slots
+    unsigned int* overflow_count;      //   (they are re-run by the generic kernel)
+    unsigned int* slot_hist;           // [5] entities by ceil(list size/64) = 1,2,3,4,>4 (sizes the next sweep's kernel variant)
     // debug
     double* tok_dbg[MVHDP_MAXM];
     int32_t n_trace;
@@ -63,6 +66,7 @@ hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats
 hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
                                        int32_t* doc_len_counts, int32_t len_len, hipStream_t s);
 hipError_t mvhdp_sweep_set_max_lds(size_t bytes);
+hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned int* hist, hipStream_t s);
 size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap);
 hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);
 int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes);

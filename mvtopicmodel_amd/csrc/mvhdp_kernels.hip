@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     int32_t* dnwk = mm.delta;
 
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
+    unsigned int hist_r[5] = {0, 0, 0, 0, 0};
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
     for (;;) {
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
             prefix[lane] = (uint32_t)(incl - cnt);
             S_used = bcast_i(incl, 63);
         }
+        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1]++; }
         LDS_FENCE();
         for (int k0 = 0; k0 < K; k0 += WAVE) {
             int k = k0 + lane;
@@ -557,6 +559,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     for (int i = threadIdx.x; i < M * K; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
     if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], hist_r[i]);
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
         if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
@@ -577,10 +581,19 @@ hipError_t mvhdp_sweep_set_max_lds(size_t bytes)
 
 int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes)
 {
-    int nb = 0;
-    hipError_t e = debug ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_kernel<true>, block_threads, lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_kernel<false>, block_threads, lds_bytes);
-    return e == hipSuccess ? nb : 0;
+    hipFuncAttributes a;
+    const void* f = debug ? (const void*)sweep_kernel<true> : (const void*)sweep_kernel<false>;
+    if (hipFuncGetAttributes(&a, f) != hipSuccess) return 1;
+    int regs = (a.numRegs + 7) / 8 * 8;
+    int waves_simd = regs > 0 ? 512 / regs : 8;
+    if (waves_simd > 8) waves_simd = 8;
+    if (waves_simd < 1) waves_simd = 1;
+    int wpb = block_threads / 64;
+    int b = waves_simd * 4 / wpb;
+    int by_lds = (int)((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));
+    if (by_lds < b) b = by_lds;
+    if (32 / wpb < b) b = 32 / wpb;
+    return b < 1 ? 1 : b;
 }
 
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s)
@@ -684,3 +697,46 @@ hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, 
     return e;
 }
 
+
+// ---------------------------------------------------------------------------
+// slot_hist: how many distinct topics each entity holds (over all views), binned by
+// ceil(n/64) = 1,2,3,4,>4.  Sizes the register-resident sweep kernel before the first
+// sweep (afterwards the sweep kernels keep the histogram current themselves).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned int* hist)
+{
+    __shared__ uint32_t bm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int h[5] = {0, 0, 0, 0, 0};
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < mm.D; d += wstride) {
+        bm[wave][lane] = 0;
+        LDS_FENCE();
+        for (int m = 0; m < mm.M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            for (int64_t i = b + lane; i < e; i += WAVE) {
+                int zz = mm.z[m][i];
+                if (zz >= 0) atomicOr(&bm[wave][zz >> 5], 1u << (zz & 31));
+            }
+        }
+        LDS_FENCE();
+        int cnt = __popc(bm[wave][lane]);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, WAVE);
+        const int hb = min((cnt + 63) >> 6, 5);
+        if (hb >= 1) h[hb - 1]++;
+        LDS_FENCE();
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned int* hist, hipStream_t s)
+{
+    if (mm.D <= 0) return hipSuccess;
+    int64_t blocks = (mm.D + 3) / 4;
+    int grid = (int)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(slot_hist_kernel, dim3(grid), dim3(256), 0, s, mm, hist);
+    return hipGetLastError();
+}

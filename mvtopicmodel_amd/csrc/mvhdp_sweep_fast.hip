@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
     int32_t* dnwk = mm.delta;
 
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
+    unsigned int hist_r[5] = {0, 0, 0, 0, 0};
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
     for (;;) {
@@ -109,7 +110,12 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
             }
         }
         LDS_FENCE();
-        const int R_eff = (S_used + 63) >> 6;                             // <= RMAX (host guarantees S_cap <= 64*RMAX)
+        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1]++; }
+        if (S_used > 64 * RMAX) {                                          // too many topics for this variant:
+            if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;   // the generic kernel takes it
+            continue;
+        }
+        const int R_eff = (S_used + 63) >> 6;
 
         int skr[RMAX];
 #pragma unroll
@@ -187,35 +193,41 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                     u2_l = bits_to_unit(x[2], x[3]);
                 }
                 if (w_l >= Vm) w_l = -1;                                     // WRK:427-428 marks OOV
-                double root_l = (w_l >= 0) ? mm.root[row0 + w_l] : 0.0;
                 int znew_l = z_l;
                 const int nt = min(WAVE, lenm - c0);
 
-                // software pipeline: n_wk values of the listed topics for the next token
+                // software pipeline: n_wk values of the listed topics for the next token, and the top of
+                // its F+tree (tree[1..63], node n in lane n-1: the root for WRK:519 and five levels of FT:122)
                 int gn[RMAX];
+                double tvn;
+                const bool tlane = (lane + 1) < 2 * K && lane < 63;
                 {
                     const int w0 = bcast_i(w_l, 0);
-                    const int32_t* __restrict__ c0p = nwk + (row0 + max(w0, 0)) * K;
+                    const int64_t r0 = row0 + max(w0, 0);
+                    const int32_t* __restrict__ c0p = nwk + r0 * K;
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? c0p[skr[r] & 0x7fffffff] : 0;
+                    tvn = tlane ? mm.trees[r0 * 2 * K + lane + 1] : 0.0;
                 }
 
                 for (int t = 0; t < nt; t++) {                              // WRK:425
                     int g[RMAX];
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) g[r] = gn[r];
+                    const double tv = tvn;
                     if (t + 1 < nt) {
                         const int wn = bcast_i(w_l, t + 1);
-                        const int32_t* __restrict__ cnp = nwk + (row0 + max(wn, 0)) * K;
+                        const int64_t rn = row0 + max(wn, 0);
+                        const int32_t* __restrict__ cnp = nwk + rn * K;
 #pragma unroll
                         for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? cnp[skr[r] & 0x7fffffff] : 0;
+                        tvn = tlane ? mm.trees[rn * 2 * K + lane + 1] : 0.0;
                     }
                     const int w = bcast_i(w_l, t);
                     if (w < 0) { n_oov++; continue; }                       // WRK:427-428
-                    const int zold = bcast_i(z_l, t);
                     const int so = bcast_i(so_l, t);
-                    const double u1 = bcast_d(u1_l, t), u2 = bcast_d(u2_l, t);
-                    const double root = bcast_d(root_l, t);
+                    const double u1 = bcast_d(u1_l, t);
+                    const double root = bcast_d(tv, 0);                      // tree[1]
                     const int64_t row = row0 + w;
 
                     // WRK:434-468 decrement the local count; drop the topic when it is gone from all views
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                         znew = bcast_i(ksel, ln);
                     } else {                                                 // WRK:533-535
                         c_tree++;
-                        znew = tree_sample(mm.trees + row * 2 * K, K, u2, root, lane);
+                        znew = tree_sample_preloaded(mm.trees + row * 2 * K, K, bcast_d(u2_l, t), tv, lane);
                     }
                     if (znew < 0) znew = K - 1;                              // WRK:549-552
                     znew = uniform_i(znew);
@@ -361,19 +373,25 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                     }
                     n_tok++;
 
-                    // WRK:587-589 + UPD:197-218: the FastQDelta becomes integer atomics on the delta arrays
-                    if (znew != zold) {
-                        n_chg++;
-                        if (lane < 2) {
-                            const int kk = lane ? znew : zold;
-                            const int vv = lane ? 1 : -1;
-                            if (kk >= 0) {
-                                __hip_atomic_fetch_add(&dnwk[row * K + kk], vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_fetch_add(&nkd[m * K + kk], vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
+                }
+
+                // WRK:587-589 + UPD:197-218 for the whole chunk at once: lane t owns token t (old topic z_l,
+                // new topic znew_l), so the FastQDelta records of up to 64 tokens become two wave-wide
+                // atomic instructions on the delta rows plus two on the block's n_k table.  Issued after
+                // the token loop so that no token ever waits on an atomic's round trip.
+                {
+                    const bool chg = tvalid && (w_l >= 0) && (znew_l != z_l);
+                    n_chg += (unsigned int)__popcll(__ballot(chg));
+                    if (chg) {
+                        const int64_t rowK = (row0 + w_l) * K;
+                        if (z_l >= 0) {
+                            __hip_atomic_fetch_add(&dnwk[rowK + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(&nkd[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        if (mm.first_inactive >= 0 && lane == 2 && mm.inactive[znew]) {   // UPD:263
-                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)(c0 + t) << 11) | (long long)znew;
+                        __hip_atomic_fetch_add(&dnwk[rowK + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&nkd[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (mm.first_inactive >= 0 && mm.inactive[znew_l]) {          // UPD:263
+                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)ti << 11) | (long long)znew_l;
                             atomicMin(sl.act_key, key);
                         }
                     }
@@ -399,6 +417,8 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
     for (int i = threadIdx.x; i < M * K; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
     if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], hist_r[i]);
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
         if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
@@ -430,19 +450,37 @@ hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int
     switch (rmax) {
     case 1: return launch_fast<1>(mm, sl, grid_blocks, debug, s);
     case 2: return launch_fast<2>(mm, sl, grid_blocks, debug, s);
-    case 3:
+    case 3: return launch_fast<3>(mm, sl, grid_blocks, debug, s);
     case 4: return launch_fast<4>(mm, sl, grid_blocks, debug, s);
     default: return hipErrorInvalidValue;
     }
 }
 
+// Resident blocks per CU from the kernel's own register count and LDS need (the occupancy API
+// mis-reports both directions for these kernels; an over-estimate only queues blocks, an
+// under-estimate idles SIMDs).
+static int blocks_per_cu_from(const void* func, int threads, size_t lds)
+{
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, func) != hipSuccess) return 1;
+    int regs = (a.numRegs + 7) / 8 * 8;
+    int waves_simd = regs > 0 ? 512 / regs : 8;
+    if (waves_simd > 8) waves_simd = 8;
+    if (waves_simd < 1) waves_simd = 1;
+    int wpb = threads / 64;
+    int by_regs = waves_simd * 4 / wpb;
+    int by_lds = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    int by_waves = 32 / wpb;
+    int b = by_regs < by_lds ? by_regs : by_lds;
+    if (by_waves < b) b = by_waves;
+    return b < 1 ? 1 : b;
+}
+
 template <int RMAX>
 static int occ_fast(bool debug, int threads, size_t lds)
 {
-    int nb = 0;
-    hipError_t e = debug ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_fast_kernel<RMAX, true>, threads, lds)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_fast_kernel<RMAX, false>, threads, lds);
-    return e == hipSuccess ? nb : 0;
+    return debug ? blocks_per_cu_from((const void*)sweep_fast_kernel<RMAX, true>, threads, lds)
+                 : blocks_per_cu_from((const void*)sweep_fast_kernel<RMAX, false>, threads, lds);
 }
 
 int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes)
@@ -450,7 +488,7 @@ int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t l
     switch (rmax) {
     case 1: return occ_fast<1>(debug, block_threads, lds_bytes);
     case 2: return occ_fast<2>(debug, block_threads, lds_bytes);
-    case 3:
+    case 3: return occ_fast<3>(debug, block_threads, lds_bytes);
     case 4: return occ_fast<4>(debug, block_threads, lds_bytes);
     default: return 0;
     }

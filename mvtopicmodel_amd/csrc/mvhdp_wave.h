@@ -148,3 +148,46 @@ __device__ __forceinline__ int tree_sample(const double* __restrict__ tree, int 
     return i - K;                                          // FT:132
 }
 
+
+// Same descent, but the first round (tree[1..63] of the word, one node per lane: lane l holds
+// tree[l+1]) was loaded ahead of time together with the token's n_wk gather, so a K<=2048 descent
+// pays one dependent load round instead of two.  Lane 0 of `first` is tree[1], the root (FT:120).
+__device__ __forceinline__ int tree_sample_preloaded(const double* __restrict__ tree, int K, double u2, double first, int lane)
+{
+    int i = 1;
+    double u = u2 * bcast_d(first, 0);                     // FT:120
+    {
+        int rel_t = 0, rel_o = 0;
+#pragma unroll
+        for (int step = 0; step < 5; step++) {
+            if (i < K) {
+                int src = (2 << rel_t) + 2 * rel_o - 1;   // lane holding tree[2*i] (node n sits in lane n-1)
+                double l = bcast_d(first, src);
+                if (u < l) { i = 2 * i; rel_o = 2 * rel_o; }
+                else { u = u - l; i = 2 * i + 1; rel_o = 2 * rel_o + 1; }
+                rel_t++;
+            }
+        }
+        i = uniform_i(i);
+    }
+    const int j = lane + 2;
+    const int t = 31 - __clz(j);
+    const int o = j - (1 << t);
+    while (i < K) {
+        long long idx = ((long long)i << t) + o;
+        double v = (lane < 62 && idx < 2LL * K) ? tree[idx] : 0.0;
+        int rel_t = 0, rel_o = 0;
+#pragma unroll
+        for (int step = 0; step < 5; step++) {
+            if (i < K) {
+                int src = (2 << rel_t) + 2 * rel_o - 2;
+                double l = bcast_d(v, src);
+                if (u < l) { i = 2 * i; rel_o = 2 * rel_o; }
+                else { u = u - l; i = 2 * i + 1; rel_o = 2 * rel_o + 1; }
+                rel_t++;
+            }
+        }
+        i = uniform_i(i);
+    }
+    return i - K;
+}

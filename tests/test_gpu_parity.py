@@ -252,3 +252,25 @@ def test_long_entities_take_the_generic_kernel_and_work_queue_order():
         assert rs.tokens == c.total_tokens
         assert_same_state(o, s, 2)
     s.close()
+
+
+def test_overflow_entities_are_rerun_by_the_generic_kernel():
+    """After the first sweep the register-resident kernel is sized for the bulk of the entities
+    (<= 0.5% overflow); the rare entity with a longer topic list goes through the overflow list
+    to the generic kernel inside the same mvhdp_sweep call.  Results must not change."""
+    K, V = 400, [3000]
+    rng = np.random.RandomState(9)
+    lens = np.full(601, 12, dtype=np.int64)
+    lens[[100, 377]] = [330, 200]                     # ~225 and ~160 distinct topics: need 4 and 3 slot rounds
+    off = np.concatenate([[0], np.cumsum(lens)])
+    from mvtopicmodel_amd.synth import Corpus
+    c = Corpus(K, V, [off], [rng.randint(0, 3000, off[-1]).astype(np.int32)])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(0)])
+    for it in range(4):
+        ro = o.sweep(it, 23); rs = s.sweep(it, 23)
+        assert rs.tokens == c.total_tokens == ro["stats"]["tokens"]
+        assert rs.changed == ro["stats"]["changed"]
+        assert_same_state(o, s, 1)
+    s.close()
