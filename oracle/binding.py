@@ -22,6 +22,7 @@ class Stats(C.Structure):
         ("word_ftree_mass_cnt", C.c_int64), ("oov_skipped", C.c_int64),
         ("aborted_docs", C.c_int64),
         ("activated_topic", C.c_int32), ("activated_modality", C.c_int32),
+        ("activation_key", C.c_int64),
     ]
 
     def as_dict(self):
@@ -86,7 +87,7 @@ def lib():
     L.orc_draw_p_philox.argtypes = [vp, u64, u32, i64, vp]
     L.orc_sweep.argtypes = [vp, u32, u64, i64, vp, u32, P(Stats), vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.orc_sweep.restype = C.c_int
-    L.orc_apply_delta.argtypes = [vp, vp, vp]
+    L.orc_apply_delta.argtypes = [vp, vp, vp, i32, i32]
     L.orc_threaded_estimate.argtypes = [vp, C.c_int, C.c_int, u64, P(Stats)]
     L.orc_threaded_estimate.restype = dbl
     _lib = L
@@ -239,10 +240,10 @@ class Oracle:
         return dict(stats=st.as_dict(), delta_nwk=dn, delta_nk=dk,
                     dbg=[d[: self.N[m]] for m, d in enumerate(dbg)] if dbg else None, trace=tout)
 
-    def apply_delta(self, dn, dk):
+    def apply_delta(self, dn, dk, act_topic=-1, act_modality=-1):
         dn = np.ascontiguousarray(dn, dtype=np.int32)
         dk = np.ascontiguousarray(dk, dtype=np.int32)
-        self.L.orc_apply_delta(self.h, _ptr(dn), _ptr(dk))
+        self.L.orc_apply_delta(self.h, _ptr(dn), _ptr(dk), int(act_topic), int(act_modality))
 
     def threaded_estimate(self, num_threads, iters, seed):
         st = Stats()

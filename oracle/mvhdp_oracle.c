@@ -680,7 +680,8 @@ static int sample_one_doc(orc_model* o, int64_t d, int64_t doc_global, uint32_t 
             st->tokens++;
             if (newTopic != oldTopic) {                                       /* WRK:587-589 */
                 st->changed++;
-                delta_t dl = { oldTopic, newTopic, type, m, 0 };
+                delta_t dl = { oldTopic, newTopic, type, m,
+                               (int64_t)(((uint64_t)doc_global << 34) | ((uint64_t)m << 31) | ((uint64_t)position << 11) | (uint64_t)newTopic) };
                 dv_push(dv, dl);
             }
         }
@@ -707,7 +708,7 @@ static void apply_deltas(orc_model* o, const delta_vec* dv, orc_stats* st, int32
         if (delta_nwk) delta_nwk[row + dl->newT]++;
         if (delta_nk) delta_nk[(size_t)dl->mod * K + dl->newT]++;
         if (o->inactive[dl->newT]) {                                                              /* UPD:263-270 */
-            if (st->activated_topic < 0) { st->activated_topic = dl->newT; st->activated_modality = dl->mod; }
+            if (st->activated_topic < 0) { st->activated_topic = dl->newT; st->activated_modality = dl->mod; st->activation_key = dl->key; }
             if (apply) {
                 o->inactive[dl->newT] = 0;
                 o->alpha[(size_t)dl->mod * (K + 1) + dl->newT] = o->alpha[(size_t)dl->mod * (K + 1) + K];
@@ -726,7 +727,7 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
 {
     const int K = o->K, M = o->M;
     orc_stats local; memset(&local, 0, sizeof local);
-    local.activated_topic = -1; local.activated_modality = -1;
+    local.activated_topic = -1; local.activated_modality = -1; local.activation_key = INT64_MAX;
 
     if (!(flags & ORC_SWEEP_REUSE_TREES)) orc_build_trees(o);
 
@@ -767,10 +768,15 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
     return 0;
 }
 
-void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk)
+void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk,
+                     int32_t act_topic, int32_t act_modality)
 {
     const int K = o->K, M = o->M;
     size_t n = (size_t)o->rowbase[M] * K;
     for (size_t i = 0; i < n; i++) o->nwk[i] += delta_nwk[i];
     for (size_t i = 0; i < (size_t)M * K; i++) o->nk[i] += delta_nk[i];
+    if (act_topic >= 0 && act_topic < K && act_modality >= 0 && act_modality < M && o->inactive[act_topic]) {
+        o->inactive[act_topic] = 0;                                                  /* UPD:266-268 */
+        o->alpha[(size_t)act_modality * (K + 1) + act_topic] = o->alpha[(size_t)act_modality * (K + 1) + K];
+    }
 }

@@ -74,6 +74,7 @@ typedef struct {
     int64_t aborted_docs;         /* Q11: exception inside a doc */
     int32_t activated_topic;      /* UPD:263-270, -1 if none */
     int32_t activated_modality;
+    int64_t activation_key;       /* (global doc<<34 | view<<31 | pos<<11 | topic) of that first delta, INT64_MAX if none */
 } orc_stats;
 
 orc_model* orc_create(int K, int M, const int32_t* V);
@@ -132,8 +133,10 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
               int n_trace, const int64_t* trace_doc, const int32_t* trace_view,
               const int32_t* trace_pos, double* trace_out);
 
-/* Apply externally reduced deltas (multi-rank tests): n_wk += d, n_k += d. */
-void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk);
+/* Apply externally reduced deltas (multi-rank tests): n_wk += d, n_k += d, then the topic
+ * activation (UPD:263-270) decided by the caller (act_topic < 0: none). */
+void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk,
+                     int32_t act_topic, int32_t act_modality);
 
 /* ---------------- CPU baseline: the reference's thread topology ---------------- */
 /* T threads -> nst = 3T/4 samplers over contiguous doc slices, nut = T/4

@@ -363,7 +363,7 @@ double orc_threaded_estimate(orc_model* o, int num_threads, int iters, uint64_t 
         st->new_mass_cnt = atomic_load(&sh.newMassCnt);
         st->topic_doc_mass_cnt = atomic_load(&sh.topicDocMassCnt);
         st->word_ftree_mass_cnt = atomic_load(&sh.wordFTreeMassCnt);
-        st->activated_topic = -1; st->activated_modality = -1;
+        st->activated_topic = -1; st->activated_modality = -1; st->activation_key = INT64_MAX;
     }
     for (int i = 0; i < nst * nut; i++) q_free(&sh.queues[i]);
     free(sh.queues); free(sh.tree_lock); free((void*)sh.hist); free(ws); free(us); free(th);

@@ -1,0 +1,88 @@
+"""GPU side of the sharded path: library-owned HBM buffers aliased as torch tensors and
+handed to the RCCL ("nccl") backend.  One GPU only here (the driver runs 2/4/8)."""
+import os
+
+import numpy as np
+import pytest
+
+from mvtopicmodel_amd.native import Hyper
+from tests.helpers import assert_same_state, make_native, make_oracle, small_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_buffers_alias_and_single_rank_rccl_all_reduce():
+    import torch
+    import torch.distributed as dist
+    from mvtopicmodel_amd.dist import GpuShard, build_counts_all_reduce, sweep_all_reduce
+    K, V = 50, [600, 80]
+    c = small_corpus(K, V, 120, [40, 6], 91)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    shard = GpuShard(s, "cuda:0")
+    # the tensors alias the library's buffers: counts visible without a copy
+    nwk0, nk0 = s.get_counts(0)
+    nw = sum(V) * K
+    assert np.array_equal(shard.counts[: V[0] * K].cpu().numpy().reshape(V[0], K), nwk0)
+    assert np.array_equal(shard.counts[nw: nw + K].cpu().numpy(), nk0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        build_counts_all_reduce(shard)
+        t = shard.delta.clone()
+        dist.all_reduce(shard.delta)            # RCCL on library-owned memory
+        torch.cuda.synchronize()
+        assert torch.equal(t, shard.delta)
+        for it in range(2):
+            o.sweep(it, 5)
+            sweep_all_reduce(shard, it, 5)
+            assert_same_state(o, s, 2)
+    finally:
+        dist.destroy_process_group()
+    s.close()
+
+
+def test_shards_on_one_gpu_equal_single_shard():
+    """Two NativeSampler shards (as two ranks would hold them) + a host-side sum of their deltas
+    == one sampler over all documents: doc sharding with a global doc id base is exact."""
+    from mvtopicmodel_amd import synth
+    from mvtopicmodel_amd.native import SWEEP_NO_APPLY
+    K, V = 60, [700, 90, 70]
+    c = small_corpus(K, V, 150, [40, 5, 6], 92)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(3)]
+    tot = sum(np.diff(c.doc_off[m]) for m in range(3))
+    bounds = synth.shard_bounds(tot, 2)
+    shards = []
+    for lo, hi in bounds:
+        sub = c.slice_docs(lo, hi)
+        zs = [z[m][c.doc_off[m][lo]:c.doc_off[m][hi]] for m in range(3)]
+        shards.append(make_native(sub, hy, zs, doc_id_base=lo))
+    # global counts on every shard
+    glob = [o.get_counts(m) for m in range(3)]
+    for sh in shards:
+        for m in range(3):
+            sh.set_counts(m, *glob[m])
+    import torch
+    from mvtopicmodel_amd.dist import GpuShard
+    gs = [GpuShard(sh, "cuda:0") for sh in shards]
+    for it in range(2):
+        o.sweep(it, 11)
+        for g in gs:
+            g.sweep_local(it, 11)
+        total = gs[0].delta + gs[1].delta
+        for g in gs:
+            g.delta.copy_(total)
+            torch.cuda.synchronize()
+            g.apply(-1, -1)
+        for m in range(3):
+            zcat = np.concatenate([sh.get_assignments(m) for sh in shards])
+            assert np.array_equal(zcat, o.get_assignments(m))
+            for sh in shards:
+                a, b = sh.get_counts(m)
+                assert np.array_equal(a, o.get_counts(m)[0]) and np.array_equal(b, o.get_counts(m)[1])
+    for sh in shards:
+        sh.close()
