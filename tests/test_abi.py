@@ -51,9 +51,11 @@ def test_no_device_is_a_loud_error_not_a_fallback():
 
 
 def test_product_never_imports_the_oracle():
+    """Nothing under mvtopicmodel_amd/ may import, load, link or call anything under oracle/."""
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|oracle[/.]binding|oracle/|libmvhdp_oracle|\borc_[a-z_]+\s*\()")
     pkg = os.path.join(ROOT, "mvtopicmodel_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
                 src = open(os.path.join(dp, f), errors="ignore").read()
-                assert "oracle" not in src.lower(), (dp, f)
+                assert not pat.search(src), (dp, f, pat.search(src).group(0))
