@@ -281,7 +281,10 @@ extern "C" int mvhdp_set_hyper(mvhdp_handle h, const mvhdp_hyper* hy)
     MvModel& mm = h->mm;
     const int K = mm.K, M = mm.M;
     for (int m = 0; m < M; m++) {
-        if (!(hy->beta_sum[m] > 0) || !(hy->beta[m] > 0)) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_hyper: beta and beta_sum must be > 0");
+        // (n_wk+beta)/(n_k+betaSum) is evaluated with the unscaled IEEE division sequence (div_inrange):
+        // keep both operands far from the exponent limits
+        if (!(hy->beta_sum[m] >= 1e-30 && hy->beta_sum[m] <= 1e30) || !(hy->beta[m] >= 1e-30 && hy->beta[m] <= 1e30))
+            FAIL(h, MVHDP_ERR_INVALID_ARG, "set_hyper: beta and beta_sum must be in [1e-30, 1e30]");
         mm.alpha_sum[m] = hy->alpha_sum[m]; mm.beta[m] = hy->beta[m];
         mm.beta_sum[m] = hy->beta_sum[m];   mm.gamma[m] = hy->gamma[m];
         for (int j = 0; j < M; j++) { mm.p_a[m][j] = hy->p_a[m][j]; mm.p_b[m][j] = hy->p_b[m][j]; }
