@@ -155,6 +155,19 @@ def main():
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     bpt = algorithmic_bytes_per_token(K)
     achieved = local_tokens * bpt / avg_kernel_s / 1e9
+    # HBM-side traffic of the same kernel from the committed PMC passes (profiles/profile_c4.sh:
+    # separate FETCH_SIZE / WRITE_SIZE runs); bytes per token there x tokens per launch here.
+    traffic = None
+    traffic_note = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc_summary.json")))
+        if args.workload == "C4":
+            bpt_meas = pm["fetch_bytes_per_token"] + pm["write_bytes_per_token"]
+            traffic = local_tokens * bpt_meas / avg_kernel_s / 1e9
+            traffic_note = (f"{bpt_meas:.0f} B/token (FETCH_SIZE+WRITE_SIZE, raw counters, Infinity-Cache hits included) "
+                            "recorded by profiles/profile_c4.sh, not re-measured in this run")
+    except Exception:
+        pass
     out = {
         "metric": "gibbs_tokens_per_sec", "value": value, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +178,7 @@ def main():
                    "topics": K, "views": M, "tokens": total_tokens, "entities": D_total,
                    "sharding": f"documents/{world}, per-sweep int32 all-reduce of n_wk,n_k deltas" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "sweep_kernel", "bytes_per_token": bpt, "tokens_per_launch": local_tokens,
                      "avg_kernel_ms": avg_kernel_s * 1e3},
         "sweep": {"changed_frac": last.changed / max(1, last.tokens),
