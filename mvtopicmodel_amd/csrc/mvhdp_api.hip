@@ -62,7 +62,7 @@ struct mvhdp_ctx {
 // Returns 5 when the generic kernel alone is the cheapest.
 static int rmax_from_hist(const unsigned int* hist5)
 {
-    static const double cost_fast[4] = {0.85, 1.0, 1.35, 1.8};
+    static const double cost_fast[4] = {0.85, 1.0, 1.8, 1.8};    // 3 is served by the 4-slot variant
     const double cost_generic = 3.2;
     double tot = 0;
     for (int i = 0; i < 5; i++) tot += hist5[i];

@@ -4,7 +4,7 @@
 // of mvhdp_kernels.hip).  Same arithmetic, same order, same results as the
 // generic kernel; what changes is where the per-entity state lives:
 //
-//   slot i = r*64 + lane  (r < RMAX)      -> lane registers
+//   slot i = lane*R + r  (R = 1,2 or 4 slots per lane, R <= RMAX)  -> lane registers
 //     skr[r]  topic of the slot, sign bit = removed from the list (WRK:451-468)
 //     cn[r]   localTopicCounts[m][topic] of the view being sampled (WRK:357,437,560)
 //     oth[r]  totalMassOtherModalities[topic]                       (WRK:399-410)
@@ -14,7 +14,8 @@
 //     the gather for token t+1 is issued before token t is sampled, so its HBM/L2
 //     latency hides behind a whole token of work (legal because the sweep reads a
 //     snapshot of n_wk: the deltas go to a separate buffer).
-//   topicDocWordMasses (WRK:511) = RMAX DPP prefix scans, never stored.
+//   topicDocWordMasses (WRK:511) = an in-lane running sum over the lane's R slots plus ONE DPP
+//     prefix scan of the lane totals per token, never stored.
 //
 // LDS per wave shrinks to bitmap + prefix + slot->topic + per-view counts
 // (~3.6 KB at K=400, M=3), so occupancy is bound by VGPRs, not LDS.
@@ -111,17 +112,20 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
         }
         LDS_FENCE();
         { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1]++; }
-        if (S_used > 64 * RMAX) {                                          // too many topics for this variant:
+        // slots per lane: 1, 2 or 4 consecutive slots (slot i = lane*R_eff + r)
+        const int lg = (S_used <= 64) ? 0 : ((S_used <= 128) ? 1 : 2);
+        const int R_eff = 1 << lg;
+        if (S_used > 256 || R_eff > RMAX) {                                // too many topics for this variant:
             if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;   // the generic kernel takes it
             continue;
         }
-        const int R_eff = (S_used + 63) >> 6;
 
-        int skr[RMAX];
+        int skr[RMAX], koff[RMAX];
 #pragma unroll
         for (int r = 0; r < RMAX; r++) {
-            const int i = r * 64 + lane;
-            skr[r] = (i < S_used) ? sk[i] : (int)0x80000000;              // unused slot = removed topic 0
+            const int i = lane * R_eff + r;
+            skr[r] = (r < R_eff && i < S_used) ? sk[i] : (int)0x80000000;  // unused slot = removed topic 0
+            koff[r] = (skr[r] & 0x7fffffff) << 2;                          // byte offset of the topic inside an n_wk row
         }
 
         const double* pd = (M > 1) ? (mm.p + d * M * M) : nullptr;        // WRK:327-337
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
 #pragma unroll
             for (int r = 0; r < RMAX; r++) {
                 cn[r] = 0; oth[r] = 0.0; den[r] = 1.0;
-                const int i = r * 64 + lane;
+                const int i = lane * R_eff + r;
                 if (r < R_eff && i < S_used) {
                     const int k = skr[r] & 0x7fffffff;
                     cn[r] = sn[m * S + i];
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                 {
                     const int w0 = bcast_i(w_l, 0);
                     const int64_t r0 = row0 + max(w0, 0);
-                    const int32_t* __restrict__ c0p = nwk + r0 * K;
+                    const char* __restrict__ c0p = (const char*)(nwk + r0 * K);
 #pragma unroll
-                    for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? c0p[skr[r] & 0x7fffffff] : 0;
+                    for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
                     tvn = tlane ? mm.trees[r0 * 2 * K + lane + 1] : 0.0;
                 }
 
@@ -218,9 +222,9 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                     if (t + 1 < nt) {
                         const int wn = bcast_i(w_l, t + 1);
                         const int64_t rn = row0 + max(wn, 0);
-                        const int32_t* __restrict__ cnp = nwk + rn * K;
+                        const char* __restrict__ cnp = (const char*)(nwk + rn * K);
 #pragma unroll
-                        for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? cnp[skr[r] & 0x7fffffff] : 0;
+                        for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? *(const int32_t*)(cnp + koff[r]) : 0;
                         tvn = tlane ? mm.trees[rn * 2 * K + lane + 1] : 0.0;
                     }
                     const int w = bcast_i(w_l, t);
@@ -232,92 +236,108 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
 
                     // WRK:434-468 decrement the local count; drop the topic when it is gone from all views
                     if (so >= 0) {
-                        const int rs = so >> 6, ls = so & 63;
-                        int csel = 0;
+                        const int rs = so & (R_eff - 1), ls = so >> lg;
+                        int csel = cn[0];
 #pragma unroll
-                        for (int r = 0; r < RMAX; r++)
-                            if (r == rs) { if (lane == ls) cn[r]--; csel = cn[r]; }
-                        const int c = bcast_i(csel, ls);
-                        if (c == 0 && !((bcast_i((int)onz, ls) >> rs) & 1)) {
+                        for (int r = 1; r < RMAX; r++) csel = (rs == r) ? cn[r] : csel;
+                        const int c = bcast_i(csel, ls) - 1;
+                        const bool kill = (c == 0) && !((bcast_i((int)onz, ls) >> rs) & 1);
+                        if (lane == ls) {
 #pragma unroll
-                            for (int r = 0; r < RMAX; r++)
-                                if (r == rs && lane == ls) skr[r] |= (int)0x80000000;
+                            for (int r = 0; r < RMAX; r++) {
+                                if (rs == r) { cn[r] = c; if (kill) skr[r] |= (int)0x80000000; }
+                            }
                         }
                     }
 
-                    // WRK:496-513 topicDocWordMasses.  pass 0: DPP prefix scans (certified below);
-                    // pass 1: the reference's sequential left-to-right sum.
-                    double cum[RMAX], term[RMAX];
+                    // WRK:496-513 topicDocWordMasses: terms of the lane's slots, in-lane running sum,
+                    // one DPP prefix scan of the lane totals (certified below); the reference's sequential
+                    // left-to-right sum only when a comparison is too close to call.
+                    double term[RMAX], cum[RMAX];
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) {
-                        term[r] = 0.0; cum[r] = 0.0;
+                        term[r] = 0.0;
                         if (r < R_eff && skr[r] >= 0) {
-                            double p_wt = div_inrange((double)g[r] + beta_m, den[r]);
-                            term[r] = (p_mm * (double)cn[r] + oth[r]) * p_wt;                // WRK:509
+                            double p_wt = div_inrange((double)g[r] + beta_m, den[r]);      // WRK:507
+                            term[r] = (p_mm * (double)cn[r] + oth[r]) * p_wt;              // WRK:509
                         }
                     }
-                    double mass = 0.0, s0 = 0.0, s1 = 0.0, total = 0.0;
-                    int branch = 0;          // 0 new-topic, 1 doc, 2 tree
-                    int slot_new = -1;
-                    for (int pass = exact_only ? 1 : 0; pass < 2; pass++) {
-                        if (pass == 0) {
-                            double carry = 0.0;
+                    double mass, s0, s1 = 0.0, total;
+                    int branch, slot_new = -1;     // branch: 0 new-topic, 1 doc, 2 tree
+                    bool unsafe;
+                    {
+                        double lsum = term[0];
+                        cum[0] = lsum;
 #pragma unroll
-                            for (int r = 0; r < RMAX; r++) {
-                                if (r < R_eff) {
-                                    cum[r] = carry + wave_incl_scan_d_dpp(term[r]);
-                                    carry = bcast_d(cum[r], 63);
-                                }
-                            }
-                            mass = carry;
-                        } else {
-                            double c = 0.0;
+                        for (int r = 1; r < RMAX; r++) { if (r < R_eff) { lsum += term[r]; } cum[r] = lsum; }
+                        const double incl = wave_incl_scan_d_dpp(lsum);
+                        const double excl = incl - lsum;
 #pragma unroll
-                            for (int r = 0; r < RMAX; r++) {
-                                if (r < R_eff) {
-                                    const int lim = min(64, S_used - r * 64);
-                                    for (int l = 0; l < lim; l++) {           // WRK:501-513, dense order
-                                        c += bcast_d(term[r], l);
-                                        if (lane == l) cum[r] = c;
-                                    }
-                                }
-                            }
-                            mass = c;
-                        }
-
-                        total = newMass + mass + root;                       // WRK:519
-                        s0 = u1 * total;
-                        // Certified scan (see mvhdp_kernels.hip / DESIGN.md): decisions are bit-identical to the
-                        // sequential sum unless a comparison is closer than tol, in which case pass 1 runs.
-                        const double tol = (pass == 0) ? total * (double)(4 * S_used + 16) * 0x1.0p-53 : -1.0;
-                        bool unsafe = false;
-                        if (s0 < newMass) {                                  // WRK:522
-                            branch = 0;
-                            if (fabs(s0 - newMass) <= tol) unsafe = true;
-                        } else {
-                            if (newMass != 0.0 && fabs(s0 - newMass) <= tol) unsafe = true;
-                            s1 = s0 - newMass;                               // WRK:528
-                            if (fabs(s1 - mass) <= tol) unsafe = true;
-                            if (s1 < mass) {                                 // WRK:529
-                                branch = 1;
-                                slot_new = -1;
-#pragma unroll
-                                for (int r = 0; r < RMAX; r++) {             // WRK:531 lower_bound over the live list
-                                    if (r < R_eff) {
-                                        const bool live = skr[r] >= 0;
-                                        const double diff = cum[r] - s1;
-                                        if (__ballot(live && fabs(diff) <= tol)) unsafe = true;
-                                        unsigned long long hit = __ballot(live && diff >= 0.0);
-                                        if (hit && slot_new < 0) slot_new = r * 64 + (int)__builtin_ctzll(hit);
-                                    }
-                                }
-                            } else {
-                                branch = 2;
-                            }
-                        }
-                        if (!(pass == 0 && unsafe)) break;
-                        n_fb++;
+                        for (int r = 0; r < RMAX; r++) cum[r] = (r == R_eff - 1) ? incl : excl + cum[r];
+                        mass = bcast_d(incl, 63);
                     }
+                    // decision on (cum, mass); tol < 0 disables the closeness checks
+#define MVHDP_DECIDE(TOL)                                                                                   \
+                    {                                                                                       \
+                        const double tol_ = (TOL);                                                          \
+                        total = newMass + mass + root;                       /* WRK:519 */                  \
+                        s0 = u1 * total;                                                                    \
+                        unsafe = false; slot_new = -1;                                                      \
+                        if (s0 < newMass) {                                  /* WRK:522 */                  \
+                            branch = 0;                                                                     \
+                            unsafe = fabs(s0 - newMass) <= tol_ * total;                                    \
+                        } else {                                                                            \
+                            s1 = s0 - newMass;                               /* WRK:528 */                  \
+                            unsafe = (newMass != 0.0 && fabs(s1) <= tol_ * total) || (fabs(s1 - mass) <= tol_ * total); \
+                            if (s1 < mass) {                                 /* WRK:529 */                  \
+                                branch = 1;                                                                 \
+                                unsigned long long anyhit = 0, near = 0, hitr[RMAX];                        \
+                                _Pragma("unroll")                                                           \
+                                for (int r = 0; r < RMAX; r++) {             /* WRK:531 lower_bound over the live list */ \
+                                    hitr[r] = 0;                                                            \
+                                    if (r < R_eff) {                                                        \
+                                        const bool live = skr[r] >= 0;                                      \
+                                        const double diff = cum[r] - s1;     /* sign-exact: diff >= 0 <=> cum >= s1 */ \
+                                        near |= __builtin_amdgcn_ballot_w64(live && fabs(diff) <= tol_ * total); \
+                                        hitr[r] = __builtin_amdgcn_ballot_w64(live && diff >= 0.0);         \
+                                        anyhit |= hitr[r];                                                  \
+                                    }                                                                       \
+                                }                                                                           \
+                                if (near) unsafe = true;                                                    \
+                                if (anyhit) {                                                               \
+                                    const int hl = (int)__builtin_ctzll(anyhit);                            \
+                                    int rr = 0;                                                             \
+                                    _Pragma("unroll")                                                       \
+                                    for (int r = RMAX - 1; r >= 0; r--) if ((hitr[r] >> hl) & 1ull) rr = r; \
+                                    slot_new = hl * R_eff + rr;                                             \
+                                }                                                                           \
+                            } else {                                                                        \
+                                branch = 2;                                                                 \
+                            }                                                                               \
+                        }                                                                                   \
+                    }
+                    // Certified scan: any summation order of the same non-negative terms differs from the
+                    // sequential one by < 2n ulp-units of the total; if no comparison is closer than that the
+                    // decisions equal the reference's bit for bit, otherwise the sequential sum decides.
+                    MVHDP_DECIDE((double)(4 * S_used + 16) * 0x1.0p-53)
+                    if (__builtin_expect(unsafe || exact_only, 0)) {
+                        if (unsafe) n_fb++;
+                        double c = 0.0;
+                        for (int i = 0; i < S_used; i++) {                   // WRK:501-513, dense order
+                            const int li = i >> lg, ri = i & (R_eff - 1);
+                            double tsel = term[0];
+#pragma unroll
+                            for (int r = 1; r < RMAX; r++) tsel = (ri == r) ? term[r] : tsel;
+                            c += bcast_d(tsel, li);
+                            if (lane == li) {
+#pragma unroll
+                                for (int r = 0; r < RMAX; r++) if (ri == r) cum[r] = c;
+                            }
+                        }
+                        mass = c;
+                        MVHDP_DECIDE(-1.0)
+                    }
+#undef MVHDP_DECIDE
 
                     if (DEBUG) {
                         if (sl.tok_dbg[m] && lane == 0) {
@@ -346,10 +366,10 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                     } else if (branch == 1) {                                // WRK:530-531
                         c_doc++;
                         if (slot_new < 0) { aborted = true; break; }         // lower_bound == -1 -> exception, Q11
-                        const int rn = slot_new >> 6, ln = slot_new & 63;
-                        int ksel = 0;
+                        const int rn = slot_new & (R_eff - 1), ln = slot_new >> lg;
+                        int ksel = skr[0];
 #pragma unroll
-                        for (int r = 0; r < RMAX; r++) if (r == rn) ksel = skr[r];
+                        for (int r = 1; r < RMAX; r++) ksel = (rn == r) ? skr[r] : ksel;
                         znew = bcast_i(ksel, ln);
                     } else {                                                 // WRK:533-535
                         c_tree++;
@@ -366,10 +386,11 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                         slot_new = uniform_i(slot_new);
                     }
                     if (slot_new >= 0) {
-                        const int rn = slot_new >> 6, ln = slot_new & 63;
+                        const int rn = slot_new & (R_eff - 1), ln = slot_new >> lg;
+                        if (lane == ln) {
 #pragma unroll
-                        for (int r = 0; r < RMAX; r++)
-                            if (r == rn && lane == ln) cn[r]++;
+                            for (int r = 0; r < RMAX; r++) if (rn == r) cn[r]++;
+                        }
                     }
                     n_tok++;
 
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
             // the view's counts go back to LDS: later views read them (WRK:404) and test them (WRK:445)
 #pragma unroll
             for (int r = 0; r < RMAX; r++) {
-                const int i = r * 64 + lane;
+                const int i = lane * R_eff + r;
                 if (r < R_eff && i < S_used) sn[m * S + i] = cn[r];
             }
             LDS_FENCE();
@@ -450,7 +471,7 @@ hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int
     switch (rmax) {
     case 1: return launch_fast<1>(mm, sl, grid_blocks, debug, s);
     case 2: return launch_fast<2>(mm, sl, grid_blocks, debug, s);
-    case 3: return launch_fast<3>(mm, sl, grid_blocks, debug, s);
+    case 3:
     case 4: return launch_fast<4>(mm, sl, grid_blocks, debug, s);
     default: return hipErrorInvalidValue;
     }
@@ -488,7 +509,7 @@ int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t l
     switch (rmax) {
     case 1: return occ_fast<1>(debug, block_threads, lds_bytes);
     case 2: return occ_fast<2>(debug, block_threads, lds_bytes);
-    case 3: return occ_fast<3>(debug, block_threads, lds_bytes);
+    case 3:
     case 4: return occ_fast<4>(debug, block_threads, lds_bytes);
     default: return 0;
     }
