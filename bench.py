@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=60000)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 ranks all on cuda:0 with the gloo backend (host-staged all-reduce): exercises the "
+                         "sharding logic on a 1-GPU box; not a performance number")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,11 +91,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sweep has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
     cfg = dict(synth.CONFIGS[args.workload])
     D_total = args.docs or cfg["D"]
@@ -121,7 +129,7 @@ def main():
         s.set_corpus(m, corpus.doc_off[m], corpus.tokens[m])
         s.set_assignments(m, z0[m])
     s.set_hyper(Hyper.defaults(K, V))
-    shard = GpuShard(s, device)
+    shard = GpuShard(s, device, host_staged=args.rehearse_on_one_gpu)
     build_counts_all_reduce(shard)
     local_tokens = corpus.total_tokens
     del z0
@@ -145,7 +153,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -172,7 +180,8 @@ def main():
         "metric": "gibbs_tokens_per_sec", "value": value, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if args.rehearse_on_one_gpu else ""),
         "config": {"workload": f"{args.workload}: {D_total} entities x {M} views, K={K}, vocab {V}, "
                                f"{total_tokens} tokens; doc-sharded across {world} GPU(s)",
                    "topics": K, "views": M, "tokens": total_tokens, "entities": D_total,
@@ -188,6 +197,9 @@ def main():
                   "exact_fallbacks": last.exact_fallbacks, "total_ms_last": last.total_ms},
         "setup_s": setup_s,
     }
+    # order-independent fingerprint of the final global counts: must not depend on the number of shards
+    nk_fp = [int(np.asarray(s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]
+    out["final_nk_fingerprint"] = nk_fp
     s.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample_docs, D_total), 2, args.seed)

@@ -36,13 +36,30 @@ def device_int32_tensor(ptr, nbytes, device):
 class GpuShard:
     """One NativeSampler (one GPU) as a shard of the global model."""
 
-    def __init__(self, sampler, device):
+    def __init__(self, sampler, device, host_staged=False):
         self.s = sampler
         self.device = torch.device(device)
         p, n = sampler.device_buffer(BUF_COUNTS)
-        self.counts = device_int32_tensor(p, n, self.device)
+        self._counts_dev = device_int32_tensor(p, n, self.device)
         p, n = sampler.device_buffer(BUF_DELTA)
-        self.delta = device_int32_tensor(p, n, self.device)
+        self._delta_dev = device_int32_tensor(p, n, self.device)
+        # host_staged: the collective runs on CPU copies (gloo rehearsal of the N>1 path on one GPU)
+        self.host_staged = host_staged
+        self._counts_host = self._delta_host = None
+
+    @property
+    def counts(self):
+        if not self.host_staged:
+            return self._counts_dev
+        self._counts_host = self._counts_dev.cpu()
+        return self._counts_host
+
+    @property
+    def delta(self):
+        if not self.host_staged:
+            return self._delta_dev
+        self._delta_host = self._delta_dev.cpu()
+        return self._delta_host
 
     def build_counts_local(self):
         self.s.build_counts()
@@ -54,6 +71,11 @@ class GpuShard:
         self.s.apply_delta(topic, modality)
 
     def sync(self):
+        if self.host_staged:                 # push all-reduced host copies back to the library's buffers
+            if self._counts_host is not None:
+                self._counts_dev.copy_(self._counts_host); self._counts_host = None
+            if self._delta_host is not None:
+                self._delta_dev.copy_(self._delta_host); self._delta_host = None
         torch.cuda.synchronize(self.device)
 
 
@@ -69,7 +91,8 @@ def build_counts_all_reduce(shard, group=None):
     shard.build_counts_local()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         shard.sync()
-        dist.all_reduce(shard.counts, op=dist.ReduceOp.SUM, group=group)
+        t = shard.counts
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         shard.sync()
 
 
@@ -82,10 +105,11 @@ def sweep_all_reduce(shard, sweep_idx, seed, group=None, flags=0, has_inactive=F
     topic, modality = st.activated_topic, st.activated_modality
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         shard.sync()
-        dist.all_reduce(shard.delta, op=dist.ReduceOp.SUM, group=group)
+        t = shard.delta
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         if has_inactive:
             # UPD:263-270: the first delta in (entity, view, position) order wins, on every replica alike
-            key = torch.tensor([st.activation_key], dtype=torch.int64, device=shard.delta.device)
+            key = torch.tensor([st.activation_key], dtype=torch.int64, device=t.device)
             dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
             topic, modality = decode_activation(int(key.item()))
         shard.sync()
