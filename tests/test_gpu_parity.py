@@ -274,3 +274,35 @@ def test_overflow_entities_are_rerun_by_the_generic_kernel():
         assert rs.changed == ro["stats"]["changed"]
         assert_same_state(o, s, 1)
     s.close()
+
+
+@pytest.mark.parametrize("K,V,D,lam", [
+    (1, [30], 20, [6]),                                  # a single topic: FTree of size 1 (no descent)
+    (2, [30, 7], 30, [9, 3]),
+    (63, [200], 40, [80]), (64, [200], 40, [80]), (65, [200], 40, [80]),   # around one slot round / one bitmap word pair
+    (1000, [900, 60, 60, 60, 60], 24, [96, 7, 7, 7, 7]),  # C5 shape (5 views, K=1000): generic kernel territory
+    (2048, [300], 12, [40]),                             # MVHDP_MAX_TOPICS
+])
+def test_edge_shapes(K, V, D, lam):
+    c = small_corpus(K, V, D, lam, 1000 + K)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    for it in range(2):
+        ro = o.sweep(it, 99); rs = s.sweep(it, 99)
+        assert rs.tokens == ro["stats"]["tokens"] and rs.changed == ro["stats"]["changed"]
+        assert_same_state(o, s, c.M)
+    s.close()
+
+
+def test_eight_views():
+    K, V = 40, [300, 20, 20, 20, 20, 20, 20, 20]
+    c = small_corpus(K, V, 30, [30, 3, 3, 3, 3, 3, 3, 3], 77)
+    hy = Hyper.defaults(K, V)
+    hy.gamma[:] = np.linspace(0.5, 1.5, 8)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(8)])
+    for it in range(2):
+        o.sweep(it, 3); s.sweep(it, 3)
+        assert_same_state(o, s, 8)
+    s.close()
