@@ -137,6 +137,14 @@ int mvhdp_get_tree(mvhdp_handle h, int32_t m, int32_t type, double* tree /*[2K],
 int mvhdp_get_doc_topic_hist(mvhdp_handle h, int32_t m, int32_t* hist /*[K][hist_len]*/, int32_t hist_len,
                              int32_t* doc_len_counts /*[len_len]*/, int32_t len_len);
 
+/* ---- the steps either side of the sweep: statistics the host's optimize* and logging need ---- */
+/* countHistogram of optimizeBeta PTM:2295-2309: hist[c] = number of (type, topic) pairs of view m holding count c (c >= 1, c < len). */
+int mvhdp_get_count_histogram(mvhdp_handle h, int32_t m, int32_t* hist, int32_t len);
+/* optimizeP PTM:2706-2792: sums[m][i] = sum over entities, in entity order, of pDistr_Mean[m][i][doc]. */
+int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums /*[M][M]*/);
+/* modelLogLikelihood PTM:3322-3452, one value per view. */
+int mvhdp_model_log_likelihood(mvhdp_handle h, double* log_likelihood /*[M]*/);
+
 /* ---- the hot path ---- */
 /* One Gibbs sweep over every entity: replaces "submit updaters + submit
  * workers + barrier.await()" PTM:1213-1239, i.e. WRK:186-233 x nst threads and

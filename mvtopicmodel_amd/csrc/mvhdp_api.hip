@@ -671,3 +671,114 @@ extern "C" int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** de
     if (which == MVHDP_BUF_DELTA) { *dev_ptr = h->mm.delta; *bytes = b; return MVHDP_OK; }
     FAIL(h, MVHDP_ERR_INVALID_ARG, "device_buffer: unknown buffer");
 }
+
+// ---------------------------------------------------------------------------
+// statistics for optimizeBeta / optimizeP and the log likelihood
+// ---------------------------------------------------------------------------
+// MALLET 2.0.8 Dirichlet.logGammaStirling (restated from the class file's bytecode)
+static double log_gamma_stirling_host(double z)
+{
+    const double HALF_LOG_TWO_PI = std::log(6.283185307179586) / 2.0;
+    int shift = 0;
+    while (z < 2.0) { z = z + 1; shift++; }
+    double result = HALF_LOG_TWO_PI + (z - 0.5) * std::log(z) - z + 1 / (12.0 * z) - 1 / (360.0 * z * z * z)
+                    + 1 / (1260.0 * z * z * z * z * z);
+    while (shift > 0) { shift--; z = z - 1; result = result - std::log(z); }
+    return result;
+}
+
+extern "C" int mvhdp_get_count_histogram(mvhdp_handle h, int32_t m, int32_t* hist, int32_t len)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M || !hist || len < 1) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_count_histogram: bad argument");
+    if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "get_count_histogram before build_counts/set_counts");
+    HIPC(h, hipSetDevice(h->device));
+    int32_t* d = nullptr;
+    HIPC(h, hipMalloc(&d, (size_t)len * sizeof(int32_t)));
+    hipError_t e = mvhdp_launch_count_hist(mm, m, d, len, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hist, d, (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    HIPC(h, e);
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (!sums) FAIL(h, MVHDP_ERR_INVALID_ARG, "view_overlap_sums: null");
+    int rc = require_corpus(h); if (rc) return rc;
+    const int M = mm.M;
+    for (int i = 0; i < M * M; i++) sums[i] = 0.0;
+    if (mm.D == 0) return MVHDP_OK;
+    HIPC(h, hipSetDevice(h->device));
+    double* d = nullptr;
+    const size_t n = (size_t)M * M * mm.D;
+    HIPC(h, hipMalloc(&d, n * sizeof(double)));
+    std::vector<double> host(n);
+    hipError_t e = mvhdp_launch_view_overlap(mm, d, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    HIPC(h, e);
+    for (int i = 0; i < M * M; i++) {                     // PTM:2789-2792: sequential, entity order
+        double acc = 0;
+        const double* col = host.data() + (size_t)i * mm.D;
+        for (int64_t doc = 0; doc < mm.D; doc++) acc += col[doc];
+        sums[i] = acc;
+    }
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (!out) FAIL(h, MVHDP_ERR_INVALID_ARG, "model_log_likelihood: null");
+    int rc = require_corpus(h); if (rc) return rc;
+    if (!h->have_hyper || !h->have_counts) FAIL(h, MVHDP_ERR_STATE, "model_log_likelihood before set_hyper/build_counts");
+    const int M = mm.M, K = mm.K;
+    HIPC(h, hipSetDevice(h->device));
+    const int NP = 1024;
+    double *d_doc = nullptr, *d_part = nullptr;
+    unsigned long long* d_nz = nullptr;
+    HIPC(h, hipMalloc(&d_doc, (size_t)std::max<int64_t>(mm.D, 1) * sizeof(double)));
+    HIPC(h, hipMalloc(&d_part, NP * sizeof(double)));
+    HIPC(h, hipMalloc(&d_nz, sizeof(unsigned long long)));
+    std::vector<double> hdoc((size_t)std::max<int64_t>(mm.D, 1)), hpart(NP);
+    std::vector<int32_t> nk((size_t)K);
+    hipError_t e = hipSuccess;
+    for (int m = 0; m < M && e == hipSuccess; m++) {
+        unsigned long long nz = 0;
+        e = mvhdp_launch_loglik(mm, m, d_doc, d_part, NP, d_nz, h->stream);
+        if (e == hipSuccess && mm.D > 0) e = hipMemcpyAsync(hdoc.data(), d_doc, (size_t)mm.D * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hpart.data(), d_part, NP * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nk.data(), mm.counts + mm.rowbase[M] * K + (int64_t)m * K, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) break;
+        double ll = 0;
+        int64_t modalityCnt = 0;
+        for (int64_t d = 0; d < mm.D; d++) {
+            if (h->h_doc_off[m][d + 1] > h->h_doc_off[m][d]) { ll += hdoc[d]; modalityCnt++; }     // PTM:3348-3367
+        }
+        ll += modalityCnt * log_gamma_stirling_host((double)mm.gamma[m] * mm.alpha_sum[m]);       // PTM:3373
+        if (std::isnan(ll) || std::isinf(ll)) { out[m] = 0; continue; }                           // PTM:3375-3383
+        for (int i = 0; i < NP; i++) ll += hpart[i];                                                // PTM:3389-3415
+        if (std::isnan(ll) || std::isinf(ll)) ll = 0;
+        const double bv = mm.beta[m] * mm.V[m];
+        for (int topic = 0; topic < K; topic++) {                                                   // PTM:3417-3435
+            ll -= (bv + nk[topic]) == 0 ? 0 : log_gamma_stirling_host(bv + nk[topic]);
+            if (std::isnan(ll) || std::isinf(ll)) ll = 0;
+        }
+        ll += bv == 0 ? 0 : log_gamma_stirling_host(bv) * K;                                        // PTM:3438
+        ll -= mm.beta[m] == 0 ? 0 : log_gamma_stirling_host(mm.beta[m]) * (double)nz;               // PTM:3441
+        if (std::isinf(ll)) ll = 0;
+        out[m] = ll;
+    }
+    hipFree(d_doc); hipFree(d_part); hipFree(d_nz);
+    HIPC(h, e);
+    return MVHDP_OK;
+}

@@ -66,6 +66,10 @@ hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats
 hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
                                        int32_t* doc_len_counts, int32_t len_len, hipStream_t s);
 hipError_t mvhdp_sweep_set_max_lds(size_t bytes);
+hipError_t mvhdp_launch_count_hist(const MvModel& mm, int m, int32_t* hist, int32_t len, hipStream_t s);
+hipError_t mvhdp_launch_view_overlap(const MvModel& mm, double* out, hipStream_t s);
+hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
+                               unsigned long long* nonzero, hipStream_t s);
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned int* hist, hipStream_t s);
 size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap);
 hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);

@@ -1,0 +1,195 @@
+// mvhdp_stats.hip — device side of the steps either side of the sweep (SURVEY §8f "next" rows):
+//   count_hist_kernel     countHistogram of optimizeBeta                   PTM:2295-2309
+//   view_overlap_kernel   pDistr_Mean[m][i][doc] of optimizeP              PTM:2706-2782
+//   loglik_doc_kernel     document half of modelLogLikelihood              PTM:3341-3373
+//   loglik_topic_kernel   topic-word half of modelLogLikelihood            PTM:3387-3415
+// Integer outputs are exact; floating-point per-entity values are produced with the reference's
+// own expression order and summed on the host in entity order (the reference's order), so only the
+// device libm (log) can differ from the CPU restatement.
+#include "mvhdp_device.h"
+#include "../../include/mvhdp.h"
+#include "mvhdp_wave.h"
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_hist_kernel(const int32_t* __restrict__ nwk, int64_t n_cells, int32_t* hist, int32_t len)
+{
+    __shared__ int local[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
+        int c = nwk[i];
+        if (c > 0 && c < len) {                                   // PTM:2305 count > 0
+            if (c < 1024) atomicAdd(&local[c], 1);
+            else atomicAdd(&hist[c], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024 && i < len; i += blockDim.x)
+        if (local[i]) atomicAdd(&hist[i], local[i]);
+}
+
+hipError_t mvhdp_launch_count_hist(const MvModel& mm, int m, int32_t* hist, int32_t len, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)len * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    int64_t n = (int64_t)mm.V[m] * mm.K;
+    int64_t blocks = (n + 255) / 256;
+    int grid = (int)(blocks < 2048 ? (blocks < 1 ? 1 : blocks) : 2048);
+    hipLaunchKernelGGL(count_hist_kernel, dim3(grid), dim3(256), 0, s, mm.counts + mm.rowbase[m] * mm.K, n, hist, len);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// optimizeP: one wave per entity.  out[(m*M+i)*D + doc] = pDistr_Mean[m][i][doc].
+// The TreeMap<Integer,Byte> keyed by view length (PTM:2717,2741) keeps one view per distinct
+// length (the later view wins); views are then visited by descending length (PTM:2744).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void view_overlap_kernel(MvModel mm, double* out)
+{
+    __shared__ uint32_t bm[4][MVHDP_MAXM][64];                   // topic-presence bitmaps per view
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, M = mm.M;
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < mm.D; d += wstride) {
+        int len[MVHDP_MAXM];
+        for (int m = 0; m < M; m++) {
+            bm[wave][m][lane] = 0;
+            len[m] = (int)(mm.doc_off[m][d + 1] - mm.doc_off[m][d]);
+        }
+        LDS_FENCE();
+        for (int m = 0; m < M; m++) {
+            const int64_t b = mm.doc_off[m][d];
+            for (int i = lane; i < len[m]; i += WAVE) {
+                int zz = mm.z[m][b + i];
+                if (zz >= 0) atomicOr(&bm[wave][m][zz >> 5], 1u << (zz & 31));   // localTopicCounts[m][z] > 0
+            }
+        }
+        LDS_FENCE();
+        // TreeMap put / descending iteration, on every lane alike
+        int keys[MVHDP_MAXM], vals[MVHDP_MAXM], nkeys = 0;
+        for (int m = 0; m < M; m++) {
+            int found = -1;
+            for (int q = 0; q < nkeys; q++) if (keys[q] == len[m]) found = q;
+            if (found >= 0) vals[found] = m; else { keys[nkeys] = len[m]; vals[nkeys] = m; nkeys++; }
+        }
+        for (int a = 0; a < nkeys; a++) for (int b2 = a + 1; b2 < nkeys; b2++)
+            if (keys[b2] > keys[a]) { int t = keys[a]; keys[a] = keys[b2]; keys[b2] = t; t = vals[a]; vals[a] = vals[b2]; vals[b2] = t; }
+        for (int i = lane; i < M * M; i += WAVE) out[(int64_t)i * mm.D + d] = 0.0;
+        for (int q = 1; q < nkeys; q++) {                               // PTM:2751
+            const int m = vals[q];
+            if (len[m] <= 0) continue;                                    // Assignments[m] == null
+            const int64_t b = mm.doc_off[m][d];
+            for (int pi = 0; pi < q; pi++) {                              // previousViews (PTM:2769)
+                const int iv = vals[pi];
+                int c = 0;
+                for (int i0 = 0; i0 < len[m]; i0 += WAVE) {
+                    const int i = i0 + lane;
+                    bool hit = false;
+                    if (i < len[m]) { int zz = mm.z[m][b + i]; hit = zz >= 0 && ((bm[wave][iv][zz >> 5] >> (zz & 31)) & 1u); }
+                    c += (int)__popcll(__builtin_amdgcn_ballot_w64(hit));
+                }
+                if (lane == 0) {
+                    // PTM:2771: c additions of 1.0/docLength[m] (the zero additions change nothing)
+                    const double x = 1.0 / (double)len[m];
+                    double acc = 0.0;
+                    for (int r = 0; r < c; r++) acc += x;
+                    out[(int64_t)(m * M + iv) * mm.D + d] = acc;
+                    out[(int64_t)(iv * M + m) * mm.D + d] = acc;          // PTM:2772
+                }
+            }
+        }
+        LDS_FENCE();
+    }
+}
+
+hipError_t mvhdp_launch_view_overlap(const MvModel& mm, double* out, hipStream_t s)
+{
+    if (mm.D <= 0) return hipSuccess;
+    int64_t blocks = (mm.D + 3) / 4;
+    int grid = (int)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(view_overlap_kernel, dim3(grid), dim3(256), 0, s, mm, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// MALLET Dirichlet.logGammaStirling (restated from the 2.0.8 class file)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double log_gamma_stirling(double z)
+{
+    const double HALF_LOG_TWO_PI = 0.91893853320467274178;       // log(6.283185307179586) / 2.0
+    int shift = 0;
+    while (z < 2.0) { z = z + 1; shift++; }
+    double result = HALF_LOG_TWO_PI + (z - 0.5) * log(z) - z + 1 / (12.0 * z) - 1 / (360.0 * z * z * z)
+                    + 1 / (1260.0 * z * z * z * z * z);
+    while (shift > 0) { shift--; z = z - 1; result = result - log(z); }
+    return result;
+}
+
+// document half: out[doc] = sum_k [lgs(gamma*alpha_k + n_dk) - lgs(gamma*alpha_k)] - lgs(gamma*alphaSum + backing length)
+// (0 and not counted when the view is absent); PTM:3347-3370 incl. the backing-array phantom zeros.
+__global__ __launch_bounds__(256) void loglik_doc_kernel(MvModel mm, int m, double* out)
+{
+    extern __shared__ int ldk[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K = mm.K;
+    int* cnt = ldk + wave * K;
+    const double g = mm.gamma[m];
+    const double* al = mm.alpha + (int64_t)m * (K + 1);
+    const int wpb = blockDim.x >> 6;
+    const int64_t wstride = (int64_t)gridDim.x * wpb;
+    for (int64_t d = (int64_t)blockIdx.x * wpb + wave; d < mm.D; d += wstride) {
+        const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+        if (e == b) { if (lane == 0) out[d] = 0.0; continue; }
+        for (int k = lane; k < K; k += WAVE) cnt[k] = 0;
+        LDS_FENCE();
+        for (int64_t i = b + lane; i < e; i += WAVE) { int zz = mm.z[m][i]; atomicAdd(&cnt[zz < 0 ? 0 : zz], 1); }
+        const int backing = (int)(e - b) > 2 ? (int)(e - b) : 2;
+        if (lane == 0 && backing > (int)(e - b)) atomicAdd(&cnt[0], backing - (int)(e - b));
+        LDS_FENCE();
+        double acc = 0.0;
+        for (int k = lane; k < K; k += WAVE) {
+            int c = cnt[k];
+            if (c > 0) acc += log_gamma_stirling(g * al[k] + c) - log_gamma_stirling(g * al[k]);
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, WAVE);
+        if (lane == 0) out[d] = acc - log_gamma_stirling((double)g * mm.alpha_sum[m] + backing);
+        LDS_FENCE();
+    }
+}
+
+// topic-word half: per-block partial sums of lgs(beta + count) over count > 0, and the number of such pairs
+__global__ __launch_bounds__(256) void loglik_topic_kernel(const int32_t* __restrict__ nwk, int64_t n_cells, double beta,
+                                                           double* partial, unsigned long long* nonzero)
+{
+    __shared__ double red[256];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    unsigned int nz = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
+        int c = nwk[i];
+        if (c > 0) { nz++; acc += log_gamma_stirling(beta + c); }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+    if (nz) atomicAdd(nonzero, (unsigned long long)nz);
+}
+
+hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
+                               unsigned long long* nonzero, hipStream_t s)
+{
+    if (mm.D > 0) {
+        int wpb = 4;
+        while (wpb > 1 && (size_t)wpb * mm.K * sizeof(int) > 60000) wpb >>= 1;
+        int64_t blocks = (mm.D + wpb - 1) / wpb;
+        int grid = (int)(blocks < 4096 ? blocks : 4096);
+        hipLaunchKernelGGL(loglik_doc_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * mm.K * sizeof(int), s, mm, m, doc_out);
+    }
+    hipError_t e = hipMemsetAsync(nonzero, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    int64_t n = (int64_t)mm.V[m] * mm.K;
+    hipLaunchKernelGGL(loglik_topic_kernel, dim3(n_partial), dim3(256), 0, s, mm.counts + mm.rowbase[m] * mm.K, n,
+                       mm.beta[m], partial, nonzero);
+    return hipGetLastError();
+}

@@ -188,6 +188,22 @@ class NativeSampler:
         self._ck(self.L.mvhdp_get_doc_topic_hist(self.h, m, _ptr(hist), hist_len, _ptr(dl), len_len))
         return hist, (dl[:len_len] if dl is not None else None)
 
+    # -- statistics either side of the sweep ------------------------
+    def get_count_histogram(self, m, length):
+        h = np.zeros(length, dtype=np.int32)
+        self._ck(self.L.mvhdp_get_count_histogram(self.h, m, _ptr(h), length))
+        return h
+
+    def view_overlap_sums(self):
+        s = np.zeros((self.M, self.M), dtype=np.float64)
+        self._ck(self.L.mvhdp_view_overlap_sums(self.h, _ptr(s)))
+        return s
+
+    def model_log_likelihood(self):
+        ll = np.zeros(self.M, dtype=np.float64)
+        self._ck(self.L.mvhdp_model_log_likelihood(self.h, _ptr(ll)))
+        return ll
+
     # -- the hot path ---------------------------------------------------------
     def sweep(self, sweep_idx, seed, flags=0, p=None, want_dbg=False, trace=None) -> SweepStats:
         st = SweepStatsC()

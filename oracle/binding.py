@@ -88,6 +88,14 @@ def lib():
     L.orc_sweep.argtypes = [vp, u32, u64, i64, vp, u32, P(Stats), vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.orc_sweep.restype = C.c_int
     L.orc_apply_delta.argtypes = [vp, vp, vp, i32, i32]
+    L.orc_log_gamma_stirling.argtypes = [dbl]; L.orc_log_gamma_stirling.restype = dbl
+    L.orc_mallet_digamma.argtypes = [dbl]; L.orc_mallet_digamma.restype = dbl
+    L.orc_learn_symmetric_concentration.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, dbl]
+    L.orc_learn_symmetric_concentration.restype = dbl
+    L.orc_count_histogram.argtypes = [vp, C.c_int, vp, i32]
+    L.orc_optimize_beta.argtypes = [vp, C.c_int, C.c_int, P(dbl)]; L.orc_optimize_beta.restype = dbl
+    L.orc_optimize_p_sums.argtypes = [vp, vp]
+    L.orc_model_log_likelihood.argtypes = [vp, vp]
     L.orc_threaded_estimate.argtypes = [vp, C.c_int, C.c_int, u64, P(Stats)]
     L.orc_threaded_estimate.restype = dbl
     _lib = L
@@ -244,6 +252,26 @@ class Oracle:
         dn = np.ascontiguousarray(dn, dtype=np.int32)
         dk = np.ascontiguousarray(dk, dtype=np.int32)
         self.L.orc_apply_delta(self.h, _ptr(dn), _ptr(dk), int(act_topic), int(act_modality))
+
+    def count_histogram(self, m, length):
+        h = np.zeros(length, dtype=np.int32)
+        self.L.orc_count_histogram(self.h, m, _ptr(h), length)
+        return h
+
+    def optimize_beta(self, m, max_type_count):
+        bs = C.c_double()
+        b = self.L.orc_optimize_beta(self.h, m, int(max_type_count), C.byref(bs))
+        return b, bs.value
+
+    def optimize_p_sums(self):
+        s = np.zeros((self.M, self.M), dtype=np.float64)
+        self.L.orc_optimize_p_sums(self.h, _ptr(s))
+        return s
+
+    def model_log_likelihood(self):
+        ll = np.zeros(self.M, dtype=np.float64)
+        self.L.orc_model_log_likelihood(self.h, _ptr(ll))
+        return ll
 
     def threaded_estimate(self, num_threads, iters, seed):
         st = Stats()

@@ -780,3 +780,223 @@ void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delt
         o->alpha[(size_t)act_modality * (K + 1) + act_topic] = o->alpha[(size_t)act_modality * (K + 1) + K];
     }
 }
+
+/* ======================================================================== */
+/* SURVEY §8f "next" rows: hyper-parameter statistics and the log likelihood */
+/* ======================================================================== */
+
+/* MALLET 2.0.8 Dirichlet.logGammaStirling (class file only; arithmetic read from the jar's bytecode
+ * with oracle/tools/javap_lite.py): shift z up to >= 2, Stirling series, subtract the logs back. */
+double orc_log_gamma_stirling(double z)
+{
+    static const double HALF_LOG_TWO_PI_UNUSED = 0; (void)HALF_LOG_TWO_PI_UNUSED;
+    const double HALF_LOG_TWO_PI = log(6.283185307179586) / 2.0;   /* Dirichlet.<clinit> */
+    int shift = 0;
+    while (z < 2.0) { z = z + 1; shift++; }
+    double result = HALF_LOG_TWO_PI + (z - 0.5) * log(z) - z + 1 / (12.0 * z) - 1 / (360.0 * z * z * z)
+                    + 1 / (1260.0 * z * z * z * z * z);
+    while (shift > 0) { shift--; z = z - 1; result = result - log(z); }
+    return result;
+}
+
+/* MALLET 2.0.8 Dirichlet.digamma as compiled: DIGAMMA_COEF_1..7 are written as integer quotients
+ * (1/12, 1/120, ...) in that release and are therefore all 0 in the class file, so the series
+ * reduces to log(z) - 0.5/z (the nested products are kept: they only produce signed zeros). */
+double orc_mallet_digamma(double z)
+{
+    double psi = 0;
+    if (z < 1e-06) { psi = -0.5772156649015329 - 1 / z; return psi; }
+    while (z < 9.5) { psi = psi - 1 / z; z = z + 1; }
+    double invZ = 1 / z;
+    double invZSquared = invZ * invZ;
+    psi = psi + (log(z) - 0.5 * invZ
+          - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * 0.0)))))));
+    return psi;
+}
+
+/* MALLET 2.0.8 Dirichlet.learnSymmetricConcentration(countHistogram, observationLengths, numDimensions,
+ * currentValue), from the bytecode.  Kept quirks: previousLength is never advanced, and for lengths
+ * <= 20 currentDigamma keeps accumulating across lengths. */
+double orc_learn_symmetric_concentration(const int32_t* countHistogram, int n_count, const int32_t* observationLengths, int n_len,
+                                         int numDimensions, double currentValue)
+{
+    double currentDigamma;
+    int largestNonZeroCount = 0;
+    int* nonZeroLengthIndex = (int*)malloc((size_t)(n_len > 0 ? n_len : 1) * sizeof(int));
+    for (int index = 0; index < n_count; index++) if (countHistogram[index] > 0) largestNonZeroCount = index;
+    int denseIndex = 0;
+    for (int index = 0; index < n_len; index++)
+        if (observationLengths[index] > 0) { nonZeroLengthIndex[denseIndex] = index; denseIndex++; }
+    int denseIndexSize = denseIndex;
+    for (int iteration = 1; iteration <= 200; iteration++) {
+        double currentParameter = currentValue / numDimensions;
+        currentDigamma = 0;
+        double numerator = 0;
+        for (int index = 1; index <= largestNonZeroCount; index++) {
+            currentDigamma += 1.0 / (currentParameter + index - 1);
+            numerator += countHistogram[index] * currentDigamma;
+        }
+        currentDigamma = 0;
+        double denominator = 0;
+        int previousLength = 0;
+        double cachedDigamma = orc_mallet_digamma(currentValue);
+        for (denseIndex = 0; denseIndex < denseIndexSize; denseIndex++) {
+            int length = nonZeroLengthIndex[denseIndex];
+            if (length - previousLength > 20) {
+                currentDigamma = orc_mallet_digamma(currentValue + length) - cachedDigamma;
+            } else {
+                for (int index = previousLength; index < length; index++) currentDigamma += 1.0 / (currentValue + index);
+            }
+            denominator += currentDigamma * observationLengths[length];
+        }
+        currentValue = currentParameter * numerator / denominator;
+    }
+    free(nonZeroLengthIndex);
+    return currentValue;
+}
+
+/* countHistogram of optimizeBeta (PTM:2295-2309): number of (type, topic) pairs holding each count > 0 */
+void orc_count_histogram(const orc_model* o, int m, int32_t* hist, int32_t len)
+{
+    const int K = o->K;
+    memset(hist, 0, (size_t)len * sizeof(int32_t));
+    for (int type = 0; type < o->V[m]; type++) {
+        const int32_t* counts = o->nwk + (size_t)(o->rowbase[m] + type) * K;
+        for (int topic = 0; topic < K; topic++) {
+            int count = counts[topic];
+            if (count > 0 && count < len) hist[count]++;
+        }
+    }
+}
+
+/* optimizeBeta for one view (PTM:2293-2366) given maxTypeCount; returns the new beta, writes betaSum.
+ * The catch (RuntimeException) arm cannot trigger in C; NaN handling is the reference's. */
+double orc_optimize_beta(orc_model* o, int m, int maxTypeCount, double* betaSum_out)
+{
+    const int K = o->K;
+    double prevBetaSum = o->beta_sum[m];
+    int32_t* countHistogram = (int32_t*)calloc((size_t)maxTypeCount + 1, sizeof(int32_t));
+    orc_count_histogram(o, m, countHistogram, maxTypeCount + 1);
+    int maxTopicSize = 0;
+    for (int topic = 0; topic < K; topic++) if (o->nk[(size_t)m * K + topic] > maxTopicSize) maxTopicSize = o->nk[(size_t)m * K + topic];
+    int32_t* topicSizeHistogram = (int32_t*)calloc((size_t)maxTopicSize + 1, sizeof(int32_t));
+    for (int topic = 0; topic < K; topic++) topicSizeHistogram[o->nk[(size_t)m * K + topic]]++;
+    double betaSum = orc_learn_symmetric_concentration(countHistogram, maxTypeCount + 1, topicSizeHistogram, maxTopicSize + 1,
+                                                       o->V[m], o->beta_sum[m]);
+    double beta = o->beta[m];
+    if (betaSum < o->V[m] * 0.0001) {                       /* PTM:2332-2335 */
+        beta = 0.0001; betaSum = beta * o->V[m];
+    } else if (isnan(betaSum)) {                            /* PTM:2337-2349 */
+        if (o->beta[m] == 0.01) { beta = 0.0001; betaSum = beta * o->V[m]; }
+        else { betaSum = prevBetaSum; beta = betaSum / o->V[m]; }
+    } else {
+        beta = betaSum / o->V[m];                           /* PTM:2351 */
+    }
+    free(countHistogram); free(topicSizeHistogram);
+    *betaSum_out = betaSum;
+    return beta;
+}
+
+/* optimizeP statistics (PTM:2706-2782): for every ordered pair the sum over entities of
+ * pDistr_Mean[m][i][doc], accumulated in entity order exactly as PTM:2789-2792 does afterwards.
+ * sums: [M][M].  The TreeMap keyed by view length (PTM:2717,2741) drops views of equal length. */
+void orc_optimize_p_sums(const orc_model* o, double* sums)
+{
+    const int K = o->K, M = o->M;
+    double* pd = (double*)calloc((size_t)M * M, sizeof(double));      /* pDistr_Mean[.][.][doc] of the current entity */
+    int32_t* localTopicCounts = (int32_t*)malloc((size_t)M * K * sizeof(int32_t));
+    for (int i = 0; i < M * M; i++) sums[i] = 0;
+    for (int64_t doc = 0; doc < o->D; doc++) {
+        int docLength[ORC_MAX_M];
+        memset(localTopicCounts, 0, (size_t)M * K * sizeof(int32_t));
+        memset(pd, 0, (size_t)M * M * sizeof(double));
+        /* TreeMap<Integer,Byte>: key = length, later views overwrite equal keys */
+        int keys[ORC_MAX_M], vals[ORC_MAX_M], nkeys = 0;
+        for (int m = 0; m < M; m++) {
+            int64_t b = o->doc_off[m][doc], e = o->doc_off[m][doc + 1];
+            docLength[m] = (int)(e - b);
+            for (int64_t t = b; t < e; t++) if (o->z[m][t] != -1) localTopicCounts[(size_t)m * K + o->z[m][t]]++;
+            int found = -1;
+            for (int q = 0; q < nkeys; q++) if (keys[q] == docLength[m]) found = q;
+            if (found >= 0) vals[found] = m; else { keys[nkeys] = docLength[m]; vals[nkeys] = m; nkeys++; }
+        }
+        /* descending by key */
+        for (int a = 0; a < nkeys; a++) for (int b2 = a + 1; b2 < nkeys; b2++)
+            if (keys[b2] > keys[a]) { int t = keys[a]; keys[a] = keys[b2]; keys[b2] = t; t = vals[a]; vals[a] = vals[b2]; vals[b2] = t; }
+        int previousViews[ORC_MAX_M], nprev = 0;
+        previousViews[nprev++] = vals[0];                                 /* PTM:2747 */
+        for (int q = 1; q < nkeys; q++) {                                 /* PTM:2751-2780 */
+            int m = vals[q];
+            if (docLength[m] > 0) {                                       /* Assignments[m] != null */
+                int64_t b = o->doc_off[m][doc];
+                for (int position = 0; position < docLength[m]; position++) {
+                    int zt = o->z[m][b + position];
+                    if (zt == -1) continue;
+                    for (int pi = 0; pi < nprev; pi++) {
+                        int i = previousViews[pi];
+                        pd[m * M + i] += (localTopicCounts[(size_t)i * K + zt] > 0 ? 1.0 : 0.0) / (double)docLength[m];
+                        pd[i * M + m] = pd[m * M + i];
+                    }
+                }
+            }
+            previousViews[nprev++] = m;
+        }
+        for (int i = 0; i < M * M; i++) sums[i] += pd[i];                 /* PTM:2790-2792, entity order */
+    }
+    free(pd); free(localTopicCounts);
+}
+
+/* modelLogLikelihood (PTM:3322-3452) per view.  docTopics.length is the LabelSequence backing array,
+ * max(len, 2) (MALLET FeatureSequence allocates at least 2): entities of length 0/1 with the view
+ * present count phantom tokens of topic 0.  A view is "present" when its span is
+ * non-empty (CSR cannot express present-but-empty), so only the length-1 phantom survives here. */
+void orc_model_log_likelihood(const orc_model* o, double* logLikelihood)
+{
+    const int K = o->K, M = o->M;
+    int32_t* topicCounts = (int32_t*)calloc((size_t)K, sizeof(int32_t));
+    double* topicLogGammas = (double*)malloc((size_t)K * sizeof(double));
+    for (int m = 0; m < M; m++) {
+        double ll = 0;
+        const double* al = o->alpha + (size_t)m * (K + 1);
+        for (int topic = 0; topic < K; topic++) topicLogGammas[topic] = orc_log_gamma_stirling(o->gamma[m] * al[topic]);
+        int modalityCnt = 0;
+        for (int64_t doc = 0; doc < o->D; doc++) {
+            int64_t b = o->doc_off[m][doc], e = o->doc_off[m][doc + 1];
+            if (e == b) continue;                                          /* Assignments[m] == null */
+            int backing = (int)(e - b) > 2 ? (int)(e - b) : 2;
+            for (int64_t t = b; t < e; t++) topicCounts[o->z[m][t] < 0 ? 0 : o->z[m][t]]++;
+            for (int t = (int)(e - b); t < backing; t++) topicCounts[0]++;  /* phantom zeros of the backing array */
+            for (int topic = 0; topic < K; topic++)
+                if (topicCounts[topic] > 0)
+                    ll += (orc_log_gamma_stirling(o->gamma[m] * al[topic] + topicCounts[topic]) - topicLogGammas[topic]);
+            ll -= orc_log_gamma_stirling((double)o->gamma[m] * o->alpha_sum[m] + backing);
+            modalityCnt++;
+            memset(topicCounts, 0, (size_t)K * sizeof(int32_t));
+        }
+        ll += modalityCnt * orc_log_gamma_stirling((double)o->gamma[m] * o->alpha_sum[m]);
+        if (isnan(ll) || isinf(ll)) { logLikelihood[m] = 0; continue; }
+        int nonZeroTypeTopics = 0;
+        int broke = 0;
+        for (int type = 0; type < o->V[m] && !broke; type++) {
+            const int32_t* cnt = o->nwk + (size_t)(o->rowbase[m] + type) * K;
+            for (int index = 0; index < K; index++) {
+                int count = cnt[index];
+                if (count > 0) {
+                    nonZeroTypeTopics++;
+                    ll += (o->beta[m] + count) == 0 ? 0 : orc_log_gamma_stirling(o->beta[m] + count);
+                    if (isnan(ll) || isinf(ll)) { ll = 0; break; }         /* PTM:3402-3410 breaks the inner loop only */
+                }
+            }
+        }
+        for (int topic = 0; topic < K; topic++) {
+            int nk = o->nk[(size_t)m * K + topic];
+            ll -= (o->beta[m] * o->V[m] + nk) == 0 ? 0 : orc_log_gamma_stirling((o->beta[m] * o->V[m]) + nk);
+            if (isnan(ll) || isinf(ll)) ll = 0;
+        }
+        ll += (o->beta[m] * o->V[m]) == 0 ? 0 : orc_log_gamma_stirling(o->beta[m] * o->V[m]) * K;
+        ll -= o->beta[m] == 0 ? 0 : orc_log_gamma_stirling(o->beta[m]) * nonZeroTypeTopics;
+        if (isinf(ll)) ll = 0;
+        logLikelihood[m] = ll;
+    }
+    free(topicCounts); free(topicLogGammas);
+}

@@ -138,6 +138,16 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
 void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk,
                      int32_t act_topic, int32_t act_modality);
 
+/* ---------------- SURVEY §8f next rows ---------------- */
+double orc_log_gamma_stirling(double z);                      /* MALLET Dirichlet.logGammaStirling, used by PTM:3343-3441 */
+double orc_mallet_digamma(double z);                          /* MALLET Dirichlet.digamma as compiled in 2.0.8 */
+double orc_learn_symmetric_concentration(const int32_t* countHistogram, int n_count, const int32_t* observationLengths,
+                                         int n_len, int numDimensions, double currentValue);   /* PTM:2327 */
+void   orc_count_histogram(const orc_model* o, int m, int32_t* hist, int32_t len);             /* PTM:2295-2309 */
+double orc_optimize_beta(orc_model* o, int m, int maxTypeCount, double* betaSum_out);          /* PTM:2293-2366 */
+void   orc_optimize_p_sums(const orc_model* o, double* sums /*[M][M]*/);                        /* PTM:2706-2792 */
+void   orc_model_log_likelihood(const orc_model* o, double* logLikelihood /*[M]*/);            /* PTM:3322-3452 */
+
 /* ---------------- CPU baseline: the reference's thread topology ---------------- */
 /* T threads -> nst = 3T/4 samplers over contiguous doc slices, nut = T/4
  * updaters over type%nut stripes, nst*nut unbounded queues, live (racy) reads,

@@ -1,0 +1,102 @@
+"""SURVEY §8f "next" rows: the statistics the host's optimizeBeta / optimizeP read, and modelLogLikelihood."""
+import math
+
+import numpy as np
+import pytest
+
+from mvtopicmodel_amd.native import Hyper
+from tests.helpers import make_native, make_oracle, small_corpus
+
+
+# ------------------------------ CPU: oracle pins ------------------------------
+def test_log_gamma_stirling_tracks_lgamma(oracle_lib):
+    for z in (1e-4, 0.01, 0.1, 0.5, 1.0, 1.9999, 2.0, 3.7, 40.25, 1e3, 1e6):
+        got = oracle_lib.orc_log_gamma_stirling(z)
+        assert abs(got - math.lgamma(z)) < 1e-5 * max(1.0, abs(math.lgamma(z))), z    # truncation error 1/(1680 z^7) <= 4.7e-6 at z=2
+    # logGammaStirling(1) = shift once: stirling(2) - log(1)
+    z = 2.0
+    st2 = math.log(6.283185307179586) / 2.0 + (z - 0.5) * math.log(z) - z + 1 / (12.0 * z) - 1 / (360.0 * z * z * z) + 1 / (1260.0 * z ** 5)
+    assert oracle_lib.orc_log_gamma_stirling(1.0) == st2 - math.log(1.0)
+
+
+def test_mallet_digamma_as_compiled(oracle_lib):
+    # the 2.0.8 class file has the series coefficients as integer quotients (= 0): psi(z) = log z - 1/(2z) for z >= 9.5
+    assert oracle_lib.orc_mallet_digamma(50.0) == math.log(50.0) - 0.5 * (1 / 50.0)
+    z, psi = 3.0, 0.0
+    while z < 9.5:
+        psi -= 1 / z; z += 1
+    assert oracle_lib.orc_mallet_digamma(3.0) == psi + (math.log(z) - 0.5 * (1 / z))
+    assert oracle_lib.orc_mallet_digamma(1e-7) == -0.5772156649015329 - 1 / 1e-7
+
+
+def test_learn_symmetric_concentration_fixed_point(oracle_lib):
+    """Known structure: observations drawn from a symmetric Dirichlet-multinomial; the estimate must
+    move from the starting value towards a finite positive concentration and be reproducible."""
+    rng = np.random.RandomState(0)
+    V, K = 200, 30
+    p = rng.dirichlet(np.full(V, 0.05), K)
+    counts = np.stack([rng.multinomial(400, p[k]) for k in range(K)])      # [K][V]
+    ch = np.bincount(counts[counts > 0], minlength=counts.max() + 1).astype(np.int32); ch[0] = 0
+    lens = np.bincount(counts.sum(axis=1)).astype(np.int32)
+    a = oracle_lib.orc_learn_symmetric_concentration(ch.ctypes.data, len(ch), lens.ctypes.data, len(lens), V, 0.01 * V)
+    b = oracle_lib.orc_learn_symmetric_concentration(ch.ctypes.data, len(ch), lens.ctypes.data, len(lens), V, 0.01 * V)
+    assert a == b and 0.5 < a < 100          # true concentration 0.05*200 = 10; MALLET's biased digamma lands in the right decade
+    assert abs(a - 10) < 6
+
+
+def test_optimize_p_sums_hand_case():
+    """Two views; entity 0: view1 shorter, 2 of its 3 tokens share a topic with view 0 -> 2/3; entity 1: equal lengths,
+    the TreeMap keeps only the later view -> no statistic; entity 2: view 1 absent."""
+    from oracle.binding import Oracle
+    K, V = 6, [10, 10]
+    off0 = np.array([0, 4, 6, 9], dtype=np.int64); off1 = np.array([0, 3, 5, 5], dtype=np.int64)
+    o = Oracle(K, V)
+    o.set_corpus(0, off0, np.zeros(9, dtype=np.int32)); o.set_corpus(1, off1, np.zeros(5, dtype=np.int32))
+    o.set_assignments(0, np.array([1, 1, 2, 3, 0, 0, 4, 4, 5], dtype=np.int32))
+    o.set_assignments(1, np.array([1, 5, 3, 0, 0], dtype=np.int32))
+    s = o.optimize_p_sums()
+    x = 1.0 / 3.0
+    assert s[1, 0] == s[0, 1] == (0.0 + x) + x
+    assert s[0, 0] == 0 and s[1, 1] == 0
+
+
+# ------------------------------ GPU: parity ------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,V,D,lam", [(20, [300, 40, 50], 90, [30, 4, 6]), (100, [900], 60, [70]), (400, [3000, 300], 50, [120, 8])])
+def test_statistics_and_log_likelihood_match_oracle(K, V, D, lam):
+    c = small_corpus(K, V, D, lam, 500 + K)
+    hy = Hyper.defaults(K, V)
+    hy.alpha[:] = np.linspace(0.02, 0.3, K + 1)[None, :]
+    hy.alpha_sum[:] = hy.alpha[:, :K].sum(axis=1)
+    hy.gamma[:] = np.linspace(0.8, 1.3, c.M)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    for it in range(3):
+        # optimizeBeta's countHistogram: exact integers
+        for m in range(c.M):
+            mx = int(max(o.get_counts(m)[0].max(), 1))
+            assert np.array_equal(o.count_histogram(m, mx + 1), s.get_count_histogram(m, mx + 1))
+        # optimizeP's per-pair sums: same per-entity arithmetic, summed in entity order -> bit-identical
+        assert np.array_equal(o.optimize_p_sums(), s.view_overlap_sums())
+        # modelLogLikelihood: device log() and a different summation order -> relative 1e-12
+        lo, ls = o.model_log_likelihood(), s.model_log_likelihood()
+        assert np.all(np.isfinite(ls)) and np.all(ls < 0)
+        assert np.allclose(lo, ls, rtol=1e-12, atol=0), (lo, ls)
+        o.sweep(it, 31); s.sweep(it, 31)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_log_likelihood_rises_over_sweeps():
+    """The only convergence signal the reference logs (PTM:1302-1304): LL/token must improve from the random start."""
+    K, V = 50, [2000, 200]
+    c = small_corpus(K, V, 400, [80, 8], 77)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    ll0 = s.model_log_likelihood()
+    for it in range(15):
+        s.sweep(it, 5)
+    ll1 = s.model_log_likelihood()
+    assert np.all(ll1 > ll0)
+    s.close()
