@@ -31,6 +31,11 @@ int64_t mvtm_model_view_tokens(void* model, int m);
 int   mvtm_model_get_view(void* model, int m, int64_t* entity_ids, int64_t* off, int32_t* tokens, int32_t* topics);
 int   mvtm_model_get_counts(void* model, int m, int32_t* typeTopicCounts, int32_t* tokensPerTopic);
 int   mvtm_model_get_log(void* model, int i, double* ms, mvhdp_sweep_stats* st);
+/* optimizeP PTM:2698-2819, optimizeBeta PTM:2288-2367, modelLogLikelihood PTM:3322-3452 */
+int   mvtm_model_optimize_p(void* model, double* p_a_out /*[M][M]*/, double* pMean_out /*[M][M]*/);
+int   mvtm_model_optimize_beta(void* model, double* beta_out /*[M]*/, double* betaSum_out /*[M]*/);
+int   mvtm_model_log_likelihood(void* model, double* ll_out /*[M]*/);
+int   mvtm_model_get_perplexities(void* model, int m, double* out, int cap);
 void* mvtm_model_native_handle(void* model);
 /* PTM:465-515 on CSR arrays: initial topic draw order of addInstances with java.util.Random(seed) */
 int   mvtm_init_assignments(int K, int M, int64_t D, const int64_t* const* doc_off, int64_t seed, int32_t* const* z_out);

@@ -218,6 +218,111 @@ void FastQMVWVParallelTopicModel::syncFromDevice(bool histograms)
     for (int k = 0; k < K; k++) if (ina[k]) inActiveTopicIndex.insert(k);
 }
 
+// ---- MALLET 2.0.8 Dirichlet.digamma as compiled: the series coefficients are integer quotients (= 0) ----
+double FastQMVWVParallelTopicModel::digamma(double z)
+{
+    double psi = 0;
+    if (z < 1e-06) { psi = -0.5772156649015329 - 1 / z; return psi; }
+    while (z < 9.5) { psi = psi - 1 / z; z = z + 1; }
+    double invZ = 1 / z;
+    double invZSquared = invZ * invZ;
+    psi = psi + (std::log(z) - 0.5 * invZ
+          - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * (0.0 - invZSquared * 0.0)))))));
+    return psi;
+}
+
+// ---- MALLET 2.0.8 Dirichlet.learnSymmetricConcentration (quirks kept: previousLength never advances) ----
+double FastQMVWVParallelTopicModel::learnSymmetricConcentration(const std::vector<int32_t>& countHistogram,
+                                                                const std::vector<int32_t>& observationLengths,
+                                                                int numDimensions, double currentValue)
+{
+    double currentDigamma;
+    int largestNonZeroCount = 0;
+    std::vector<int> nonZeroLengthIndex(observationLengths.size());
+    for (size_t index = 0; index < countHistogram.size(); index++) if (countHistogram[index] > 0) largestNonZeroCount = (int)index;
+    int denseIndex = 0;
+    for (size_t index = 0; index < observationLengths.size(); index++)
+        if (observationLengths[index] > 0) { nonZeroLengthIndex[denseIndex] = (int)index; denseIndex++; }
+    int denseIndexSize = denseIndex;
+    for (int iteration = 1; iteration <= 200; iteration++) {
+        double currentParameter = currentValue / numDimensions;
+        currentDigamma = 0;
+        double numerator = 0;
+        for (int index = 1; index <= largestNonZeroCount; index++) {
+            currentDigamma += 1.0 / (currentParameter + index - 1);
+            numerator += countHistogram[index] * currentDigamma;
+        }
+        currentDigamma = 0;
+        double denominator = 0;
+        int previousLength = 0;
+        double cachedDigamma = digamma(currentValue);
+        for (denseIndex = 0; denseIndex < denseIndexSize; denseIndex++) {
+            int length = nonZeroLengthIndex[denseIndex];
+            if (length - previousLength > 20) currentDigamma = digamma(currentValue + length) - cachedDigamma;
+            else for (int index = previousLength; index < length; index++) currentDigamma += 1.0 / (currentValue + index);
+            denominator += currentDigamma * observationLengths[length];
+        }
+        currentValue = currentParameter * numerator / denominator;
+    }
+    return currentValue;
+}
+
+void FastQMVWVParallelTopicModel::optimizeP(bool appendMetadata)
+{
+    (void)appendMetadata;
+    const int M = numModalities;
+    std::vector<double> sums((size_t)M * M, 0.0);
+    check(mvhdp_view_overlap_sums(h_, sums.data()), "mvhdp_view_overlap_sums");      // PTM:2706-2782 on the device
+    pMean.assign(M, std::vector<double>(M, 0.0));
+    for (int m = 0; m < M; m++) {                                                    // PTM:2784-2812
+        pMean[m][m] = 1;
+        for (int i = m + 1; i < M; i++) {
+            double sum = sums[(size_t)m * M + i];
+            pMean[m][i] = sum / (std::min(totalDocsPerModality[m], totalDocsPerModality[i]));
+            pMean[i][m] = pMean[m][i];
+            double a = pMean[m][i] == 1 ? 5000 : -1.0 / std::log(pMean[m][i]);
+            double b = 1;
+            p_a[m][i] = std::min(a, 100.0);
+            p_a[i][m] = std::min(a, 100.0);
+            p_b[m][i] = b;
+            p_b[i][m] = b;
+        }
+    }
+}
+
+void FastQMVWVParallelTopicModel::optimizeBeta()
+{
+    const int M = numModalities, K = numTopics;
+    for (int m = 0; m < M; m++) {                                                    // PTM:2293
+        double prevBetaSum = betaSum[m];
+        std::vector<int32_t> countHistogram((size_t)maxTypeCount[m] + 1, 0);
+        check(mvhdp_get_count_histogram(h_, m, countHistogram.data(), maxTypeCount[m] + 1), "mvhdp_get_count_histogram");  // PTM:2299-2309
+        std::vector<int32_t> nk((size_t)K);
+        check(mvhdp_get_counts(h_, m, nullptr, nk.data()), "mvhdp_get_counts");
+        int maxTopicSize = 0;
+        for (int topic = 0; topic < K; topic++) maxTopicSize = std::max(maxTopicSize, nk[topic]);
+        std::vector<int32_t> topicSizeHistogram((size_t)maxTopicSize + 1, 0);
+        for (int topic = 0; topic < K; topic++) topicSizeHistogram[nk[topic]]++;
+        betaSum[m] = learnSymmetricConcentration(countHistogram, topicSizeHistogram, numTypes[m], betaSum[m]);   // PTM:2327
+        if (betaSum[m] < numTypes[m] * 0.0001) {                                     // PTM:2332-2335
+            beta[m] = 0.0001;
+            betaSum[m] = beta[m] * numTypes[m];
+        } else if (std::isnan(betaSum[m])) {                                         // PTM:2337-2349
+            if (beta[m] == 0.01) { beta[m] = 0.0001; betaSum[m] = beta[m] * numTypes[m]; }
+            else { betaSum[m] = prevBetaSum; beta[m] = betaSum[m] / numTypes[m]; }
+        } else {
+            beta[m] = betaSum[m] / numTypes[m];                                      // PTM:2351
+        }
+    }
+}
+
+std::vector<double> FastQMVWVParallelTopicModel::modelLogLikelihood()
+{
+    std::vector<double> ll((size_t)numModalities, 0.0);
+    check(mvhdp_model_log_likelihood(h_, ll.data()), "mvhdp_model_log_likelihood");
+    return ll;
+}
+
 void FastQMVWVParallelTopicModel::estimate()
 {
     if (!h_) throw std::runtime_error("estimate() before addInstances()");
@@ -235,15 +340,26 @@ void FastQMVWVParallelTopicModel::estimate()
             double v = std::min((double)iteration / 100 + 0.3, 1.1);
             for (int i = 0; i < M; i++) std::fill(p_a[i].begin(), p_a[i].end(), v);
         } else if (iteration > burninPeriod && optimizeInterval != 0 && iteration % optimizeInterval == 0) {
-            // PTM:1173-1210 optimizeP/optimizeDP/optimizeGamma/optimizeBeta + buildFTrees(false):
-            // SURVEY §8f next #1, not part of this build.  The trees are rebuilt from the
-            // counts at the start of every sweep anyway (DESIGN.md "tree freshness").
+            // PTM:1173-1210.  optimizeP and optimizeBeta run (device statistics + the reference's closed forms);
+            // optimizeDP / optimizeGamma (random samplers) are not in this build: alpha and gamma stay as they are.
+            optimizeP(iteration + optimizeInterval > numIterations);                 // PTM:1176
+            if (notes.empty()) notes.push_back("optimizeDP/optimizeGamma skipped (not in this build): alpha, gamma unchanged");
+            optimizeBeta();                                                          // PTM:1186
+            // buildFTrees(false) PTM:1209: mvhdp_sweep rebuilds the trees from the counts and the new hyper-parameters
         }
         pushHyper();
         mvhdp_sweep_stats st;
         check(mvhdp_sweep(h_, (uint32_t)iteration, seed, 0, nullptr, nullptr, &st), "mvhdp_sweep");  // PTM:1213-1239
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         iterationLog.push_back({iteration, ms, st});
+        if (iteration % 10 == 0 && printLogLikelihood) {               // PTM:1296-1304
+            std::vector<double> ll = modelLogLikelihood();
+            if (perplexities.size() != (size_t)M) perplexities.assign(M, std::vector<double>());
+            for (int i = 0; i < M; i++) {
+                if ((int)perplexities[i].size() <= iteration / 10) perplexities[i].resize(iteration / 10 + 1, 0.0);
+                perplexities[i][iteration / 10] = ll[i] / totalTokens[i];
+            }
+        }
         if (st.activated_topic >= 0) {                                // keep the host copy of alpha / inActiveTopicIndex current
             std::vector<double> a((size_t)M * (numTopics + 1));
             std::vector<uint8_t> ina((size_t)numTopics);
@@ -356,6 +472,50 @@ int mvtm_model_get_log(void* p, int i, double* ms, mvhdp_sweep_stats* st)
     if (ms) *ms = model->iterationLog[i].ms;
     if (st) *st = model->iterationLog[i].stats;
     return 0;
+}
+
+int mvtm_model_optimize_p(void* p, double* p_a_out, double* pMean_out)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    try {
+        model->optimizeP(false);
+        const int M = model->numModalities;
+        for (int m = 0; m < M; m++) for (int i = 0; i < M; i++) {
+            if (p_a_out) p_a_out[m * M + i] = model->p_a[m][i];
+            if (pMean_out) pMean_out[m * M + i] = model->pMean[m][i];
+        }
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_model_optimize_beta(void* p, double* beta_out, double* betaSum_out)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    try {
+        model->optimizeBeta();
+        for (int m = 0; m < model->numModalities; m++) { beta_out[m] = model->beta[m]; betaSum_out[m] = model->betaSum[m]; }
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_model_log_likelihood(void* p, double* ll_out)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    try {
+        std::vector<double> ll = model->modelLogLikelihood();
+        for (size_t m = 0; m < ll.size(); m++) ll_out[m] = ll[m];
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+// perplexities[m][iteration/10] (LL/token, PTM:1302-1303); returns the number of entries written per view
+int mvtm_model_get_perplexities(void* p, int m, double* out, int cap)
+{
+    auto* model = (FastQMVWVParallelTopicModel*)p;
+    if (m < 0 || m >= (int)model->perplexities.size()) return 0;
+    int n = std::min<int>(cap, (int)model->perplexities[m].size());
+    for (int i = 0; i < n; i++) out[i] = model->perplexities[m][i];
+    return n;
 }
 
 void* mvtm_model_native_handle(void* p) { return ((FastQMVWVParallelTopicModel*)p)->nativeHandle(); }

@@ -109,6 +109,24 @@ public:
     // refresh typeTopicCounts / tokensPerTopic / topicDocCounts / data[].topics from the device
     void syncFromDevice(bool histograms = true);
 
+    // SURVEY §8f #1/#2 (the steps either side of the sweep).  The statistics come from device kernels;
+    // the closed-form updates are the reference's.
+    void optimizeP(bool appendMetadata = false);               // PTM:2698-2819
+    void optimizeBeta();                                       // PTM:2288-2367
+    std::vector<double> modelLogLikelihood();                  // PTM:3322-3452
+    // optimizeDP PTM:2440-2591 and optimizeGamma PTM:2369-2438 (random table-count / Escobar-West samplers
+    // over knowceans + MALLET Randoms.nextGamma) are not in this build; estimate() keeps alpha and gamma
+    // fixed at those steps and says so in `notes`.
+    std::vector<std::vector<double>> pMean;                     // PTM:134
+    std::vector<std::vector<double>> perplexities;              // PTM:144  [M][iteration/10] = LL/token
+    bool printLogLikelihood = true;                             // PTM:128
+    std::vector<std::string> notes;
+
+    // MALLET 2.0.8 arithmetic used by optimizeBeta (restated from the jar's bytecode, see oracle/tools/javap_lite.py)
+    static double digamma(double z);
+    static double learnSymmetricConcentration(const std::vector<int32_t>& countHistogram, const std::vector<int32_t>& observationLengths,
+                                              int numDimensions, double currentValue);
+
 private:
     void initializeHistograms();          // PTM:849-897
     void pushHyper();

@@ -11,6 +11,7 @@ HOST_SYMBOLS = [
     "mvtm_model_add_instances", "mvtm_model_estimate", "mvtm_model_num_entities",
     "mvtm_model_view_tokens", "mvtm_model_get_view", "mvtm_model_get_counts",
     "mvtm_model_get_log", "mvtm_model_native_handle", "mvtm_init_assignments",
+    "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
 ]
 
 _ready = False
@@ -34,6 +35,10 @@ def _lib():
         L.mvtm_model_get_log.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(SweepStatsC)]
         L.mvtm_model_native_handle.argtypes = [vp]; L.mvtm_model_native_handle.restype = vp
         L.mvtm_init_assignments.argtypes = [i32, i32, i64, vp, i64, vp]
+        L.mvtm_model_optimize_p.argtypes = [vp, vp, vp]
+        L.mvtm_model_optimize_beta.argtypes = [vp, vp, vp]
+        L.mvtm_model_log_likelihood.argtypes = [vp, vp]
+        L.mvtm_model_get_perplexities.argtypes = [vp, i32, vp, i32]
         _ready = True
     return L
 
@@ -125,6 +130,29 @@ class FastQMVWVParallelTopicModel:
         nwk = np.empty((self.V[m], self.K), dtype=np.int32); nk = np.empty(self.K, dtype=np.int32)
         self.L.mvtm_model_get_counts(self.p, m, nwk.ctypes.data, nk.ctypes.data)
         return nwk, nk
+
+    def optimizeP(self):
+        pa = np.zeros((self.M, self.M)); pm = np.zeros((self.M, self.M))
+        if self.L.mvtm_model_optimize_p(self.p, pa.ctypes.data, pm.ctypes.data):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return pa, pm
+
+    def optimizeBeta(self):
+        b = np.zeros(self.M); bs = np.zeros(self.M)
+        if self.L.mvtm_model_optimize_beta(self.p, b.ctypes.data, bs.ctypes.data):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return b, bs
+
+    def modelLogLikelihood(self):
+        ll = np.zeros(self.M)
+        if self.L.mvtm_model_log_likelihood(self.p, ll.ctypes.data):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return ll
+
+    def perplexities(self, m, cap=1024):
+        out = np.zeros(cap)
+        n = self.L.mvtm_model_get_perplexities(self.p, m, out.ctypes.data, cap)
+        return out[:n]
 
     def iteration_log(self):
         out = []

@@ -93,3 +93,68 @@ def test_single_view_is_plain_lda_path():
     assert np.array_equal(ref, nwk) and np.array_equal(nwk.sum(axis=0), nk)
     assert (z != z_init).mean() > 0.3
     model.close()
+
+
+def test_estimate_with_optimize_steps_matches_oracle_schedule():
+    """Past burn-in, every optimizeInterval iterations estimate() runs optimizeP and optimizeBeta
+    (PTM:1173-1210) before the sweep; the same schedule replayed on the oracle gives the same integers."""
+    import math
+    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from oracle.binding import Oracle
+    from mvtopicmodel_amd import synth
+    K, V = 30, [400, 50, 40]
+    c = synth.generate(K, V, 150, [40, 6, 5], seed=321, chunk_docs=4096)
+    training = [(np.arange(c.D, dtype=np.int64), c.doc_off[m], c.tokens[m], V[m]) for m in range(3)]
+    model = FastQMVWVParallelTopicModel(K, 3, 0.1, 0.01)
+    model.setNumIterations(10); model.setBurninPeriod(2); model.setOptimizeInterval(2); model.setRandomSeed(5)
+    model.addInstances(training)
+
+    o = Oracle(K, V)
+    for m in range(3):
+        o.set_corpus(m, c.doc_off[m], c.tokens[m])
+    hy = Hyper.defaults(K, V, p_a=0.2)
+    push = lambda: o.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, None)
+    push()
+    o.init_assignments(5)
+    o.build_counts()
+    present = [c.D] * 3        # every view lists every entity (some with an empty FeatureSequence): totalDocsPerModality PTM:624
+    max_type_count = [int(np.bincount(c.tokens[m], minlength=V[m]).max()) for m in range(3)]
+    ll_at_10 = None
+    for it in range(1, 11):
+        if it < 2:
+            hy.p_a[:] = min(it / 100 + 0.3, 1.1)
+        elif it > 2 and it % 2 == 0:
+            sums = o.optimize_p_sums()                                   # PTM:2784-2812
+            for m in range(3):
+                for i in range(m + 1, 3):
+                    pmean = sums[m, i] / min(present[m], present[i])
+                    a = 5000 if pmean == 1 else -1.0 / math.log(pmean)
+                    hy.p_a[m, i] = hy.p_a[i, m] = min(a, 100.0)
+                    hy.p_b[m, i] = hy.p_b[i, m] = 1.0
+            for m in range(3):                                           # PTM:2293-2366
+                b, bs = o.optimize_beta(m, max_type_count[m])
+                hy.beta[m], hy.beta_sum[m] = b, bs
+        push()
+        o.sweep(it, 5)
+        if it == 10:
+            ll_at_10 = o.model_log_likelihood()
+    model.estimate()
+    for m in range(3):
+        assert np.array_equal(model.get_view(m)[3], o.get_assignments(m)), f"assignments differ in view {m}"
+        a, b = model.get_counts(m)
+        assert np.array_equal(a, o.get_counts(m)[0]) and np.array_equal(b, o.get_counts(m)[1])
+    # beta moved away from its initial value and is what the oracle computed
+    pa, pm = model.optimizeP()
+    bb, bbs = model.optimizeBeta()
+    for m in range(3):
+        ob, obs = o.optimize_beta(m, max_type_count[m])
+        assert bb[m] == ob and bbs[m] == obs
+        assert bb[m] != 0.01
+    sums = o.optimize_p_sums()
+    assert pm[0, 1] == sums[0, 1] / min(present[0], present[1])
+    # LL/token recorded at iteration 10 (PTM:1302-1303)
+    tok = [int(c.doc_off[m][-1]) for m in range(3)]
+    for m in range(3):
+        per = model.perplexities(m)
+        assert len(per) == 2 and abs(per[1] - ll_at_10[m] / tok[m]) < 1e-9 * abs(per[1])
+    model.close()
