@@ -102,6 +102,8 @@ typedef struct {
 #define MVHDP_SWEEP_NO_APPLY    0x2u  /* leave the deltas unapplied (multi-GPU: all-reduce MVHDP_BUF_DELTA, then mvhdp_apply_delta) */
 #define MVHDP_SWEEP_EXACT_CHAIN 0x4u  /* always use the sequential WRK:501-513 sum (test mode for the certified scan) */
 #define MVHDP_SWEEP_GENERIC_KERNEL 0x8u /* force the LDS-resident kernel even when the register-resident one applies (test mode) */
+#define MVHDP_SWEEP_FROZEN      0x10u /* the inferencer's call of the same worker (INF:211-294: nst=1, nut=0): sample against the
+                                         stored trees and counts, queue no deltas (WRK:587), leave the model untouched */
 
 /* device buffers a host may hand to a collective (RCCL through torch.distributed or directly) */
 typedef enum {
@@ -128,6 +130,9 @@ int mvhdp_set_hyper(mvhdp_handle h, const mvhdp_hyper* hy);
 int mvhdp_get_alpha(mvhdp_handle h, double* alpha /*[M][K+1]*/, uint8_t* inactive /*[K]*/); /* after a topic activation UPD:263-270 */
 int mvhdp_build_counts(mvhdp_handle h);                          /* buildInitialTypeTopicCounts PTM:600-652 */
 int mvhdp_build_trees(mvhdp_handle h);                           /* buildFTrees PTM:2660-2696 */
+int mvhdp_build_inference_trees(mvhdp_handle h);                 /* FastQMVWVTopicInferencer.initInferencer INF:557-586: leaves p_wt, no gamma*alpha */
+/* INF:169-199: z = trees[m][type].sample(u) for in-vocabulary tokens, 0 otherwise; u from the token stream with sweep 0xFFFFFFFF */
+int mvhdp_init_assignments_from_trees(mvhdp_handle h, uint64_t seed);
 int mvhdp_get_counts(mvhdp_handle h, int32_t m, int32_t* n_wk /*[V_m][K] or NULL*/, int32_t* n_k /*[K] or NULL*/);
 int mvhdp_set_counts(mvhdp_handle h, int32_t m, const int32_t* n_wk, const int32_t* n_k);
 int mvhdp_get_tree(mvhdp_handle h, int32_t m, int32_t type, double* tree /*[2K], FTree.tree FT:21*/);

@@ -12,6 +12,7 @@ ABI_SYMBOLS = [
     "mvhdp_create", "mvhdp_destroy", "mvhdp_last_error", "mvhdp_version",
     "mvhdp_set_corpus", "mvhdp_set_assignments", "mvhdp_get_assignments",
     "mvhdp_set_hyper", "mvhdp_get_alpha", "mvhdp_build_counts", "mvhdp_build_trees",
+    "mvhdp_build_inference_trees", "mvhdp_init_assignments_from_trees",
     "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
     "mvhdp_get_count_histogram", "mvhdp_view_overlap_sums", "mvhdp_model_log_likelihood",
     "mvhdp_sweep", "mvhdp_apply_delta", "mvhdp_get_view_weights",
@@ -78,6 +79,8 @@ def load_library():
     L.mvhdp_get_alpha.argtypes = [vp, vp, vp]
     L.mvhdp_build_counts.argtypes = [vp]
     L.mvhdp_build_trees.argtypes = [vp]
+    L.mvhdp_build_inference_trees.argtypes = [vp]
+    L.mvhdp_init_assignments_from_trees.argtypes = [vp, u64]
     L.mvhdp_get_counts.argtypes = [vp, i32, vp, vp]
     L.mvhdp_set_counts.argtypes = [vp, i32, vp, vp]
     L.mvhdp_get_tree.argtypes = [vp, i32, i32, vp]

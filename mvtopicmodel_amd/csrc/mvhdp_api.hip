@@ -329,9 +329,33 @@ extern "C" int mvhdp_build_trees(mvhdp_handle h)
     if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "build_trees before set_hyper");
     if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "build_trees before build_counts/set_counts");
     HIPC(h, hipSetDevice(h->device));
-    HIPC(h, mvhdp_launch_build_trees(h->mm, h->stream));
+    HIPC(h, mvhdp_launch_build_trees(h->mm, false, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     h->have_trees = true;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_build_inference_trees(mvhdp_handle h)
+{
+    CHECK_H(h);
+    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "build_inference_trees before set_hyper");
+    if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "build_inference_trees before build_counts/set_counts");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, mvhdp_launch_build_trees(h->mm, true, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->have_trees = true;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_init_assignments_from_trees(mvhdp_handle h, uint64_t seed)
+{
+    CHECK_H(h);
+    int rc = require_corpus(h); if (rc) return rc;
+    if (!h->have_trees) FAIL(h, MVHDP_ERR_STATE, "init_assignments_from_trees before build_trees/build_inference_trees");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, mvhdp_launch_init_from_trees(h->mm, (uint32_t)seed, (uint32_t)(seed >> 32), h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->rmax_hint = 0;
     return MVHDP_OK;
 }
 
@@ -460,8 +484,9 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     int rc = require_corpus(h); if (rc) return rc;
     if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "sweep before set_hyper");
     if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "sweep before build_counts/set_counts");
-    if ((flags & MVHDP_SWEEP_REUSE_TREES) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES without trees");
-    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+    if (flags & MVHDP_SWEEP_FROZEN) flags |= MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY;   // nut == 0: the model is read-only
+    if ((flags & MVHDP_SWEEP_REUSE_TREES) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES / FROZEN without trees");
+    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL | MVHDP_SWEEP_FROZEN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
     const int K = mm.K, M = mm.M;
     HIPC(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -575,7 +600,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, s));
         }
     }
-    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) { step(mvhdp_launch_build_trees(mm, s)); h->have_trees = true; }
+    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) { step(mvhdp_launch_build_trees(mm, false, s)); h->have_trees = true; }
     step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
     step(hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
     const long long kmax = LLONG_MAX;

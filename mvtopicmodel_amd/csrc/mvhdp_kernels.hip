@@ -66,7 +66,7 @@ hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens,
 // by level (children always have larger indices, so descending depth is safe)
 // and written out whole, coalesced.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm)
+__global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves)
 {
     extern __shared__ double t[];                  // 2K doubles
     const int K = mm.K, lane = threadIdx.x;
@@ -81,7 +81,9 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm)
         const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
         for (int k = lane; k < K; k += WAVE) {
             double leaf;
-            if (mm.inactive[k]) {                                  // PTM:2670-2671
+            if (inference_leaves) {                                // INF:576: p_wt alone
+                leaf = ((double)cnt[k] + beta) / ((double)nk[k] + beta_sum);
+            } else if (mm.inactive[k]) {                           // PTM:2670-2671
                 leaf = 0.0;
             } else {
                 double p_wt = ((double)cnt[k] + beta) / ((double)nk[k] + beta_sum);   // PTM:2676
@@ -106,12 +108,12 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm)
     }
 }
 
-hipError_t mvhdp_launch_build_trees(const MvModel& mm, hipStream_t s)
+hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, hipStream_t s)
 {
     int64_t nrows = mm.rowbase[mm.M];
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm);
+    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves);
     return hipGetLastError();
 }
 
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                     n_tok++;
 
                     // WRK:587-589 + UPD:197-218: the FastQDelta becomes integer atomics on the delta arrays
-                    if (znew != zold) {
+                    if (znew != zold && !(sl.flags & MVHDP_SWEEP_FROZEN)) {
                         n_chg++;
                         if (lane == 0 && zold >= 0) {
                             atomicAdd(&dnwk[row * K + zold], -1);
@@ -738,5 +740,43 @@ hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned int* hist, hipStre
     int64_t blocks = (mm.D + 3) / 4;
     int grid = (int)(blocks < 4096 ? blocks : 4096);
     hipLaunchKernelGGL(slot_hist_kernel, dim3(grid), dim3(256), 0, s, mm, hist);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// init_from_trees: INF:169-199.  One wave per (view, entity): each token's topic is drawn from its
+// type's tree (FTree.sample FT:111-136); out-of-vocabulary tokens get 0 (Java's new int[]).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_from_trees_kernel(MvModel mm, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K = mm.K;
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < mm.D; d += wstride) {
+        const int64_t dg = mm.doc_id_base + d;
+        for (int m = 0; m < mm.M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            for (int64_t i = b; i < e; i++) {                      // tokens one at a time: the descent is wave-wide
+                const int type = mm.tok[m][i];
+                int topic = 0;
+                if (type >= 0 && type < mm.V[m]) {
+                    uint32_t x[4];
+                    philox4x32_10((uint32_t)(i - b), (uint32_t)m, (uint32_t)dg, 0xFFFFFFFFu,
+                                  seed_lo, seed_hi ^ (uint32_t)((unsigned long long)dg >> 32), x);
+                    const double u = bits_to_unit(x[0], x[1]);
+                    const int64_t row = mm.rowbase[m] + type;
+                    topic = tree_sample(mm.trees + row * 2 * K, K, u, mm.root[row], lane);
+                }
+                if (lane == 0) mm.z[m][i] = topic;
+            }
+        }
+    }
+}
+
+hipError_t mvhdp_launch_init_from_trees(const MvModel& mm, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s)
+{
+    if (mm.D <= 0) return hipSuccess;
+    int64_t blocks = (mm.D + 3) / 4;
+    int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(init_from_trees_kernel, dim3(grid), dim3(256), 0, s, mm, seed_lo, seed_hi);
     return hipGetLastError();
 }

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void sweep_fast_kernel(MvModel mm, SweepLaunch
                 // atomic instructions on the delta rows plus two on the block's n_k table.  Issued after
                 // the token loop so that no token ever waits on an atomic's round trip.
                 {
-                    const bool chg = tvalid && (w_l >= 0) && (znew_l != z_l);
+                    const bool chg = tvalid && (w_l >= 0) && (znew_l != z_l) && !(sl.flags & MVHDP_SWEEP_FROZEN);
                     n_chg += (unsigned int)__popcll(__ballot(chg));
                     if (chg) {
                         const int64_t rowK = (row0 + w_l) * K;

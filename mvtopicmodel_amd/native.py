@@ -14,6 +14,7 @@ SWEEP_REUSE_TREES = 0x1
 SWEEP_NO_APPLY = 0x2
 SWEEP_EXACT_CHAIN = 0x4
 SWEEP_GENERIC_KERNEL = 0x8
+SWEEP_FROZEN = 0x10
 
 BUF_COUNTS = 0
 BUF_DELTA = 1
@@ -164,6 +165,12 @@ class NativeSampler:
 
     def build_trees(self):
         self._ck(self.L.mvhdp_build_trees(self.h))
+
+    def build_inference_trees(self):
+        self._ck(self.L.mvhdp_build_inference_trees(self.h))
+
+    def init_assignments_from_trees(self, seed):
+        self._ck(self.L.mvhdp_init_assignments_from_trees(self.h, int(seed)))
 
     def get_counts(self, m):
         nwk = np.empty((self.V[m], self.K), dtype=np.int32)

@@ -79,6 +79,8 @@ def lib():
     L.orc_init_assignments.argtypes = [vp, i64]
     L.orc_build_counts.argtypes = [vp]
     L.orc_build_trees.argtypes = [vp]
+    L.orc_build_inference_trees.argtypes = [vp]
+    L.orc_init_assignments_from_trees.argtypes = [vp, u64, i64]
     L.orc_get_counts.argtypes = [vp, C.c_int, vp, vp]
     L.orc_set_counts.argtypes = [vp, C.c_int, vp, vp]
     L.orc_get_tree.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -108,6 +110,7 @@ def _ptr(a):
 
 SWEEP_REUSE_TREES = 1
 SWEEP_NO_APPLY = 2
+SWEEP_FROZEN = 16
 
 
 class Oracle:
@@ -182,6 +185,12 @@ class Oracle:
 
     def build_trees(self):
         self.L.orc_build_trees(self.h)
+
+    def build_inference_trees(self):
+        self.L.orc_build_inference_trees(self.h)
+
+    def init_assignments_from_trees(self, seed, doc_id_base=0):
+        self.L.orc_init_assignments_from_trees(self.h, int(seed), int(doc_id_base))
 
     def get_counts(self, m):
         nwk = np.empty((self.V[m], self.K), dtype=np.int32)

@@ -427,6 +427,40 @@ void orc_build_trees(orc_model* o)
     free(temp);
 }
 
+void orc_build_inference_trees(orc_model* o)
+{
+    /* FastQMVWVTopicInferencer.initInferencer INF:557-586: leaves are p_wt alone (no gamma*alpha, no inactive test) */
+    int K = o->K, M = o->M;
+    double* temp = (double*)malloc((size_t)K * sizeof(double));
+    for (int m = 0; m < M; m++)
+        for (int w = 0; w < o->V[m]; ++w) {
+            const int32_t* cnt = o->nwk + (size_t)(o->rowbase[m] + w) * K;
+            for (int t = 0; t < K; t++) temp[t] = (cnt[t] + o->beta[m]) / (o->nk[(size_t)m * K + t] + o->beta_sum[m]);   /* INF:576 */
+            orc_ftree_construct(o->trees + (size_t)(o->rowbase[m] + w) * 2 * K, K, temp);
+        }
+    free(temp);
+}
+
+void orc_init_assignments_from_trees(orc_model* o, uint64_t seed, int64_t doc_id_base)
+{
+    /* INF:169-199: every in-vocabulary token starts at trees[m][type].sample(u); out-of-vocabulary tokens keep the
+     * 0 of `new int[]`.  u stands in for ThreadLocalRandom: u1 of the token stream with sweep index 0xFFFFFFFF. */
+    for (int m = 0; m < o->M; m++)
+        for (int64_t d = 0; d < o->D; d++) {
+            int64_t b = o->doc_off[m][d], e = o->doc_off[m][d + 1];
+            for (int64_t i = b; i < e; i++) {
+                int type = o->tokens[m][i];
+                if (type >= 0 && type < o->V[m]) {
+                    double u1, u2;
+                    orc_token_uniforms(seed, 0xFFFFFFFFu, doc_id_base + d, m, (uint32_t)(i - b), &u1, &u2);
+                    o->z[m][i] = orc_ftree_sample(o->trees + (size_t)(o->rowbase[m] + type) * 2 * o->K, o->K, u1);
+                } else {
+                    o->z[m][i] = 0;
+                }
+            }
+        }
+}
+
 void orc_get_counts(const orc_model* o, int m, int32_t* nwk, int32_t* nk)
 {
     int K = o->K;
@@ -729,7 +763,7 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
     orc_stats local; memset(&local, 0, sizeof local);
     local.activated_topic = -1; local.activated_modality = -1; local.activation_key = INT64_MAX;
 
-    if (!(flags & ORC_SWEEP_REUSE_TREES)) orc_build_trees(o);
+    if (!(flags & (ORC_SWEEP_REUSE_TREES | ORC_SWEEP_FROZEN))) orc_build_trees(o);
 
     int first_inactive = -1;                      /* inActiveTopicIndex.first() WRK:525 */
     for (int k = 0; k < K; k++) if (o->inactive[k]) { first_inactive = k; break; }
@@ -760,6 +794,7 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
         if (rc) local.aborted_docs++;
     }
 
+    if (flags & ORC_SWEEP_FROZEN) { dv.n = 0; local.changed = 0; }     /* nut == 0: no FastQDelta is ever queued (WRK:587) */
     apply_deltas(o, &dv, &local, delta_nwk, delta_nk, !(flags & ORC_SWEEP_NO_APPLY));
 
     free(dv.v); free(localTopicCounts); free(localTopicIndex);

@@ -99,6 +99,8 @@ void orc_init_assignments(orc_model* o, int64_t seed);
 void orc_build_counts(orc_model* o);
 /* PTM:2660-2696 */
 void orc_build_trees(orc_model* o);
+void orc_build_inference_trees(orc_model* o);                                            /* INF:557-586 */
+void orc_init_assignments_from_trees(orc_model* o, uint64_t seed, int64_t doc_id_base);  /* INF:169-199 */
 void orc_get_counts(const orc_model* o, int m, int32_t* nwk, int32_t* nk);
 void orc_set_counts(orc_model* o, int m, const int32_t* nwk, const int32_t* nk);
 void orc_get_tree(const orc_model* o, int m, int w, double* tree2K);
@@ -116,6 +118,7 @@ void orc_draw_p_philox(const orc_model* o, uint64_t seed, uint32_t sweep, int64_
 
 #define ORC_SWEEP_REUSE_TREES 1u  /* do not rebuild trees from the snapshot first */
 #define ORC_SWEEP_NO_APPLY    2u  /* leave n_wk/n_k untouched; deltas returned */
+#define ORC_SWEEP_FROZEN      16u /* the inferencer's mode (INF:211-212 nst=1, nut=0): stored trees, no deltas at all */
 
 /* One deferred-update sweep (SURVEY §7 "hard parts": every token sampled
  * against the sweep-start n_wk, n_k, trees; deltas applied afterwards in

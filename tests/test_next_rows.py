@@ -100,3 +100,51 @@ def test_log_likelihood_rises_over_sweeps():
     ll1 = s.model_log_likelihood()
     assert np.all(ll1 > ll0)
     s.close()
+
+
+@pytest.mark.gpu
+def test_inferencer_frozen_model_mode():
+    """the inferencer is a second caller of the same worker with nut=0 (INF:211-294):
+    trees without gamma*alpha (INF:557-586), initial topics drawn from the trees (INF:169-199), the
+    model never updated, out-of-vocabulary tokens skipped (WRK:427) but counted as topic 0."""
+    from mvtopicmodel_amd import NativeSampler
+    from mvtopicmodel_amd.native import SWEEP_FROZEN
+    from oracle.binding import Oracle, SWEEP_FROZEN as ORC_FROZEN
+    K, V = 40, [600, 70]
+    train = small_corpus(K, V, 200, [50, 6], 901)
+    hy = Hyper.defaults(K, V)
+    o_tr = make_oracle(train, hy)
+    for it in range(3):
+        o_tr.sweep(it, 1)
+    model = [o_tr.get_counts(m) for m in range(2)]
+
+    new = small_corpus(K, V, 60, [40, 5], 902)
+    tok0 = new.tokens[0].copy(); tok0[::17] = V[0] + 3          # out-of-vocabulary types (new alphabet entries)
+    from mvtopicmodel_amd.synth import Corpus
+    new = Corpus(K, V, new.doc_off, [tok0, new.tokens[1]])
+    hyi = Hyper.defaults(K, V, p_a=0.2)                         # INF: p_a = 0.2, p_b = 1
+    o = Oracle(K, V); s = NativeSampler(K, V)
+    for be in (o, s):
+        for m in range(2):
+            be.set_corpus(m, new.doc_off[m], new.tokens[m])
+            be.set_counts(m, *model[m])
+    o.set_hyper(hyi.alpha, hyi.alpha_sum, hyi.beta, hyi.beta_sum, hyi.gamma, hyi.p_a, hyi.p_b, None)
+    s.set_hyper(hyi)
+    o.build_inference_trees(); s.build_inference_trees()
+    for m, w in [(0, 0), (0, 599), (1, 33)]:
+        assert np.array_equal(o.get_tree(m, w), s.get_tree(m, w))
+    o.init_assignments_from_trees(77); s.init_assignments_from_trees(77)
+    for m in range(2):
+        assert np.array_equal(o.get_assignments(m), s.get_assignments(m))
+    assert (s.get_assignments(0)[::17] == 0).all()
+    for it in range(1, 4):                                      # numIterations = 10 in the reference; 3 suffice here
+        ro = o.sweep(it, 77, flags=ORC_FROZEN)
+        rs = s.sweep(it, 77, flags=SWEEP_FROZEN)
+        assert rs.changed == 0 == ro["stats"]["changed"]
+        assert rs.oov_skipped == ro["stats"]["oov_skipped"] > 0
+        for m in range(2):
+            assert np.array_equal(o.get_assignments(m), s.get_assignments(m))
+            a, b = s.get_counts(m)
+            assert np.array_equal(a, model[m][0]) and np.array_equal(b, model[m][1])      # frozen model
+    assert (s.get_assignments(0)[::17] == 0).all()              # OOV tokens are never resampled
+    s.close()
