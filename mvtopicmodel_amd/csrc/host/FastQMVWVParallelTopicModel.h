@@ -122,7 +122,7 @@ public:
     bool printLogLikelihood = true;                             // PTM:128
     std::vector<std::string> notes;
 
-    // MALLET 2.0.8 arithmetic used by optimizeBeta (restated from the jar's bytecode, see oracle/tools/javap_lite.py)
+    // MALLET 2.0.8 arithmetic used by optimizeBeta (restated from the jar's bytecode, see tools/javap_lite.py)
     static double digamma(double z);
     static double learnSymmetricConcentration(const std::vector<int32_t>& countHistogram, const std::vector<int32_t>& observationLengths,
                                               int numDimensions, double currentValue);

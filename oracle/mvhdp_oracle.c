@@ -821,7 +821,7 @@ void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delt
 /* ======================================================================== */
 
 /* MALLET 2.0.8 Dirichlet.logGammaStirling (class file only; arithmetic read from the jar's bytecode
- * with oracle/tools/javap_lite.py): shift z up to >= 2, Stirling series, subtract the logs back. */
+ * with tools/javap_lite.py): shift z up to >= 2, Stirling series, subtract the logs back. */
 double orc_log_gamma_stirling(double z)
 {
     static const double HALF_LOG_TWO_PI_UNUSED = 0; (void)HALF_LOG_TWO_PI_UNUSED;

@@ -6,7 +6,7 @@ in the reference only as class files inside output/lib/mallet-2.0.8.jar.  This t
 method's bytecode so that its published algorithm can be restated exactly in the oracle / host
 code.  Study tool only: it reads a class file, it copies nothing.
 
-  python oracle/tools/javap_lite.py <jar> <class/path/Name.class> [method-name ...]
+  python tools/javap_lite.py <jar> <class/path/Name.class> [method-name ...]
 """
 import struct
 import sys
