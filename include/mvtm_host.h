@@ -36,6 +36,9 @@ int   mvtm_model_optimize_p(void* model, double* p_a_out /*[M][M]*/, double* pMe
 int   mvtm_model_optimize_beta(void* model, double* beta_out /*[M]*/, double* betaSum_out /*[M]*/);
 int   mvtm_model_log_likelihood(void* model, double* ll_out /*[M]*/);
 int   mvtm_model_get_perplexities(void* model, int m, double* out, int cap);
+/* printState PTM:3269-3320 (text; gzip when the name ends in .gz) */
+int   mvtm_model_print_state(void* model, const char* filename);
+int   mvtm_java_double_to_string(double v, char* out, int cap);
 void* mvtm_model_native_handle(void* model);
 /* PTM:465-515 on CSR arrays: initial topic draw order of addInstances with java.util.Random(seed) */
 int   mvtm_init_assignments(int K, int M, int64_t D, const int64_t* const* doc_off, int64_t seed, int32_t* const* z_out);

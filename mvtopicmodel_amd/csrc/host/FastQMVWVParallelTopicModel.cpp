@@ -8,7 +8,13 @@
 #include <cstring>
 #include <random>
 #include <stdexcept>
+#include <charconv>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
 #include <unordered_map>
+
+#include <zlib.h>
 
 #include "java_random.h"
 
@@ -61,6 +67,8 @@ void FastQMVWVParallelTopicModel::addInstances(const std::vector<InstanceList>& 
 
     for (int m = 0; m < M; m++) {                                     // PTM:410-463
         numTypes[m] = training[m].alphabetSize;                       // PTM:413
+        if (alphabet.size() != (size_t)M) alphabet.assign(M, {});
+        alphabet[m] = training[m].alphabet;                           // PTM:412
         if (numTypes[m] < 1) throw std::invalid_argument("addInstances: empty alphabet");
         typeTotals[m].assign(numTypes[m], 0);
         betaSum[m] = beta[m] * numTypes[m];                           // PTM:420
@@ -68,6 +76,7 @@ void FastQMVWVParallelTopicModel::addInstances(const std::vector<InstanceList>& 
             TopicAssignment t;
             t.present = true;
             t.tokens = instance.features;
+            t.source = instance.source;
             t.topics.assign(instance.features.size(), 0);             // new int[tokens.size()] PTM:430
             const std::string& entityId = instance.name;              // PTM:437
             auto it = entityPosition.find(entityId);
@@ -316,6 +325,83 @@ void FastQMVWVParallelTopicModel::optimizeBeta()
     }
 }
 
+// Java Double.toString layout: decimal for 1e-3 <= |v| < 1e7, otherwise d.dddE[-]n; always at least one
+// digit after the point.  Digits: shortest round-trip (JDK >= 19; older JDKs print a few values longer).
+std::string FastQMVWVParallelTopicModel::javaDoubleToString(double v)
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    if (v == 0) return std::signbit(v) ? "-0.0" : "0.0";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, std::fabs(v), std::chars_format::scientific);
+    std::string sci(buf, r.ptr);                       // d[.ddd]e[+-]xx
+    size_t epos = sci.find('e');
+    std::string mant = sci.substr(0, epos);
+    int exp10 = std::stoi(sci.substr(epos + 1));
+    std::string digits;
+    for (char c : mant) if (c != '.') digits.push_back(c);
+    std::string out = v < 0 ? "-" : "";
+    if (exp10 >= -3 && exp10 < 7) {
+        if (exp10 >= 0) {
+            std::string ip = digits.substr(0, std::min<size_t>(digits.size(), (size_t)exp10 + 1));
+            while ((int)ip.size() < exp10 + 1) ip.push_back('0');
+            std::string fp = digits.size() > (size_t)exp10 + 1 ? digits.substr((size_t)exp10 + 1) : "0";
+            out += ip + "." + fp;
+        } else {
+            out += "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
+        }
+    } else {
+        out += digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(exp10);
+    }
+    return out;
+}
+
+std::string FastQMVWVParallelTopicModel::printStateToString()
+{
+    syncFromDevice(false);
+    const int M = numModalities;
+    std::ostringstream out;
+    out << "#doc source pos typeindex type topic\n";                                  // PTM:3278
+    out << "#alpha : ";
+    for (int m = 0; m < M; m++) {
+        out << "modality:" << m << "\n";
+        for (int topic = 0; topic < numTopics; topic++) out << javaDoubleToString(gamma[m] * alpha[m][topic]) << " ";   // PTM:3283
+    }
+    out << "\n";
+    out << "#beta[0] : " << javaDoubleToString(beta[0]) << "\n";
+    for (size_t doc = 0; doc < data.size(); doc++) {
+        for (int m = 0; m < M; m++) {
+            const TopicAssignment& ta = data[doc].Assignments[m];
+            if (!ta.present)                                                           // PTM:3291 dereferences null here
+                throw std::runtime_error("printState: entity " + data[doc].EntityId + " has no view " + std::to_string(m) +
+                                         " (the reference throws NullPointerException, PTM:3291)");
+            const std::string source = ta.source.empty() ? "NA" : ta.source;
+            for (size_t pi = 0; pi < ta.tokens.size(); pi++) {
+                int type = ta.tokens[pi];
+                const std::string word = (m < (int)alphabet.size() && type >= 0 && type < (int)alphabet[m].size())
+                                             ? alphabet[m][type] : std::to_string(type);
+                out << doc << " " << source << " " << pi << " " << type << " " << word << " " << ta.topics[pi] << "\n";   // PTM:3303
+            }
+        }
+    }
+    return out.str();
+}
+
+void FastQMVWVParallelTopicModel::printState(const std::string& filename)
+{
+    const std::string text = printStateToString();
+    if (filename.size() > 3 && filename.compare(filename.size() - 3, 3, ".gz") == 0) {   // PTM:3269-3274 GZIPOutputStream
+        gzFile f = gzopen(filename.c_str(), "wb");
+        if (!f) throw std::runtime_error("printState: cannot open " + filename);
+        gzwrite(f, text.data(), (unsigned)text.size());
+        gzclose(f);
+    } else {
+        std::ofstream f(filename, std::ios::binary);
+        if (!f) throw std::runtime_error("printState: cannot open " + filename);
+        f << text;
+    }
+}
+
 std::vector<double> FastQMVWVParallelTopicModel::modelLogLikelihood()
 {
     std::vector<double> ll((size_t)numModalities, 0.0);
@@ -516,6 +602,20 @@ int mvtm_model_get_perplexities(void* p, int m, double* out, int cap)
     int n = std::min<int>(cap, (int)model->perplexities[m].size());
     for (int i = 0; i < n; i++) out[i] = model->perplexities[m][i];
     return n;
+}
+
+int mvtm_model_print_state(void* p, const char* filename)
+{
+    try { ((FastQMVWVParallelTopicModel*)p)->printState(filename); return 0; }
+    catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_java_double_to_string(double v, char* out, int cap)
+{
+    std::string s = FastQMVWVParallelTopicModel::javaDoubleToString(v);
+    if ((int)s.size() + 1 > cap) return -1;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
 }
 
 void* mvtm_model_native_handle(void* p) { return ((FastQMVWVParallelTopicModel*)p)->nativeHandle(); }

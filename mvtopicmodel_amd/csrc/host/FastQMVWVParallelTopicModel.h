@@ -22,16 +22,19 @@ namespace mvtm {
 struct Instance {
     std::string name;
     std::vector<int32_t> features;
+    std::string source;                   // getSource(), "NA" when empty (PTM:3293-3296)
 };
 
 // MALLET InstanceList: instances + getDataAlphabet().size() (PTM:412-413).
 struct InstanceList {
     std::vector<Instance> instances;
     int32_t alphabetSize = 0;
+    std::vector<std::string> alphabet;    // optional: getDataAlphabet().lookupObject(type) for printState (PTM:3303)
 };
 
 // cc.mallet.topics.TopicAssignment: instance + topicSequence (LabelSequence features).
 struct TopicAssignment {
+    std::string source;                   // instance.getSource()
     bool present = false;                 // false == null (MTA:19)
     std::vector<int32_t> tokens;          // instance.getData()
     std::vector<int32_t> topics;          // topicSequence.getFeatures(), sized by getLength()
@@ -121,6 +124,13 @@ public:
     std::vector<std::vector<double>> perplexities;              // PTM:144  [M][iteration/10] = LL/token
     bool printLogLikelihood = true;                             // PTM:128
     std::vector<std::string> notes;
+
+    // the text state format of printState (PTM:3269-3320); gz when the name ends in ".gz".
+    // Java's Double.toString is approximated by the shortest round-trip decimal in Java's layout.
+    void printState(const std::string& filename);
+    std::string printStateToString();
+    static std::string javaDoubleToString(double v);
+    std::vector<std::vector<std::string>> alphabet;             // PTM:68 (strings), empty = print the type index
 
     // MALLET 2.0.8 arithmetic used by optimizeBeta (restated from the jar's bytecode, see tools/javap_lite.py)
     static double digamma(double z);

@@ -11,7 +11,7 @@ HOST_SYMBOLS = [
     "mvtm_model_add_instances", "mvtm_model_estimate", "mvtm_model_num_entities",
     "mvtm_model_view_tokens", "mvtm_model_get_view", "mvtm_model_get_counts",
     "mvtm_model_get_log", "mvtm_model_native_handle", "mvtm_init_assignments",
-    "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
+    "mvtm_model_print_state", "mvtm_java_double_to_string", "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
 ]
 
 _ready = False
@@ -35,12 +35,21 @@ def _lib():
         L.mvtm_model_get_log.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(SweepStatsC)]
         L.mvtm_model_native_handle.argtypes = [vp]; L.mvtm_model_native_handle.restype = vp
         L.mvtm_init_assignments.argtypes = [i32, i32, i64, vp, i64, vp]
+        L.mvtm_model_print_state.argtypes = [vp, C.c_char_p]
+        L.mvtm_java_double_to_string.argtypes = [dbl, C.c_char_p, i32]
         L.mvtm_model_optimize_p.argtypes = [vp, vp, vp]
         L.mvtm_model_optimize_beta.argtypes = [vp, vp, vp]
         L.mvtm_model_log_likelihood.argtypes = [vp, vp]
         L.mvtm_model_get_perplexities.argtypes = [vp, i32, vp, i32]
         _ready = True
     return L
+
+
+def java_double_to_string(v):
+    L = _lib()
+    buf = C.create_string_buffer(64)
+    n = L.mvtm_java_double_to_string(float(v), buf, 64)
+    return buf.value[:n].decode()
 
 
 def init_assignments(K, doc_off, seed):
@@ -130,6 +139,10 @@ class FastQMVWVParallelTopicModel:
         nwk = np.empty((self.V[m], self.K), dtype=np.int32); nk = np.empty(self.K, dtype=np.int32)
         self.L.mvtm_model_get_counts(self.p, m, nwk.ctypes.data, nk.ctypes.data)
         return nwk, nk
+
+    def printState(self, filename):
+        if self.L.mvtm_model_print_state(self.p, str(filename).encode()):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
 
     def optimizeP(self):
         pa = np.zeros((self.M, self.M)); pm = np.zeros((self.M, self.M))

@@ -158,3 +158,43 @@ def test_estimate_with_optimize_steps_matches_oracle_schedule():
         per = model.perplexities(m)
         assert len(per) == 2 and abs(per[1] - ll_at_10[m] / tok[m]) < 1e-9 * abs(per[1])
     model.close()
+
+
+def test_print_state_format(tmp_path):
+    """SURVEY §8f #4: the text state of printState (PTM:3276-3320), plain and gzipped."""
+    import gzip
+    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, java_double_to_string
+    K, V = 7, [30, 9]
+    rng = np.random.RandomState(8)
+    lens0, lens1 = [3, 2, 4], [1, 2, 1]
+    off0 = np.concatenate([[0], np.cumsum(lens0)]).astype(np.int64); off1 = np.concatenate([[0], np.cumsum(lens1)]).astype(np.int64)
+    tok0 = rng.randint(0, 30, off0[-1]).astype(np.int32); tok1 = rng.randint(0, 9, off1[-1]).astype(np.int32)
+    model = FastQMVWVParallelTopicModel(K, 2, 0.1, 0.01)
+    model.setNumIterations(2); model.setRandomSeed(3)
+    model.addInstances([(np.arange(3, dtype=np.int64), off0, tok0, 30), (np.arange(3, dtype=np.int64), off1, tok1, 9)])
+    model.estimate()
+    p_txt, p_gz = tmp_path / "state.txt", tmp_path / "state.txt.gz"
+    model.printState(p_txt); model.printState(p_gz)
+    text = open(p_txt).read()
+    assert gzip.open(p_gz, "rt").read() == text
+    lines = text.split("\n")
+    assert lines[0] == "#doc source pos typeindex type topic"
+    assert lines[1] == "#alpha : modality:0"
+    # gamma*alpha = 0.1 for every topic, then the next view's header on the same line (print, not println)
+    assert lines[2] == "0.1 " * K + "modality:1"
+    assert lines[3] == "0.1 " * K
+    assert lines[4] == "#beta[0] : 0.01"
+    body = [l.split(" ") for l in lines[5:] if l]
+    assert len(body) == int(off0[-1] + off1[-1])
+    z0, z1 = model.get_view(0)[3], model.get_view(1)[3]
+    # entity-major, view-minor, position order; "NA" source; type printed for the alphabet entry
+    exp = []
+    for d in range(3):
+        for pi in range(lens0[d]):
+            i = off0[d] + pi; exp.append([str(d), "NA", str(pi), str(tok0[i]), str(tok0[i]), str(z0[i])])
+        for pi in range(lens1[d]):
+            i = off1[d] + pi; exp.append([str(d), "NA", str(pi), str(tok1[i]), str(tok1[i]), str(z1[i])])
+    assert body == exp
+    assert java_double_to_string(1e-4) == "1.0E-4" and java_double_to_string(0.001) == "0.001"
+    assert java_double_to_string(1e7) == "1.0E7" and java_double_to_string(9999999.0) == "9999999.0"
+    model.close()
