@@ -46,7 +46,7 @@ struct mvhdp_ctx {
     unsigned long long* d_doc_counter = nullptr;
     int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
     int32_t* d_overflow = nullptr;           // [D] entities handed from the register-resident kernel to the generic one
-    unsigned int* d_ovf_meta = nullptr;      // [0] overflow count, [1..5] entities by ceil(topic list/64) = 1,2,3,4,>4
+    unsigned int* d_ovf_meta = nullptr;      // [0] overflow count (u32), then at byte 8: u64[5] tokens by ceil(topic list/64) = 1,2,3,4,>4
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
     size_t lds_attr_set = 0;
 };
@@ -60,7 +60,7 @@ struct mvhdp_ctx {
 // larger r costs registers, i.e. resident waves (measured relative sweep cost per entity below);
 // entities that do not fit are re-run by the generic LDS kernel at about 3x the r=2 cost.
 // Returns 5 when the generic kernel alone is the cheapest.
-static int rmax_from_hist(const unsigned int* hist5)
+static int rmax_from_hist(const unsigned long long* hist5)
 {
     static const double cost_fast[4] = {0.85, 1.0, 1.45, 1.45};  // 3 is served by the 4-slot variant (measured: 68.8 vs 47.9 ms on C4)
     const double cost_generic = 3.2;
@@ -137,7 +137,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMalloc(&h->d_stats, ST_COUNT * sizeof(unsigned long long)));
     CREATE_HIP(hipMalloc(&h->d_act_key, sizeof(long long)));
     CREATE_HIP(hipMalloc(&h->d_doc_counter, sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 8 * sizeof(unsigned int)));
+    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 64));
     mm.alpha = h->d_alpha;
     mm.inactive = h->d_inactive;
     h->h_alpha.assign((size_t)M * (K + 1), 0.0);
@@ -510,9 +510,9 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     if (fast) {
         if (h->rmax_hint <= 0) {
             // first sweep on these assignments: measure the topic lists (one pass over z)
-            unsigned int hist[8] = {0};
-            HIPC(h, hipMemsetAsync(h->d_ovf_meta, 0, 8 * sizeof(unsigned int), h->stream));
-            HIPC(h, mvhdp_launch_slot_hist(mm, h->d_ovf_meta + 1, h->stream));
+            unsigned long long hist[8] = {0};
+            HIPC(h, hipMemsetAsync(h->d_ovf_meta, 0, 64, h->stream));
+            HIPC(h, mvhdp_launch_slot_hist(mm, (unsigned long long*)(h->d_ovf_meta + 2), h->stream));
             HIPC(h, hipMemcpyAsync(hist, h->d_ovf_meta, sizeof hist, hipMemcpyDeviceToHost, h->stream));
             HIPC(h, hipStreamSynchronize(h->stream));
             h->rmax_hint = rmax_from_hist(hist + 1);
@@ -524,7 +524,8 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     }
     struct Geo { uint32_t wave_bytes; int wpb; size_t lds; int grid; };
     auto geometry = [&](bool is_fast, int r, Geo& g) -> int {
-        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, S_cap) : mvhdp_sweep_wave_bytes(M, S_cap));
+        // the register-resident kernel never holds more than 256 slots (longer lists overflow before any slot write)
+        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, std::min(S_cap, 256)) : mvhdp_sweep_wave_bytes(M, S_cap));
         g.wpb = 4;
         while (g.wpb > 1 && sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes > h->max_lds) g.wpb >>= 1;
         g.lds = sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes;
@@ -557,7 +558,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     sl.doc_order = h->d_doc_order;
     sl.overflow_list = h->d_overflow;
     sl.overflow_count = h->d_ovf_meta;
-    sl.slot_hist = h->d_ovf_meta + 1;
+    sl.slot_hist = (unsigned long long*)(h->d_ovf_meta + 2);
 
     // debug buffers
     std::vector<void*> to_free;
@@ -607,21 +608,24 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     const long long kmax = LLONG_MAX;
     step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
     step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
-    step(hipMemsetAsync(h->d_ovf_meta, 0, 8 * sizeof(unsigned int), s));
+    step(hipMemsetAsync(h->d_ovf_meta, 0, 64, s));
     step(hipEventRecord(h->ev[1], s));
-    unsigned int ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // [0] low 32 bits = overflow count, [1..5] token histogram
     if (e == hipSuccess && mm.D > 0) {
         if (fast) {
             sl.wave_bytes = fst.wave_bytes; sl.waves_per_block = fst.wpb;
+            sl.S_cap = std::min(S_cap, 256);
             step(mvhdp_launch_sweep_fast(mm, sl, rmax, fst.grid, debug, s));
             step(hipMemcpyAsync(ovf, h->d_ovf_meta, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
             step(hipStreamSynchronize(s));
+            ovf[0] &= 0xffffffffull;
             if (e == hipSuccess && ovf[0] > 0) {
                 // entities whose topic list did not fit: same sweep, generic kernel, over the overflow list
                 MvModel mo = mm;
                 mo.D = (int64_t)ovf[0];
                 SweepLaunch so = sl;
                 so.doc_order = h->d_overflow; so.wave_bytes = gen.wave_bytes; so.waves_per_block = gen.wpb;
+                so.S_cap = S_cap;
                 step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
                 int64_t need = ((int64_t)ovf[0] + (int64_t)gen.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)gen.wpb * MVHDP_DOC_BATCH);
                 step(mvhdp_launch_sweep(mo, so, (int)std::min<int64_t>(need, gen.grid), debug, s));

@@ -44,7 +44,7 @@ struct SweepLaunch {
     const int32_t* doc_order;          // optional permutation (longest entities first), or nullptr
     int32_t* overflow_list;            // entities whose topic list exceeds the register-resident kernel's slots
     unsigned int* overflow_count;      //   (they are re-run by the generic kernel)
-    unsigned int* slot_hist;           // [5] entities by ceil(list size/64) = 1,2,3,4,>4 (sizes the next sweep's kernel variant)
+    unsigned long long* slot_hist;     // [5] tokens of the entities with ceil(list size/64) = 1,2,3,4,>4 (sizes the next sweep's variant)
     // debug
     double* tok_dbg[MVHDP_MAXM];
     int32_t n_trace;
@@ -71,7 +71,7 @@ hipError_t mvhdp_launch_count_hist(const MvModel& mm, int m, int32_t* hist, int3
 hipError_t mvhdp_launch_view_overlap(const MvModel& mm, double* out, hipStream_t s);
 hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
                                unsigned long long* nonzero, hipStream_t s);
-hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned int* hist, hipStream_t s);
+hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s);
 size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap);
 hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);
 int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes);

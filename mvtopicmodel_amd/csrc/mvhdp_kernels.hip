@@ -279,8 +279,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
         if (lane < 64) { bitmap[lane] = 0; }
         LDS_FENCE();
+        int doc_tokens = 0;
         for (int m = 0; m < M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            doc_tokens += (int)(e - b);
             if (lane == 0) wlen[m] = (int)(e - b);
             for (int64_t i = b + lane; i < e; i += WAVE) {
                 int zz = mm.z[m][i];
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
             prefix[lane] = (uint32_t)(incl - cnt);
             S_used = bcast_i(incl, 63);
         }
-        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1]++; }
+        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1] += (unsigned int)doc_tokens; }   // token-weighted
         LDS_FENCE();
         for (int k0 = 0; k0 < K; k0 += WAVE) {
             int k = k0 + lane;
@@ -387,7 +389,6 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                 for (int t = 0; t < nt; t++) {                              // WRK:425
                     const int w = bcast_i(w_l, t);
                     if (w < 0 || w >= Vm) { n_oov++; continue; }            // WRK:427-428
-                    const int zold = bcast_i(z_l, t);
                     const int so = bcast_i(so_l, t);
                     const double u1 = bcast_d(u1_l, t), u2 = bcast_d(u2_l, t);
                     const double root = bcast_d(root_l, t);
@@ -421,11 +422,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                                 if (i < S_used) {
                                     int k = sk[i];
                                     if (k >= 0) {
-                                        double p_wt = ((double)cnt[k] + beta_m) / sden[i];                  // WRK:507
+                                        double p_wt = div_inrange((double)cnt[k] + beta_m, sden[i]);          // WRK:507
                                         term = (p_mm * (double)sn[m * S + i] + soth[i]) * p_wt;            // WRK:509
                                     }
                                 }
-                                double cum = carry + wave_incl_scan_d(term, lane);
+                                double cum = carry + wave_incl_scan_d_dpp(term);
                                 if (i < S_used) scum[i] = cum;
                                 carry = bcast_d(cum, 63);
                             }
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                                 int k = sk[i];
                                 double term = 0.0;
                                 if (k >= 0) {
-                                    double p_wt = ((double)cnt[k] + beta_m) / sden[i];
+                                    double p_wt = div_inrange((double)cnt[k] + beta_m, sden[i]);
                                     term = (p_mm * (double)sn[m * S + i] + soth[i]) * p_wt;
                                 }
                                 scum[i] = term;
@@ -531,19 +532,23 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                     LDS_FENCE();
                     n_tok++;
 
-                    // WRK:587-589 + UPD:197-218: the FastQDelta becomes integer atomics on the delta arrays
-                    if (znew != zold && !(sl.flags & MVHDP_SWEEP_FROZEN)) {
-                        n_chg++;
-                        if (lane == 0 && zold >= 0) {
-                            atomicAdd(&dnwk[row * K + zold], -1);
-                            atomicAdd(&nkd[m * K + zold], -1);
+                }
+
+                // WRK:587-589 + UPD:197-218 for the whole chunk at once (lane t owns token t): wave-wide atomics on
+                // the delta rows and on the block's n_k table, issued after the token loop so that no token waits on them
+                {
+                    const bool chg = tvalid && (w_l >= 0) && (w_l < Vm) && (znew_l != z_l) && !(sl.flags & MVHDP_SWEEP_FROZEN);
+                    n_chg += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(chg));
+                    if (chg) {
+                        const int64_t rowK = (row0 + w_l) * K;
+                        if (z_l >= 0) {
+                            __hip_atomic_fetch_add(&dnwk[rowK + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(&nkd[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        if (lane == 1) {
-                            atomicAdd(&dnwk[row * K + znew], 1);
-                            atomicAdd(&nkd[m * K + znew], 1);
-                        }
-                        if (mm.first_inactive >= 0 && lane == 2 && mm.inactive[znew]) {   // UPD:263
-                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)(c0 + t) << 11) | (long long)znew;
+                        __hip_atomic_fetch_add(&dnwk[rowK + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&nkd[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (mm.first_inactive >= 0 && mm.inactive[znew_l]) {          // UPD:263
+                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)ti << 11) | (long long)znew_l;
                             atomicMin(sl.act_key, key);
                         }
                     }
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
         if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], hist_r[i]);
+        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], (unsigned long long)hist_r[i]);
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
         if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
@@ -705,7 +710,7 @@ hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, 
 // ceil(n/64) = 1,2,3,4,>4.  Sizes the register-resident sweep kernel before the first
 // sweep (afterwards the sweep kernels keep the histogram current themselves).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned int* hist)
+__global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned long long* hist)
 {
     __shared__ uint32_t bm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -714,8 +719,10 @@ __global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned int
     for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < mm.D; d += wstride) {
         bm[wave][lane] = 0;
         LDS_FENCE();
+        int doc_tokens = 0;
         for (int m = 0; m < mm.M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            doc_tokens += (int)(e - b);
             for (int64_t i = b + lane; i < e; i += WAVE) {
                 int zz = mm.z[m][i];
                 if (zz >= 0) atomicOr(&bm[wave][zz >> 5], 1u << (zz & 31));
@@ -726,15 +733,15 @@ __global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned int
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, WAVE);
         const int hb = min((cnt + 63) >> 6, 5);
-        if (hb >= 1) h[hb - 1]++;
+        if (hb >= 1) h[hb - 1] += (unsigned int)doc_tokens;          // weighted by tokens: cost is per token
         LDS_FENCE();
     }
     if (lane == 0)
 #pragma unroll
-        for (int i = 0; i < 5; i++) if (h[i]) atomicAdd(&hist[i], h[i]);
+        for (int i = 0; i < 5; i++) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned int* hist, hipStream_t s)
+hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s)
 {
     if (mm.D <= 0) return hipSuccess;
     int64_t blocks = (mm.D + 3) / 4;

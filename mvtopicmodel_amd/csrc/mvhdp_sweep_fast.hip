@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
         bitmap[lane] = 0;
         LDS_FENCE();
+        int doc_tokens = 0;
         for (int m = 0; m < M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            doc_tokens += (int)(e - b);
             if (lane == 0) wlen[m] = (int)(e - b);
             for (int64_t i = b + lane; i < e; i += WAVE) {
                 int zz = mm.z[m][i];
@@ -100,6 +102,14 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
             S_used = bcast_i(incl, 63);
         }
         LDS_FENCE();
+        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1] += (unsigned int)doc_tokens; }   // token-weighted
+        // slots per lane: 1, 2 or 4 consecutive slots (slot i = lane*R_eff + r)
+        const int lg = (S_used <= 64) ? 0 : ((S_used <= 128) ? 1 : 2);
+        const int R_eff = 1 << lg;
+        if (S_used > 256 || R_eff > RMAX) {                                // too many topics for this variant:
+            if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;   // the generic kernel takes it
+            continue;
+        }
         for (int k0 = 0; k0 < K; k0 += WAVE) {
             int k = k0 + lane;
             if (k < K) {
@@ -122,15 +132,6 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
             }
         }
         LDS_FENCE();
-        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1]++; }
-        // slots per lane: 1, 2 or 4 consecutive slots (slot i = lane*R_eff + r)
-        const int lg = (S_used <= 64) ? 0 : ((S_used <= 128) ? 1 : 2);
-        const int R_eff = 1 << lg;
-        if (S_used > 256 || R_eff > RMAX) {                                // too many topics for this variant:
-            if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;   // the generic kernel takes it
-            continue;
-        }
-
         int skr[RMAX], koff[RMAX];
 #pragma unroll
         for (int r = 0; r < RMAX; r++) {
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
         if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], hist_r[i]);
+        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], (unsigned long long)hist_r[i]);
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
         if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
