@@ -45,8 +45,9 @@ struct mvhdp_ctx {
     long long* d_act_key = nullptr;
     unsigned long long* d_doc_counter = nullptr;
     int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
-    int32_t* d_overflow = nullptr;           // [D] entities handed from the register-resident kernel to the generic one
-    unsigned int* d_ovf_meta = nullptr;      // [0] overflow count (u32), then at byte 8: u64[5] tokens by ceil(topic list/64) = 1,2,3,4,>4
+    int32_t* d_overflow = nullptr;           // [D] entities handed from the primary register-resident variant to the next pass
+    int32_t* d_overflow2 = nullptr;          // [D] entities that exceed even the 16-slot variant: generic LDS kernel
+    unsigned int* d_ovf_meta = nullptr;      // u32 overflow counts of pass 1 and 2, then at byte 8: u64[17] tokens by ceil(topic list/64)
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
     size_t lds_attr_set = 0;
 };
@@ -56,23 +57,29 @@ struct mvhdp_ctx {
     (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
 #define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
 
-// Which register-resident variant (64*r topic slots per entity) should the next sweep use?  A
-// larger r costs registers, i.e. resident waves (measured relative sweep cost per entity below);
-// entities that do not fit are re-run by the generic LDS kernel at about 3x the r=2 cost.
-// Returns 5 when the generic kernel alone is the cheapest.
-static int rmax_from_hist(const unsigned long long* hist5)
+// Which register-resident variant (64*r topic slots per entity, r = 1,2,4,8,16) should the next sweep's
+// first pass use?  hist[b] = tokens of the entities whose topic list needs b+1 rounds of 64 slots
+// (b = 16: more than 1024 slots).  A larger r costs registers, i.e. resident waves (relative cost per
+// token below, measured on C4/C5); entities that do not fit go to a second pass with the 16-slot
+// variant and, beyond 1024 slots, to the generic LDS kernel.  Returns 32 when the generic kernel alone
+// is the cheapest.
+static int rmax_from_hist(const unsigned long long* hist)
 {
-    static const double cost_fast[4] = {0.85, 1.0, 1.45, 1.45};  // 3 is served by the 4-slot variant (measured: 68.8 vs 47.9 ms on C4)
-    const double cost_generic = 3.2;
+    static const int variants[5] = {1, 2, 4, 8, 16};
+    static const double cost[5] = {0.85, 1.0, 1.45, 2.6, 4.5};
+    const double cost_generic = 6.0;
     double tot = 0;
-    for (int i = 0; i < 5; i++) tot += hist5[i];
+    for (int i = 0; i < MVHDP_HIST_BINS; i++) tot += (double)hist[i];
     if (tot == 0) return 1;
-    int best = 5; double best_cost = cost_generic * tot;
-    double fit = 0;
-    for (int r = 1; r <= 4; r++) {
-        fit += hist5[r - 1];
-        double c = tot * cost_fast[r - 1] * 0.98 + fit * cost_fast[r - 1] * 0.02 + (tot - fit) * cost_generic;
-        if (c < best_cost) { best_cost = c; best = r; }
+    int best = 32; double best_cost = cost_generic * tot;
+    for (int v = 0; v < 5; v++) {
+        double c = 0;
+        for (int b = 0; b < MVHDP_HIST_BINS; b++) {
+            const double t = (double)hist[b];
+            if (b + 1 <= variants[v]) c += t * cost[v];
+            else c += t * (0.02 * cost[v] + (b + 1 <= 16 ? cost[4] : cost_generic));   // prologue in pass 1 + the later pass
+        }
+        if (c < best_cost) { best_cost = c; best = variants[v]; }
     }
     return best;
 }
@@ -137,7 +144,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMalloc(&h->d_stats, ST_COUNT * sizeof(unsigned long long)));
     CREATE_HIP(hipMalloc(&h->d_act_key, sizeof(long long)));
     CREATE_HIP(hipMalloc(&h->d_doc_counter, sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 64));
+    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 256));
     mm.alpha = h->d_alpha;
     mm.inactive = h->d_inactive;
     h->h_alpha.assign((size_t)M * (K + 1), 0.0);
@@ -168,6 +175,7 @@ extern "C" int mvhdp_destroy(mvhdp_handle h)
     if (h->d_doc_counter) hipFree(h->d_doc_counter);
     if (h->d_doc_order) hipFree(h->d_doc_order);
     if (h->d_overflow) hipFree(h->d_overflow);
+    if (h->d_overflow2) hipFree(h->d_overflow2);
     if (h->d_ovf_meta) hipFree(h->d_ovf_meta);
     for (auto& e : h->ev) if (e) hipEventDestroy(e);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -231,6 +239,7 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     h->max_doc_tokens = -1;
     if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
     if (h->d_overflow) { hipFree(h->d_overflow); h->d_overflow = nullptr; }
+    if (h->d_overflow2) { hipFree(h->d_overflow2); h->d_overflow2 = nullptr; }
     h->rmax_hint = 0;
     mm.D = D;
     mm.doc_off[m] = (const int64_t*)h->d_doc_off[m];
@@ -498,34 +507,38 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     SweepLaunch sl{};
     sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
     sl.flags = flags; sl.S_cap = S_cap;
-    sl.block_shared_bytes = (uint32_t)(((size_t)M * K * sizeof(int) + 15) & ~(size_t)15);
+    sl.block_shared_bytes = (uint32_t)((((size_t)M * K + MVHDP_HIST_BINS) * sizeof(int) + 15) & ~(size_t)15);
     const bool debug = dbg != nullptr;
     // Kernel variant.  The register-resident kernel holds 64*rmax topic slots per entity; rmax is
     // sized from the largest topic list the previous sweep saw (or, first time, from the expected
     // number of distinct topics of the longest entity), and entities that still exceed it are
     // handed to the generic LDS kernel through the overflow list.
-    int rmax_cap = S_cap / 64;
     bool fast = !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
     int rmax = 0;
     if (fast) {
         if (h->rmax_hint <= 0) {
             // first sweep on these assignments: measure the topic lists (one pass over z)
-            unsigned long long hist[8] = {0};
-            HIPC(h, hipMemsetAsync(h->d_ovf_meta, 0, 64, h->stream));
+            unsigned long long hist[1 + MVHDP_HIST_BINS] = {0};
+            HIPC(h, hipMemsetAsync(h->d_ovf_meta, 0, 256, h->stream));
             HIPC(h, mvhdp_launch_slot_hist(mm, (unsigned long long*)(h->d_ovf_meta + 2), h->stream));
             HIPC(h, hipMemcpyAsync(hist, h->d_ovf_meta, sizeof hist, hipMemcpyDeviceToHost, h->stream));
             HIPC(h, hipStreamSynchronize(h->stream));
             h->rmax_hint = rmax_from_hist(hist + 1);
         }
         rmax = h->rmax_hint;
-        if (const char* f = getenv("MVHDP_FORCE_RMAX")) { int v = atoi(f); if (v >= 1 && v <= 4) rmax = v; }   // diagnostics only
-        if (rmax > 4) fast = false;
-        rmax = std::max(1, std::min(rmax, std::max(rmax_cap, 1)));
+        if (const char* f = getenv("MVHDP_FORCE_RMAX")) { int v = atoi(f); if (v >= 1 && v <= 16) rmax = v; }   // diagnostics only
+        if (rmax > 16) fast = false;
+        else {
+            { int v = 1; while (v < rmax) v <<= 1; rmax = v; }              // variants exist for 1, 2, 4, 8, 16
+            while (rmax > 1 && 64 * (rmax / 2) >= S_cap) rmax /= 2;          // no larger than the corpus can need
+        }
     }
+    // second pass for entities beyond the primary variant: the 16-slot variant when it can hold more
+    const bool second_fast = fast && rmax < 16 && S_cap > 64 * rmax;
     struct Geo { uint32_t wave_bytes; int wpb; size_t lds; int grid; };
     auto geometry = [&](bool is_fast, int r, Geo& g) -> int {
-        // the register-resident kernel never holds more than 256 slots (longer lists overflow before any slot write)
-        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, std::min(S_cap, 256)) : mvhdp_sweep_wave_bytes(M, S_cap));
+        // a register-resident variant never holds more than 64*r slots (longer lists overflow before any slot write)
+        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, std::min(S_cap, 64 * r)) : mvhdp_sweep_wave_bytes(M, S_cap));
         g.wpb = 4;
         while (g.wpb > 1 && sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes > h->max_lds) g.wpb >>= 1;
         g.lds = sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes;
@@ -536,7 +549,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * bpc));
         return MVHDP_OK;
     };
-    Geo gen{}, fst{};
+    Geo gen{}, fst{}, fst2{};
     {
         // the generic kernel may need > 64 KiB of dynamic LDS
         uint32_t wb = (uint32_t)mvhdp_sweep_wave_bytes(M, S_cap);
@@ -548,17 +561,19 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     }
     if (geometry(false, 0, gen) != MVHDP_OK) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB");
     if (fast && geometry(true, rmax, fst) != MVHDP_OK) fast = false;
+    bool use_second = second_fast && fast && geometry(true, 16, fst2) == MVHDP_OK;
     if (fast && !h->d_overflow && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow, (size_t)mm.D * sizeof(int32_t)));
+    if (use_second && !h->d_overflow2 && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow2, (size_t)mm.D * sizeof(int32_t)));
     if (getenv("MVHDP_DEBUG"))
-        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
-                sweep_idx, (int)fast, rmax, h->rmax_hint, S_cap, fst.grid, fst.wpb, fst.lds, gen.grid, gen.wpb, gen.lds);
+        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) second16=%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
+                sweep_idx, (int)fast, rmax, h->rmax_hint, (int)use_second, S_cap, fst.grid, fst.wpb, fst.lds, gen.grid, gen.wpb, gen.lds);
     sl.stats = h->d_stats;
     sl.act_key = h->d_act_key;
     sl.doc_counter = h->d_doc_counter;
     sl.doc_order = h->d_doc_order;
     sl.overflow_list = h->d_overflow;
     sl.overflow_count = h->d_ovf_meta;
-    sl.slot_hist = (unsigned long long*)(h->d_ovf_meta + 2);
+    sl.slot_hist = (unsigned long long*)(h->d_ovf_meta + 2);     // first pass only
 
     // debug buffers
     std::vector<void*> to_free;
@@ -608,26 +623,46 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     const long long kmax = LLONG_MAX;
     step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
     step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
-    step(hipMemsetAsync(h->d_ovf_meta, 0, 64, s));
+    step(hipMemsetAsync(h->d_ovf_meta, 0, 256, s));
     step(hipEventRecord(h->ev[1], s));
-    unsigned long long ovf[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // [0] low 32 bits = overflow count, [1..5] token histogram
+    unsigned long long ovf[1 + MVHDP_HIST_BINS] = {0};      // [0]: two u32 overflow counts, [1..17]: token histogram
+    auto overflow_count = [&](int which, unsigned int& n) {
+        unsigned int c[2] = {0, 0};
+        step(hipMemcpyAsync(c, h->d_ovf_meta, sizeof c, hipMemcpyDeviceToHost, s));
+        step(hipStreamSynchronize(s));
+        n = c[which];
+    };
     if (e == hipSuccess && mm.D > 0) {
         if (fast) {
+            // pass 1: the primary register-resident variant over every entity
             sl.wave_bytes = fst.wave_bytes; sl.waves_per_block = fst.wpb;
-            sl.S_cap = std::min(S_cap, 256);
+            sl.S_cap = std::min(S_cap, 64 * rmax);
             step(mvhdp_launch_sweep_fast(mm, sl, rmax, fst.grid, debug, s));
-            step(hipMemcpyAsync(ovf, h->d_ovf_meta, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-            step(hipStreamSynchronize(s));
-            ovf[0] &= 0xffffffffull;
-            if (e == hipSuccess && ovf[0] > 0) {
-                // entities whose topic list did not fit: same sweep, generic kernel, over the overflow list
-                MvModel mo = mm;
-                mo.D = (int64_t)ovf[0];
-                SweepLaunch so = sl;
-                so.doc_order = h->d_overflow; so.wave_bytes = gen.wave_bytes; so.waves_per_block = gen.wpb;
-                so.S_cap = S_cap;
+            unsigned int n1 = 0, n2 = 0;
+            overflow_count(0, n1);
+            const int32_t* list = h->d_overflow;
+            unsigned int nlist = n1;
+            if (e == hipSuccess && n1 > 0 && use_second) {
+                // pass 2: the same sweep with the 16-slot variant over the entities that did not fit
+                MvModel m2 = mm; m2.D = (int64_t)n1;
+                SweepLaunch s2 = sl;
+                s2.doc_order = h->d_overflow; s2.overflow_list = h->d_overflow2; s2.overflow_count = h->d_ovf_meta + 1;
+                s2.slot_hist = nullptr;
+                s2.wave_bytes = fst2.wave_bytes; s2.waves_per_block = fst2.wpb; s2.S_cap = std::min(S_cap, 1024);
                 step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
-                int64_t need = ((int64_t)ovf[0] + (int64_t)gen.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)gen.wpb * MVHDP_DOC_BATCH);
+                int64_t need = ((int64_t)n1 + (int64_t)fst2.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)fst2.wpb * MVHDP_DOC_BATCH);
+                step(mvhdp_launch_sweep_fast(m2, s2, 16, (int)std::min<int64_t>(need, fst2.grid), debug, s));
+                overflow_count(1, n2);
+                list = h->d_overflow2; nlist = n2;
+            }
+            if (e == hipSuccess && nlist > 0) {
+                // last pass: topic lists beyond the register variants, generic LDS kernel
+                MvModel mo = mm; mo.D = (int64_t)nlist;
+                SweepLaunch so = sl;
+                so.doc_order = list; so.slot_hist = nullptr;
+                so.wave_bytes = gen.wave_bytes; so.waves_per_block = gen.wpb; so.S_cap = S_cap;
+                step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
+                int64_t need = ((int64_t)nlist + (int64_t)gen.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)gen.wpb * MVHDP_DOC_BATCH);
                 step(mvhdp_launch_sweep(mo, so, (int)std::min<int64_t>(need, gen.grid), debug, s));
             }
         } else {

@@ -44,7 +44,8 @@ struct SweepLaunch {
     const int32_t* doc_order;          // optional permutation (longest entities first), or nullptr
     int32_t* overflow_list;            // entities whose topic list exceeds the register-resident kernel's slots
     unsigned int* overflow_count;      //   (they are re-run by the generic kernel)
-    unsigned long long* slot_hist;     // [5] tokens of the entities with ceil(list size/64) = 1,2,3,4,>4 (sizes the next sweep's variant)
+    unsigned long long* slot_hist;     // [17] tokens of the entities with ceil(list size/64) = 1..16, >16 (sizes the next sweep's variant);
+                                       //      nullptr on the overflow passes
     // debug
     double* tok_dbg[MVHDP_MAXM];
     int32_t n_trace;
@@ -78,3 +79,4 @@ int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t l
 int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes);
 
 #define MVHDP_DOC_BATCH 2
+#define MVHDP_HIST_BINS 17

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     const bool exact_only = (sl.flags & MVHDP_SWEEP_EXACT_CHAIN) != 0;
 
     int* nkd = (int*)smem;                                  // [M*K] n_k deltas of this block
-    for (int i = threadIdx.x; i < M * K; i += blockDim.x) nkd[i] = 0;
+    unsigned int* hist_s = (unsigned int*)(nkd + M * K);    // [MVHDP_HIST_BINS] tokens by topic-list size class
+    for (int i = threadIdx.x; i < M * K + MVHDP_HIST_BINS; i += blockDim.x) nkd[i] = 0;
     __syncthreads();
 
     unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
@@ -263,7 +264,6 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     int32_t* dnwk = mm.delta;
 
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
-    unsigned int hist_r[5] = {0, 0, 0, 0, 0};
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
     for (;;) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
             prefix[lane] = (uint32_t)(incl - cnt);
             S_used = bcast_i(incl, 63);
         }
-        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1] += (unsigned int)doc_tokens; }   // token-weighted
+        if (sl.slot_hist && lane == 0 && S_used > 0) atomicAdd(&hist_s[min((S_used + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);
         LDS_FENCE();
         for (int k0 = 0; k0 < K; k0 += WAVE) {
             int k = k0 + lane;
@@ -565,9 +565,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     int32_t* dnk = mm.delta + mm.rowbase[M] * K;
     for (int i = threadIdx.x; i < M * K; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
+    if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
     if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], (unsigned long long)hist_r[i]);
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
         if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
@@ -714,7 +713,9 @@ __global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned lon
 {
     __shared__ uint32_t bm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int h[5] = {0, 0, 0, 0, 0};
+    __shared__ unsigned int hs[MVHDP_HIST_BINS];
+    if (threadIdx.x < MVHDP_HIST_BINS) hs[threadIdx.x] = 0;
+    __syncthreads();
     const int64_t wstride = (int64_t)gridDim.x * 4;
     for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < mm.D; d += wstride) {
         bm[wave][lane] = 0;
@@ -732,13 +733,11 @@ __global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned lon
         int cnt = __popc(bm[wave][lane]);
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, WAVE);
-        const int hb = min((cnt + 63) >> 6, 5);
-        if (hb >= 1) h[hb - 1] += (unsigned int)doc_tokens;          // weighted by tokens: cost is per token
+        if (lane == 0 && cnt > 0) atomicAdd(&hs[min((cnt + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);   // weighted by tokens
         LDS_FENCE();
     }
-    if (lane == 0)
-#pragma unroll
-        for (int i = 0; i < 5; i++) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+    __syncthreads();
+    if (threadIdx.x < MVHDP_HIST_BINS && hs[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)hs[threadIdx.x]);
 }
 
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s)

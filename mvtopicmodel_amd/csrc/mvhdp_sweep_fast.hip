@@ -41,7 +41,7 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap)
 #define MVHDP_LB4 4
 #endif
 template <int RMAX, bool DEBUG>
-__global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : MVHDP_LB1))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+__global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : 1))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
     const bool exact_only = (sl.flags & MVHDP_SWEEP_EXACT_CHAIN) != 0;
 
     int* nkd = (int*)smem;                                  // [M*K] n_k deltas of this block
-    for (int i = threadIdx.x; i < M * K; i += blockDim.x) nkd[i] = 0;
+    unsigned int* hist_s = (unsigned int*)(nkd + M * K);    // [MVHDP_HIST_BINS] tokens by topic-list size class
+    for (int i = threadIdx.x; i < M * K + MVHDP_HIST_BINS; i += blockDim.x) nkd[i] = 0;
     __syncthreads();
 
     unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
@@ -66,7 +67,6 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
     int32_t* dnwk = mm.delta;
 
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
-    unsigned int hist_r[5] = {0, 0, 0, 0, 0};
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
     for (;;) {
@@ -102,11 +102,11 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
             S_used = bcast_i(incl, 63);
         }
         LDS_FENCE();
-        { const int hb = min((S_used + 63) >> 6, 5); if (hb >= 1) hist_r[hb - 1] += (unsigned int)doc_tokens; }   // token-weighted
+        if (sl.slot_hist && lane == 0 && S_used > 0) atomicAdd(&hist_s[min((S_used + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);
         // slots per lane: 1, 2 or 4 consecutive slots (slot i = lane*R_eff + r)
-        const int lg = (S_used <= 64) ? 0 : ((S_used <= 128) ? 1 : 2);
+        const int lg = (S_used <= 64) ? 0 : (S_used <= 128) ? 1 : (S_used <= 256) ? 2 : (S_used <= 512) ? 3 : 4;
         const int R_eff = 1 << lg;
-        if (S_used > 256 || R_eff > RMAX) {                                // too many topics for this variant:
+        if (S_used > 1024 || R_eff > RMAX) {                                // too many topics for this variant:
             if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;   // the generic kernel takes it
             continue;
         }
@@ -449,9 +449,8 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
     int32_t* dnk = mm.delta + mm.rowbase[M] * K;
     for (int i = threadIdx.x; i < M * K; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
+    if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
     if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 5; i++) if (hist_r[i]) atomicAdd(&sl.slot_hist[i], (unsigned long long)hist_r[i]);
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
         if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
@@ -485,6 +484,8 @@ hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int
     case 2: return launch_fast<2>(mm, sl, grid_blocks, debug, s);
     case 3:
     case 4: return launch_fast<4>(mm, sl, grid_blocks, debug, s);
+    case 8: return launch_fast<8>(mm, sl, grid_blocks, debug, s);
+    case 16: return launch_fast<16>(mm, sl, grid_blocks, debug, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -523,6 +524,8 @@ int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t l
     case 2: return occ_fast<2>(debug, block_threads, lds_bytes);
     case 3:
     case 4: return occ_fast<4>(debug, block_threads, lds_bytes);
+    case 8: return occ_fast<8>(debug, block_threads, lds_bytes);
+    case 16: return occ_fast<16>(debug, block_threads, lds_bytes);
     default: return 0;
     }
 }

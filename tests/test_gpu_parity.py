@@ -276,6 +276,34 @@ def test_overflow_entities_are_rerun_by_the_generic_kernel():
     s.close()
 
 
+@pytest.mark.parametrize("force", ["", "1", "2", "4", "8", "16"])
+def test_register_variants_and_three_pass_overflow_chain(force, monkeypatch):
+    """Topic lists of ~50 ... ~1500 distinct topics in one corpus: whatever primary variant (64*r slots,
+    r = 1..16) the sweep starts with, the entities that do not fit go to the 16-round variant and, beyond
+    1024 slots, to the generic LDS kernel -- all inside one mvhdp_sweep call, with identical results."""
+    K, V = 2048, [5000, 300]
+    rng = np.random.RandomState(21)
+    lens0 = np.array([60, 110, 150, 260, 300, 520, 700, 1100, 1500, 2600, 4000, 9, 0, 33, 64, 128, 256, 512, 1024] + [20] * 40, dtype=np.int64)
+    lens1 = rng.randint(0, 12, len(lens0)).astype(np.int64)
+    off0 = np.concatenate([[0], np.cumsum(lens0)]); off1 = np.concatenate([[0], np.cumsum(lens1)])
+    from mvtopicmodel_amd.synth import Corpus
+    c = Corpus(K, V, [off0, off1], [rng.randint(0, 5000, off0[-1]).astype(np.int32), rng.randint(0, 300, off1[-1]).astype(np.int32)])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(2)]
+    d0 = np.unique(z0[0][off0[10]:off0[11]]).size
+    assert d0 > 1024                                    # the 4000-token entity really needs the generic pass
+    if force:
+        monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
+    s = make_native(c, hy, z0)
+    for it in range(3):
+        ro = o.sweep(it, 31); rs = s.sweep(it, 31)
+        assert rs.tokens == c.total_tokens == ro["stats"]["tokens"]
+        assert rs.changed == ro["stats"]["changed"]
+        assert_same_state(o, s, 2)
+    s.close()
+
+
 @pytest.mark.parametrize("K,V,D,lam", [
     (1, [30], 20, [6]),                                  # a single topic: FTree of size 1 (no descent)
     (2, [30, 7], 30, [9, 3]),
