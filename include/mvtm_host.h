@@ -35,6 +35,21 @@ int   mvtm_model_get_log(void* model, int i, double* ms, mvhdp_sweep_stats* st);
 int   mvtm_model_optimize_p(void* model, double* p_a_out /*[M][M]*/, double* pMean_out /*[M][M]*/);
 int   mvtm_model_optimize_beta(void* model, double* beta_out /*[M]*/, double* betaSum_out /*[M]*/);
 int   mvtm_model_log_likelihood(void* model, double* ll_out /*[M]*/);
+/* optimizeDP PTM:2440-2591 and optimizeGamma PTM:2369-2438.  tables_out = tablesCnt[0..M-1], rootTablesCnt.
+ * mvtm_model_seed_host_samplers seeds the two java.util.Random streams that stand in for the reference's
+ * unseedable ones (`samp` over ThreadLocalRandom PTM:236; the ctor's unseeded Randoms PTM:241-246). */
+int   mvtm_model_seed_host_samplers(void* model, int64_t samp_seed, int64_t random_seed);
+int   mvtm_model_optimize_dp(void* model, double* alpha_out /*[M][K+1]*/, double* alphaSum_out /*[M]*/,
+                             uint8_t* inactive_out /*[K]*/, double* tables_out /*[M+1]*/);
+int   mvtm_model_optimize_gamma(void* model, double* gamma_out /*[M]*/, double* gammaView_out /*[M]*/, double* gammaRoot_out);
+/* known-answer hooks for the host-side samplers those two steps use (fresh generator state per call):
+ * Cokus.java (MT19937, self-seeded 4357), Samplers.randAntoniak (static Stirling cache, -1 = the call threw),
+ * RandomSamplers.randGamma(a) / randBeta(a,b) / randBernoulli(a) / randGamma(a,b) = kind 0..3 over
+ * java.util.Random(seed), MALLET Randoms(seed).nextGamma(alpha, beta). */
+int   mvtm_cokus_stream(int n, uint32_t* out);
+int   mvtm_rand_antoniak_seq(int ncalls, const double* alpha, const int32_t* n, int32_t* out);
+int   mvtm_random_samplers_stream(int64_t seed, int kind, double a, double b, int n, double* out);
+int   mvtm_mallet_next_gamma_stream(int64_t seed, double alpha, double beta, int n, double* out);
 int   mvtm_model_get_perplexities(void* model, int m, double* out, int cap);
 /* printState PTM:3269-3320 (text; gzip when the name ends in .gz) */
 int   mvtm_model_print_state(void* model, const char* filename);

@@ -41,6 +41,8 @@ FastQMVWVParallelTopicModel::FastQMVWVParallelTopicModel(int numberOfTopics, int
         beta[m] = beta_;
         gamma[m] = 1;
     }
+    tablesCnt.assign(M, 0.0);                          // PTM:238-239
+    gammaView.assign(M, 0.0);
     p_a.assign(M, std::vector<double>(M, 0.0));        // PTM:228-229
     p_b.assign(M, std::vector<double>(M, 0.0));
 }
@@ -325,6 +327,148 @@ void FastQMVWVParallelTopicModel::optimizeBeta()
     }
 }
 
+void FastQMVWVParallelTopicModel::seedHostSamplers(int64_t sampSeed, int64_t randomSeed64)
+{
+    sampRand_.setSeed(sampSeed);
+    random_ = Randoms(randomSeed64);
+    hostSamplersSeeded_ = true;
+}
+
+void FastQMVWVParallelTopicModel::ensureHostSamplers()
+{
+    if (hostSamplersSeeded_) return;
+    if (randomSeed == -1) { std::random_device rd; seedHostSamplers((int64_t)rd(), (int64_t)rd()); }
+    else seedHostSamplers((int64_t)randomSeed + 1, (int64_t)randomSeed);
+}
+
+std::vector<double> FastQMVWVParallelTopicModel::sampleDirichlet(const std::vector<double>& p)
+{
+    double magnitude = 0;                                                            // PTM:2593-2634
+    std::vector<double> partition(p.size());
+    for (size_t i = 0; i < p.size(); i++) magnitude += p[i];
+    for (size_t i = 0; i < p.size(); i++) partition[i] = p[i] / magnitude;
+    std::vector<double> distribution(partition.size());
+    double sum = 0;
+    for (size_t i = 0; i < distribution.size(); i++) {
+        if (partition[i] * magnitude > 0) {
+            distribution[i] = random_.nextGamma(partition[i] * magnitude, 1);
+            if (distribution[i] <= 0) distribution[i] = 0.0001;
+        } else {
+            distribution[i] = 0.0001;
+        }
+        sum += distribution[i];
+    }
+    for (size_t i = 0; i < distribution.size(); i++) distribution[i] /= sum;
+    return distribution;
+}
+
+void FastQMVWVParallelTopicModel::optimizeDP()
+{
+    const int M = numModalities, K = numTopics;
+    ensureHostSamplers();
+    std::vector<std::vector<double>> mk(M, std::vector<double>((size_t)K + 1, 0.0));
+    std::vector<double> mk_root((size_t)K + 1, 0.0);
+    std::fill(tablesCnt.begin(), tablesCnt.end(), 0.0);
+    for (int t = 0; t < K; t++) inActiveTopicIndex.insert(t);                        // PTM:2449-2451
+
+    // view tables simulation PTM:2454-2488; topicDocCounts[m][t][i] = entities with i tokens of topic t in view m
+    for (int m = 0; m < M; m++) {
+        const int len = histogramSize[m] + 1;
+        topicDocCounts[m].assign((size_t)K * len, 0);
+        check(mvhdp_get_doc_topic_hist(h_, m, topicDocCounts[m].data(), len, docLengthCounts[m].data(), len), "mvhdp_get_doc_topic_hist");
+        for (int t = 0; t < K; t++) {
+            const int32_t* tdc = topicDocCounts[m].data() + (size_t)t * len;
+            for (int i = 0; i < len; i++) {
+                if (tdc[i] > 0 && i > 1) {
+                    inActiveTopicIndex.erase(t);
+                    int curTbls = 0;
+                    try { curTbls = Samplers.randAntoniak(gamma[m] * alpha[m][t], i); }
+                    catch (const std::exception&) { curTbls = 1; }
+                    mk[m][t] += (tdc[i] * curTbls);
+                } else if (tdc[i] > 0 && i == 1) {
+                    inActiveTopicIndex.erase(t);
+                    mk[m][t] += tdc[i];
+                }
+            }
+        }
+    }
+    // root tables simulation PTM:2491-2517
+    for (int t = 0; t < K; t++)
+        for (int m = 0; m < M; m++) {
+            if (mk[m][t] > 1) {
+                int curTbls = 0;
+                try {
+                    const double c = std::ceil(mk[m][t]);
+                    // Java (int) of a double saturates
+                    const int n = c >= 2147483647.0 ? 2147483647 : (int)c;
+                    curTbls = Samplers.randAntoniak(gammaRoot, n);
+                } catch (const std::exception&) { curTbls = 1; }
+                mk_root[t] += curTbls;
+            } else if (mk[m][t] == 1) {
+                mk_root[t] += 1;
+            }
+        }
+
+    std::vector<double> v((size_t)K + 1, 0.0);
+    mk_root[K] = gammaRoot;
+    rootTablesCnt = 0;
+    for (double x : mk_root) rootTablesCnt += x;                                     // Vectors.sum
+    int numSamples = 10;
+    for (int i = 0; i < numSamples; i++) {                                           // PTM:2525-2535
+        std::vector<double> tt = sampleDirichlet(mk_root);
+        for (int kk = 0; kk <= K; kk++) v[kk] += tt[kk] / (double)numSamples;
+    }
+    for (int m = 0; m < M; m++) {                                                    // PTM:2549-2580
+        for (int t = 0; t < K; t++) mk[m][t] += v[t] * gammaRoot;
+        std::fill(alpha[m].begin(), alpha[m].end(), 0.0);
+        alphaSum[m] = 0;
+        mk[m][K] = gammaView[m] + v[K] * gammaRoot;
+        tablesCnt[m] = 0;
+        for (double x : mk[m]) tablesCnt[m] += x;
+        for (int i = 0; i < numSamples; i++) {
+            std::vector<double> tt = sampleDirichlet(mk[m]);
+            for (int kk = 0; kk <= K; kk++) {
+                double sampleAlpha = tt[kk] / (double)numSamples;
+                alpha[m][kk] += sampleAlpha;
+                alphaSum[m] += sampleAlpha;
+            }
+        }
+    }
+}
+
+void FastQMVWVParallelTopicModel::optimizeGamma()
+{
+    const int M = numModalities, K = numTopics;
+    ensureHostSamplers();
+    RandomSamplers<JavaRandom> samp(&sampRand_);
+    const double aalpha = 5, balpha = 0.1, agamma = 5, bgamma = 0.1;                 // PTM:2373-2379
+    const int R = 10;
+    for (int r = 0; r < R; r++) {                                                    // root level PTM:2384-2395
+        double eta = samp.randBeta(gammaRoot + 1, rootTablesCnt);
+        double bloge = bgamma - std::log(eta);
+        double pie = 1. / (1. + (rootTablesCnt * bloge / (agamma + K - 1)));
+        int u = samp.randBernoulli(pie);
+        gammaRoot = samp.randGamma(agamma + K - 1 + u, 1. / bloge);
+    }
+    for (int m = 0; m < M; m++)                                                      // per view PTM:2398-2437
+        for (int r = 0; r < R; r++) {
+            double prevGamma = gamma[m];
+            double eta = samp.randBeta(gammaView[m] + 1, tablesCnt[m]);
+            double bloge = bgamma - std::log(eta);
+            double pie = 1. / (1. + (tablesCnt[m] * bloge / (agamma + K - 1)));
+            int u = samp.randBernoulli(pie);
+            gammaView[m] = samp.randGamma(agamma + K - 1 + u, 1. / bloge);
+            double qs = 0, qw = 0;                                                   // document level (Teh+06)
+            for (size_t j = 0; j < docLengthCounts[m].size(); j++)
+                for (int i = 0; i < docLengthCounts[m][j]; i++) {
+                    qs += samp.randBernoulli((double)j / ((double)j + gamma[m]));
+                    qw += std::log(samp.randBeta(gamma[m] + 1, (double)j));
+                }
+            gamma[m] = samp.randGamma(aalpha + tablesCnt[m] - qs, 1. / (balpha - qw));
+            if (gamma[m] == 0) gamma[m] = prevGamma;
+        }
+}
+
 // Java Double.toString layout: decimal for 1e-3 <= |v| < 1e7, otherwise d.dddE[-]n; always at least one
 // digit after the point.  Digits: shortest round-trip (JDK >= 19; older JDKs print a few values longer).
 std::string FastQMVWVParallelTopicModel::javaDoubleToString(double v)
@@ -426,10 +570,10 @@ void FastQMVWVParallelTopicModel::estimate()
             double v = std::min((double)iteration / 100 + 0.3, 1.1);
             for (int i = 0; i < M; i++) std::fill(p_a[i].begin(), p_a[i].end(), v);
         } else if (iteration > burninPeriod && optimizeInterval != 0 && iteration % optimizeInterval == 0) {
-            // PTM:1173-1210.  optimizeP and optimizeBeta run (device statistics + the reference's closed forms);
-            // optimizeDP / optimizeGamma (random samplers) are not in this build: alpha and gamma stay as they are.
+            // PTM:1173-1210: statistics from device kernels, the closed forms and samplers are the reference's
             optimizeP(iteration + optimizeInterval > numIterations);                 // PTM:1176
-            if (notes.empty()) notes.push_back("optimizeDP/optimizeGamma skipped (not in this build): alpha, gamma unchanged");
+            optimizeDP();                                                            // PTM:1184
+            optimizeGamma();                                                         // PTM:1185
             optimizeBeta();                                                          // PTM:1186
             // buildFTrees(false) PTM:1209: mvhdp_sweep rebuilds the trees from the counts and the new hyper-parameters
         }
@@ -582,6 +726,85 @@ int mvtm_model_optimize_beta(void* p, double* beta_out, double* betaSum_out)
         for (int m = 0; m < model->numModalities; m++) { beta_out[m] = model->beta[m]; betaSum_out[m] = model->betaSum[m]; }
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_model_seed_host_samplers(void* p, int64_t samp_seed, int64_t random_seed)
+{
+    ((FastQMVWVParallelTopicModel*)p)->seedHostSamplers(samp_seed, random_seed);
+    return 0;
+}
+
+int mvtm_model_optimize_dp(void* p, double* alpha_out, double* alphaSum_out, uint8_t* inactive_out, double* tables_out)
+{
+    auto* mdl = (FastQMVWVParallelTopicModel*)p;
+    try {
+        mdl->optimizeDP();
+        const int M = mdl->numModalities, K = mdl->numTopics;
+        for (int m = 0; m < M; m++) {
+            if (alpha_out) std::copy(mdl->alpha[m].begin(), mdl->alpha[m].end(), alpha_out + (size_t)m * (K + 1));
+            if (alphaSum_out) alphaSum_out[m] = mdl->alphaSum[m];
+            if (tables_out) tables_out[m] = mdl->tablesCnt[m];
+        }
+        if (tables_out) tables_out[M] = mdl->rootTablesCnt;
+        if (inactive_out) for (int k = 0; k < K; k++) inactive_out[k] = mdl->inActiveTopicIndex.count(k) ? 1 : 0;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_model_optimize_gamma(void* p, double* gamma_out, double* gammaView_out, double* gammaRoot_out)
+{
+    auto* mdl = (FastQMVWVParallelTopicModel*)p;
+    try {
+        mdl->optimizeGamma();
+        for (int m = 0; m < mdl->numModalities; m++) {
+            if (gamma_out) gamma_out[m] = mdl->gamma[m];
+            if (gammaView_out) gammaView_out[m] = mdl->gammaView[m];
+        }
+        if (gammaRoot_out) *gammaRoot_out = mdl->gammaRoot;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+// Known-answer hooks for the host-side samplers (fresh generator state per call)
+int mvtm_cokus_stream(int n, uint32_t* out)
+{
+    mvtm::Cokus c;
+    for (int i = 0; i < n; i++) out[i] = c.rand();
+    return 0;
+}
+
+int mvtm_rand_antoniak_seq(int ncalls, const double* alpha, const int32_t* n, int32_t* out)
+{
+    mvtm::StaticSamplers s;
+    for (int i = 0; i < ncalls; i++) {
+        try { out[i] = s.randAntoniak(alpha[i], n[i]); }
+        catch (const std::exception&) { out[i] = -1; }
+    }
+    return 0;
+}
+
+int mvtm_random_samplers_stream(int64_t seed, int kind, double a, double b, int n, double* out)
+{
+    mvtm::JavaRandom r(seed);
+    mvtm::RandomSamplers<mvtm::JavaRandom> samp(&r);
+    for (int i = 0; i < n; i++) {
+        switch (kind) {
+        case 0: out[i] = samp.randGamma(a); break;
+        case 1: out[i] = samp.randBeta(a, b); break;
+        case 2: out[i] = samp.randBernoulli(a); break;
+        case 3: out[i] = samp.randGamma(a, b); break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+int mvtm_mallet_next_gamma_stream(int64_t seed, double alpha, double beta, int n, double* out)
+{
+    mvtm::Randoms r(seed);
+    try { for (int i = 0; i < n; i++) out[i] = r.nextGamma(alpha, beta); }
+    catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+    return 0;
 }
 
 int mvtm_model_log_likelihood(void* p, double* ll_out)

@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../../include/mvhdp.h"
+#include "java_random.h"
+#include "knowceans_samplers.h"
 
 namespace mvtm {
 
@@ -117,9 +119,20 @@ public:
     void optimizeP(bool appendMetadata = false);               // PTM:2698-2819
     void optimizeBeta();                                       // PTM:2288-2367
     std::vector<double> modelLogLikelihood();                  // PTM:3322-3452
-    // optimizeDP PTM:2440-2591 and optimizeGamma PTM:2369-2438 (random table-count / Escobar-West samplers
-    // over knowceans + MALLET Randoms.nextGamma) are not in this build; estimate() keeps alpha and gamma
-    // fixed at those steps and says so in `notes`.
+    // The two randomised steps.  Their statistics (topicDocCounts) come from a device kernel; the samplers are
+    // the reference's own (knowceans_samplers.h, java_random.h).  RNG streams: Samplers.randAntoniak draws from
+    // the JVM-wide Cokus generator (self-seeded with 4357, reproduced as is); `samp` runs over
+    // ThreadLocalRandom and `random` is an unseeded Randoms in the reference (PTM:236,241-246) -- neither can
+    // be seeded there, so this build feeds both from java.util.Random streams derived from randomSeed.
+    void optimizeDP();                                         // PTM:2440-2591
+    void optimizeGamma();                                      // PTM:2369-2438
+    std::vector<double> sampleDirichlet(const std::vector<double>& p);   // PTM:2593-2634
+    std::vector<double> tablesCnt;                              // PTM:136
+    double rootTablesCnt = 0;                                   // PTM:137
+    std::vector<double> gammaView;                              // PTM:138
+    double gammaRoot = 10;                                      // PTM:139
+    StaticSamplers Samplers;                                    // the static half of org.knowceans.util.Samplers
+    void seedHostSamplers(int64_t sampSeed, int64_t randomSeed64);
     std::vector<std::vector<double>> pMean;                     // PTM:134
     std::vector<std::vector<double>> perplexities;              // PTM:144  [M][iteration/10] = LL/token
     bool printLogLikelihood = true;                             // PTM:128
@@ -141,6 +154,10 @@ private:
     void initializeHistograms();          // PTM:849-897
     void pushHyper();
     void check(int rc, const char* what);
+    void ensureHostSamplers();
+    JavaRandom sampRand_{0};                                    // stands in for ThreadLocalRandom.current()
+    Randoms random_{0};                                         // the ctor's `random` field (PTM:241-246)
+    bool hostSamplersSeeded_ = false;
     mvhdp_handle h_ = nullptr;
     int device_ = 0;
     int64_t docIdBase_ = 0;

@@ -1,9 +1,11 @@
 // java_random.h — java.util.Random (documented 48-bit LCG) and the parts of
 // cc.mallet.util.Randoms (mallet 2.0.8) the host side of the hot path draws
-// from: PTM:404-408,500-506 (initial assignments) and WRK:327-337 (view weights).
+// from: PTM:404-408,500-506 (initial assignments), WRK:327-337 (view weights) and
+// PTM:2616 (sampleDirichlet's nextGamma).
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <stdexcept>
 
 namespace mvtm {
 
@@ -67,6 +69,46 @@ public:
         double v1 = std::pow(nextUniform(), 1 / alpha), v2 = std::pow(nextUniform(), 1 / beta);
         while (v1 + v2 > 1) { v1 = std::pow(nextUniform(), 1 / alpha); v2 = std::pow(nextUniform(), 1 / beta); }
         return v1 / (v1 + v2);
+    }
+
+    // Randoms.nextGamma(alpha, beta, lambda) as compiled in mallet-2.0.8.jar (read with tools/javap_lite.py):
+    // alpha < 1: rejection from the b = 1 + alpha/e envelope; alpha == 1: -log U; alpha > 1: Best's rejection.
+    // Comparisons are written so that a NaN takes the branch the JVM's dcmpl/dcmpg encoding takes.
+    double nextGamma(double alpha, double beta = 1, double lambda = 0)
+    {
+        double gamma = 0;
+        if (alpha <= 0 || beta <= 0) throw std::invalid_argument("alpha and beta must be strictly positive.");
+        if (alpha < 1) {
+            const double b = 1 + alpha * std::exp(-1.0);
+            bool flag = false;
+            while (!flag) {
+                const double p = b * nextUniform();
+                if (p > 1) {
+                    gamma = -std::log((b - p) / alpha);
+                    if (nextUniform() <= std::pow(gamma, alpha - 1)) flag = true;
+                } else {
+                    gamma = std::pow(p, 1 / alpha);
+                    if (nextUniform() <= std::exp(-gamma)) flag = true;
+                }
+            }
+        } else if (alpha == 1) {
+            gamma = -std::log(nextUniform());
+        } else {
+            const double b = alpha - 1, c = 3.0 * alpha - 0.75;
+            bool flag = false;
+            while (!flag) {
+                const double u = nextUniform(), v = nextUniform();
+                const double w = u * (1 - u);
+                const double y = std::sqrt(c / w) * (u - 0.5);
+                gamma = b + y;
+                if (gamma >= 0) {
+                    const double z = 64.0 * w * w * w * v * v;
+                    flag = z <= 1 - 2.0 * y * y / gamma;
+                    if (!flag) flag = std::log(z) <= 2.0 * (b * std::log(gamma / b) - y);
+                }
+            }
+        }
+        return beta * gamma + lambda;
     }
 
 private:

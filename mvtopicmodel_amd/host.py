@@ -12,6 +12,8 @@ HOST_SYMBOLS = [
     "mvtm_model_view_tokens", "mvtm_model_get_view", "mvtm_model_get_counts",
     "mvtm_model_get_log", "mvtm_model_native_handle", "mvtm_init_assignments",
     "mvtm_model_print_state", "mvtm_java_double_to_string", "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
+    "mvtm_model_seed_host_samplers", "mvtm_model_optimize_dp", "mvtm_model_optimize_gamma",
+    "mvtm_cokus_stream", "mvtm_rand_antoniak_seq", "mvtm_random_samplers_stream", "mvtm_mallet_next_gamma_stream",
 ]
 
 _ready = False
@@ -41,6 +43,13 @@ def _lib():
         L.mvtm_model_optimize_beta.argtypes = [vp, vp, vp]
         L.mvtm_model_log_likelihood.argtypes = [vp, vp]
         L.mvtm_model_get_perplexities.argtypes = [vp, i32, vp, i32]
+        L.mvtm_model_seed_host_samplers.argtypes = [vp, i64, i64]
+        L.mvtm_model_optimize_dp.argtypes = [vp, vp, vp, vp, vp]
+        L.mvtm_model_optimize_gamma.argtypes = [vp, vp, vp, vp]
+        L.mvtm_cokus_stream.argtypes = [i32, vp]
+        L.mvtm_rand_antoniak_seq.argtypes = [i32, vp, vp, vp]
+        L.mvtm_random_samplers_stream.argtypes = [i64, i32, dbl, dbl, i32, vp]
+        L.mvtm_mallet_next_gamma_stream.argtypes = [i64, dbl, dbl, i32, vp]
         _ready = True
     return L
 
@@ -65,6 +74,36 @@ def init_assignments(K, doc_off, seed):
     if rc:
         raise RuntimeError("mvtm_init_assignments failed")
     return z
+
+
+def cokus_stream(n):
+    """First n 32-bit outputs of a fresh knowceans Cokus generator (self-seeded with 4357)."""
+    out = np.empty(n, dtype=np.uint32)
+    _lib().mvtm_cokus_stream(int(n), out.ctypes.data)
+    return out
+
+
+def rand_antoniak_seq(alpha, n):
+    """Samplers.randAntoniak(alpha[i], n[i]) called in order on fresh statics; -1 where the call threw."""
+    a = np.ascontiguousarray(alpha, dtype=np.float64); nn = np.ascontiguousarray(n, dtype=np.int32)
+    out = np.empty(len(a), dtype=np.int32)
+    _lib().mvtm_rand_antoniak_seq(len(a), a.ctypes.data, nn.ctypes.data, out.ctypes.data)
+    return out
+
+
+def random_samplers_stream(seed, kind, a, b, n):
+    kinds = {"gamma": 0, "beta": 1, "bernoulli": 2, "gamma_scale": 3}
+    out = np.empty(n, dtype=np.float64)
+    if _lib().mvtm_random_samplers_stream(int(seed), kinds[kind], float(a), float(b), int(n), out.ctypes.data):
+        raise ValueError(kind)
+    return out
+
+
+def mallet_next_gamma_stream(seed, alpha, beta, n):
+    out = np.empty(n, dtype=np.float64)
+    if _lib().mvtm_mallet_next_gamma_stream(int(seed), float(alpha), float(beta), int(n), out.ctypes.data):
+        raise ValueError(_lib().mvtm_last_error().decode())
+    return out
 
 
 class FastQMVWVParallelTopicModel:
@@ -155,6 +194,22 @@ class FastQMVWVParallelTopicModel:
         if self.L.mvtm_model_optimize_beta(self.p, b.ctypes.data, bs.ctypes.data):
             raise RuntimeError(self.L.mvtm_last_error().decode())
         return b, bs
+
+    def seedHostSamplers(self, samp_seed, random_seed):
+        self.L.mvtm_model_seed_host_samplers(self.p, int(samp_seed), int(random_seed))
+
+    def optimizeDP(self):
+        alpha = np.zeros((self.M, self.K + 1)); asum = np.zeros(self.M)
+        ina = np.zeros(self.K, dtype=np.uint8); tables = np.zeros(self.M + 1)
+        if self.L.mvtm_model_optimize_dp(self.p, alpha.ctypes.data, asum.ctypes.data, ina.ctypes.data, tables.ctypes.data):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return alpha, asum, ina, tables
+
+    def optimizeGamma(self):
+        g = np.zeros(self.M); gv = np.zeros(self.M); gr = C.c_double()
+        if self.L.mvtm_model_optimize_gamma(self.p, g.ctypes.data, gv.ctypes.data, C.addressof(gr)):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return g, gv, gr.value
 
     def modelLogLikelihood(self):
         ll = np.zeros(self.M)

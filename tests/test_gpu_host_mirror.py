@@ -96,11 +96,14 @@ def test_single_view_is_plain_lda_path():
 
 
 def test_estimate_with_optimize_steps_matches_oracle_schedule():
-    """Past burn-in, every optimizeInterval iterations estimate() runs optimizeP and optimizeBeta
-    (PTM:1173-1210) before the sweep; the same schedule replayed on the oracle gives the same integers."""
+    """Past burn-in, every optimizeInterval iterations estimate() runs optimizeP, optimizeDP, optimizeGamma and
+    optimizeBeta (PTM:1173-1210) before the sweep; the same schedule replayed on the oracle (C sweep + the
+    Python restatement of the two randomised steps, same injected streams) gives the same integers and the
+    same hyper-parameters bit for bit."""
     import math
     from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
     from oracle.binding import Oracle
+    from oracle import dp_samplers as dps
     from mvtopicmodel_amd import synth
     K, V = 30, [400, 50, 40]
     c = synth.generate(K, V, 150, [40, 6, 5], seed=321, chunk_docs=4096)
@@ -113,17 +116,24 @@ def test_estimate_with_optimize_steps_matches_oracle_schedule():
     for m in range(3):
         o.set_corpus(m, c.doc_off[m], c.tokens[m])
     hy = Hyper.defaults(K, V, p_a=0.2)
-    push = lambda: o.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, None)
+    inactive = np.zeros(K, dtype=np.uint8)
+    push = lambda: o.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, inactive)
     push()
     o.init_assignments(5)
     o.build_counts()
     present = [c.D] * 3        # every view lists every entity (some with an empty FeatureSequence): totalDocsPerModality PTM:624
     max_type_count = [int(np.bincount(c.tokens[m], minlength=V[m]).max()) for m in range(3)]
+    hist_len = [int(np.diff(c.doc_off[m]).max()) + 1 for m in range(3)]
+    # the host mirror seeds its stand-ins for the reference's unseedable streams from randomSeed: samp <- seed+1, random <- seed
+    dp = dps.DPState(K, 3, hy.alpha, hy.gamma)
+    statics, samp, rnd = dps.StaticSamplers(), dps.RandomSamplers(dps.JavaRandom(6)), dps.JavaRandom(5)
     ll_at_10 = None
+    n_opt = 0
     for it in range(1, 11):
         if it < 2:
             hy.p_a[:] = min(it / 100 + 0.3, 1.1)
         elif it > 2 and it % 2 == 0:
+            n_opt += 1
             sums = o.optimize_p_sums()                                   # PTM:2784-2812
             for m in range(3):
                 for i in range(m + 1, 3):
@@ -131,21 +141,43 @@ def test_estimate_with_optimize_steps_matches_oracle_schedule():
                     a = 5000 if pmean == 1 else -1.0 / math.log(pmean)
                     hy.p_a[m, i] = hy.p_a[i, m] = min(a, 100.0)
                     hy.p_b[m, i] = hy.p_b[i, m] = 1.0
+            hists = [o.get_doc_topic_hist(m, hist_len[m], hist_len[m]) for m in range(3)]
+            dp.alpha = [list(map(float, a)) for a in hy.alpha]; dp.gamma = list(map(float, hy.gamma))
+            dp.inactive = set(np.flatnonzero(inactive).tolist())
+            dps.optimize_dp(dp, [h[0] for h in hists], statics, rnd)     # PTM:1184
+            dps.optimize_gamma(dp, [h[1] for h in hists], samp)         # PTM:1185
+            hy.alpha[:] = np.array(dp.alpha); hy.alpha_sum[:] = dp.alphaSum; hy.gamma[:] = dp.gamma
+            inactive[:] = 0; inactive[sorted(dp.inactive)] = 1
             for m in range(3):                                           # PTM:2293-2366
                 b, bs = o.optimize_beta(m, max_type_count[m])
                 hy.beta[m], hy.beta_sum[m] = b, bs
         push()
-        o.sweep(it, 5)
+        r = o.sweep(it, 5)
+        if r["stats"]["activated_topic"] >= 0:                           # UPD:263-270 changed alpha / the inactive set
+            hy.alpha[:] = o.get_alpha(); inactive[:] = o.get_inactive()
         if it == 10:
             ll_at_10 = o.model_log_likelihood()
+    assert n_opt == 4
     model.estimate()
     for m in range(3):
         assert np.array_equal(model.get_view(m)[3], o.get_assignments(m)), f"assignments differ in view {m}"
         a, b = model.get_counts(m)
         assert np.array_equal(a, o.get_counts(m)[0]) and np.array_equal(b, o.get_counts(m)[1])
-    # beta moved away from its initial value and is what the oracle computed
+    # one more round of every step, state read back: same numbers as the oracle's next round
     pa, pm = model.optimizeP()
+    alpha, asum, ina, tables = model.optimizeDP()
+    g, gv, groot = model.optimizeGamma()
     bb, bbs = model.optimizeBeta()
+    hists = [o.get_doc_topic_hist(m, hist_len[m], hist_len[m]) for m in range(3)]
+    dp.alpha = [list(map(float, a)) for a in hy.alpha]; dp.gamma = list(map(float, hy.gamma))
+    dp.inactive = set(np.flatnonzero(inactive).tolist())
+    dps.optimize_dp(dp, [h[0] for h in hists], statics, rnd)
+    assert np.array_equal(alpha, np.array(dp.alpha)) and np.array_equal(asum, np.array(dp.alphaSum))
+    assert set(np.flatnonzero(ina).tolist()) == dp.inactive
+    assert tables.tolist() == dp.tablesCnt + [dp.rootTablesCnt]
+    dps.optimize_gamma(dp, [h[1] for h in hists], samp)
+    assert g.tolist() == dp.gamma and gv.tolist() == dp.gammaView and groot == dp.gammaRoot
+    assert np.all(g > 0) and np.all(g != 1.0) and abs(asum.sum() - 3) < 1e-9      # each view's alpha is a Dirichlet mean
     for m in range(3):
         ob, obs = o.optimize_beta(m, max_type_count[m])
         assert bb[m] == ob and bbs[m] == obs
