@@ -47,7 +47,7 @@ struct mvhdp_ctx {
     int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
     int32_t* d_overflow = nullptr;           // [D] entities handed from the primary register-resident variant to the next pass
     int32_t* d_overflow2 = nullptr;          // [D] entities that exceed even the 16-slot variant: generic LDS kernel
-    unsigned int* d_ovf_meta = nullptr;      // u32 overflow counts of pass 1 and 2, then at byte 8: u64[17] tokens by ceil(topic list/64)
+    unsigned int* d_ovf_meta = nullptr;      // u32 overflow counts of pass 1 and 2, at byte 8: u64[17] tokens by ceil(topic list/64), then the count of pass 3
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
     size_t lds_attr_set = 0;
 };
@@ -77,7 +77,7 @@ static int rmax_from_hist(const unsigned long long* hist)
         for (int b = 0; b < MVHDP_HIST_BINS; b++) {
             const double t = (double)hist[b];
             if (b + 1 <= variants[v]) c += t * cost[v];
-            else c += t * (0.02 * cost[v] + (b + 1 <= 16 ? cost[4] : cost_generic));   // prologue in pass 1 + the later pass
+            else c += t * (0.02 * cost[v] + (b + 1 <= 8 ? cost[3] : (b + 1 <= 16 ? cost[4] : cost_generic)));   // prologue in pass 1 + the later pass
         }
         if (c < best_cost) { best_cost = c; best = variants[v]; }
     }
@@ -533,8 +533,15 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             while (rmax > 1 && 64 * (rmax / 2) >= S_cap) rmax /= 2;          // no larger than the corpus can need
         }
     }
-    // second pass for entities beyond the primary variant: the 16-slot variant when it can hold more
-    const bool second_fast = fast && rmax < 16 && S_cap > 64 * rmax;
+    // Passes of the register-resident kernel: the primary variant over every entity, then the 8- and
+    // 16-round variants over what did not fit (each only when the corpus can need it); what exceeds
+    // 1024 slots ends in the generic LDS kernel.
+    int chain[3] = {0, 0, 0}, n_chain = 0;
+    if (fast) {
+        chain[n_chain++] = rmax;
+        if (rmax < 8 && S_cap > 64 * rmax) chain[n_chain++] = 8;
+        if (rmax < 16 && S_cap > 512) chain[n_chain++] = 16;
+    }
     struct Geo { uint32_t wave_bytes; int wpb; size_t lds; int grid; };
     auto geometry = [&](bool is_fast, int r, Geo& g) -> int {
         // a register-resident variant never holds more than 64*r slots (longer lists overflow before any slot write)
@@ -549,7 +556,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * bpc));
         return MVHDP_OK;
     };
-    Geo gen{}, fst{}, fst2{};
+    Geo gen{}, fst[3] = {};
     {
         // the generic kernel may need > 64 KiB of dynamic LDS
         uint32_t wb = (uint32_t)mvhdp_sweep_wave_bytes(M, S_cap);
@@ -560,13 +567,14 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         if (lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
     }
     if (geometry(false, 0, gen) != MVHDP_OK) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB");
-    if (fast && geometry(true, rmax, fst) != MVHDP_OK) fast = false;
-    bool use_second = second_fast && fast && geometry(true, 16, fst2) == MVHDP_OK;
+    if (fast && geometry(true, rmax, fst[0]) != MVHDP_OK) { fast = false; n_chain = 0; }
+    for (int p = 1; p < n_chain; p++)
+        if (geometry(true, chain[p], fst[p]) != MVHDP_OK) { n_chain = p; break; }     // later passes fall to the generic kernel
     if (fast && !h->d_overflow && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow, (size_t)mm.D * sizeof(int32_t)));
-    if (use_second && !h->d_overflow2 && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow2, (size_t)mm.D * sizeof(int32_t)));
+    if (n_chain > 1 && !h->d_overflow2 && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow2, (size_t)mm.D * sizeof(int32_t)));
     if (getenv("MVHDP_DEBUG"))
-        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) second16=%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
-                sweep_idx, (int)fast, rmax, h->rmax_hint, (int)use_second, S_cap, fst.grid, fst.wpb, fst.lds, gen.grid, gen.wpb, gen.lds);
+        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) chain=%d,%d,%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
+                sweep_idx, (int)fast, rmax, h->rmax_hint, chain[0], chain[1], chain[2], S_cap, fst[0].grid, fst[0].wpb, fst[0].lds, gen.grid, gen.wpb, gen.lds);
     sl.stats = h->d_stats;
     sl.act_key = h->d_act_key;
     sl.doc_counter = h->d_doc_counter;
@@ -626,34 +634,35 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     step(hipMemsetAsync(h->d_ovf_meta, 0, 256, s));
     step(hipEventRecord(h->ev[1], s));
     unsigned long long ovf[1 + MVHDP_HIST_BINS] = {0};      // [0]: two u32 overflow counts, [1..17]: token histogram
-    auto overflow_count = [&](int which, unsigned int& n) {
-        unsigned int c[2] = {0, 0};
-        step(hipMemcpyAsync(c, h->d_ovf_meta, sizeof c, hipMemcpyDeviceToHost, s));
+    // overflow counters of the passes: u32 words 0, 1 and 36 of d_ovf_meta (the histogram sits in between)
+    static const int ovf_word[3] = {0, 1, 2 + 2 * MVHDP_HIST_BINS};
+    auto overflow_count = [&](int pass, unsigned int& n) {
+        unsigned int c = 0;
+        step(hipMemcpyAsync(&c, h->d_ovf_meta + ovf_word[pass], sizeof c, hipMemcpyDeviceToHost, s));
         step(hipStreamSynchronize(s));
-        n = c[which];
+        n = c;
     };
     if (e == hipSuccess && mm.D > 0) {
         if (fast) {
-            // pass 1: the primary register-resident variant over every entity
-            sl.wave_bytes = fst.wave_bytes; sl.waves_per_block = fst.wpb;
-            sl.S_cap = std::min(S_cap, 64 * rmax);
-            step(mvhdp_launch_sweep_fast(mm, sl, rmax, fst.grid, debug, s));
-            unsigned int n1 = 0, n2 = 0;
-            overflow_count(0, n1);
-            const int32_t* list = h->d_overflow;
-            unsigned int nlist = n1;
-            if (e == hipSuccess && n1 > 0 && use_second) {
-                // pass 2: the same sweep with the 16-slot variant over the entities that did not fit
-                MvModel m2 = mm; m2.D = (int64_t)n1;
-                SweepLaunch s2 = sl;
-                s2.doc_order = h->d_overflow; s2.overflow_list = h->d_overflow2; s2.overflow_count = h->d_ovf_meta + 1;
-                s2.slot_hist = nullptr;
-                s2.wave_bytes = fst2.wave_bytes; s2.waves_per_block = fst2.wpb; s2.S_cap = std::min(S_cap, 1024);
-                step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
-                int64_t need = ((int64_t)n1 + (int64_t)fst2.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)fst2.wpb * MVHDP_DOC_BATCH);
-                step(mvhdp_launch_sweep_fast(m2, s2, 16, (int)std::min<int64_t>(need, fst2.grid), debug, s));
-                overflow_count(1, n2);
-                list = h->d_overflow2; nlist = n2;
+            const int32_t* list = nullptr;                  // entities of the current pass (nullptr: all, in work-queue order)
+            unsigned int nlist = 0;
+            for (int p = 0; p < n_chain && e == hipSuccess; p++) {
+                MvModel mp = mm;
+                SweepLaunch sp = sl;
+                int32_t* out = (p & 1) ? h->d_overflow2 : h->d_overflow;
+                if (p > 0) {
+                    mp.D = (int64_t)nlist;
+                    sp.doc_order = list; sp.slot_hist = nullptr;
+                    step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
+                }
+                sp.overflow_list = out; sp.overflow_count = h->d_ovf_meta + ovf_word[p];
+                sp.wave_bytes = fst[p].wave_bytes; sp.waves_per_block = fst[p].wpb;
+                sp.S_cap = std::min(S_cap, 64 * chain[p]);
+                int64_t need = (mp.D + (int64_t)fst[p].wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)fst[p].wpb * MVHDP_DOC_BATCH);
+                step(mvhdp_launch_sweep_fast(mp, sp, chain[p], (int)std::max<int64_t>(1, std::min<int64_t>(need, fst[p].grid)), debug, s));
+                overflow_count(p, nlist);
+                list = out;
+                if (nlist == 0) break;
             }
             if (e == hipSuccess && nlist > 0) {
                 // last pass: topic lists beyond the register variants, generic LDS kernel

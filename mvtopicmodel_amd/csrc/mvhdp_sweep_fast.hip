@@ -212,38 +212,59 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
                 int znew_l = z_l;
                 const int nt = min(WAVE, lenm - c0);
 
-                // software pipeline: n_wk values of the listed topics for the next token, and the top of
-                // its F+tree (tree[1..63], node n in lane n-1: the root for WRK:519 and five levels of FT:122)
+                // FT:118-132 for the whole chunk, one lane per token.  The trees do not change during a
+                // sweep and u2 belongs to the token, so the topic the tree branch WOULD return (WRK:533-535)
+                // does not depend on the entity's state: every lane walks its own word's tree here, 64
+                // dependent-load chains in flight at once, and the sequential loop below only picks the
+                // result up.  root_l = tree[1] (WRK:519), zt_l = the sampled topic, st_l = its slot or -1.
+                double root_l = 0.0;
+                int zt_l = -1, st_l = -1;
+                {
+                    const bool act = tvalid && w_l >= 0;
+                    const double* __restrict__ tr = mm.trees + (row0 + max(w_l, 0)) * 2 * K;
+                    if (act) root_l = tr[1];
+                    double u = u2_l * root_l;                                // FT:120
+                    int i = 1;
+                    while (__builtin_amdgcn_ballot_w64(act && i < K)) {      // FT:122
+                        if (act && i < K) {
+                            const double l = tr[2 * i];
+                            if (u < l) i = 2 * i;                            // FT:124-125
+                            else { u = u - l; i = 2 * i + 1; }               // FT:127-128
+                        }
+                    }
+                    if (act) {
+                        zt_l = i - K;                                        // FT:132
+                        const uint32_t wbit = bitmap[zt_l >> 5];
+                        if ((wbit >> (zt_l & 31)) & 1u) st_l = (int)(prefix[zt_l >> 5] + __popc(wbit & ((1u << (zt_l & 31)) - 1u)));
+                    }
+                }
+
+                // software pipeline: n_wk values of the listed topics for the next token
                 int gn[RMAX];
-                double tvn;
-                const bool tlane = (lane + 1) < 2 * K && lane < 63;
                 {
                     const int w0 = bcast_i(w_l, 0);
                     const int64_t r0 = row0 + max(w0, 0);
                     const char* __restrict__ c0p = (const char*)(nwk + r0 * K);
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
-                    tvn = tlane ? mm.trees[r0 * 2 * K + lane + 1] : 0.0;
                 }
 
                 for (int t = 0; t < nt; t++) {                              // WRK:425
                     int g[RMAX];
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) g[r] = gn[r];
-                    const double tv = tvn;
                     if (t + 1 < nt) {
                         const int wn = bcast_i(w_l, t + 1);
                         const int64_t rn = row0 + max(wn, 0);
                         const char* __restrict__ cnp = (const char*)(nwk + rn * K);
 #pragma unroll
                         for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? *(const int32_t*)(cnp + koff[r]) : 0;
-                        tvn = tlane ? mm.trees[rn * 2 * K + lane + 1] : 0.0;
                     }
                     const int w = bcast_i(w_l, t);
                     if (w < 0) { n_oov++; continue; }                       // WRK:427-428
                     const int so = bcast_i(so_l, t);
                     const double u1 = bcast_d(u1_l, t);
-                    const double root = bcast_d(tv, 0);                      // tree[1]
+                    const double root = bcast_d(root_l, t);                  // tree[1]
                     const int64_t row = row0 + w;
 
                     // WRK:434-468 decrement the local count; drop the topic when it is gone from all views
@@ -385,14 +406,15 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
                         znew = bcast_i(ksel, ln);
                     } else {                                                 // WRK:533-535
                         c_tree++;
-                        znew = tree_sample_preloaded(mm.trees + row * 2 * K, K, bcast_d(u2_l, t), tv, lane);
+                        znew = bcast_i(zt_l, t);
+                        slot_new = bcast_i(st_l, t);
                     }
                     if (znew < 0) znew = K - 1;                              // WRK:549-552
                     znew = uniform_i(znew);
 
                     // WRK:557-560
                     if (lane == t) znew_l = znew;
-                    if (branch != 1) {
+                    if (branch == 0) {
                         uint32_t wbit = bitmap[znew >> 5];
                         slot_new = ((wbit >> (znew & 31)) & 1u) ? (int)(prefix[znew >> 5] + __popc(wbit & ((1u << (znew & 31)) - 1u))) : -1;
                         slot_new = uniform_i(slot_new);
