@@ -6,6 +6,7 @@
 #include "../../include/mvhdp.h"
 
 #include <algorithm>
+#include <functional>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -48,6 +49,11 @@ struct mvhdp_ctx {
     int32_t* d_overflow = nullptr;           // [D] entities handed from the primary register-resident variant to the next pass
     int32_t* d_overflow2 = nullptr;          // [D] entities that exceed even the 16-slot variant: generic LDS kernel
     unsigned int* d_ovf_meta = nullptr;      // u32 overflow counts of pass 1 and 2, at byte 8: u64[17] tokens by ceil(topic list/64), then the count of pass 3
+    int32_t* d_lists = nullptr;              // classified mode: [MVHDP_N_CLASSES][D] entity lists written by classify_kernel
+    hipStream_t side[MVHDP_N_CLASSES]{};     // one stream per wider kernel class (created on first use)
+    hipEvent_t ev_fork = nullptr, ev_join[MVHDP_N_CLASSES]{};
+    std::vector<int64_t> tokens_desc;        // entity token counts, descending (the order of d_doc_order)
+    unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class, from the last sweep (or the probe)
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
     size_t lds_attr_set = 0;
 };
@@ -143,8 +149,8 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMemset(h->d_inactive, 0, (size_t)K));
     CREATE_HIP(hipMalloc(&h->d_stats, ST_COUNT * sizeof(unsigned long long)));
     CREATE_HIP(hipMalloc(&h->d_act_key, sizeof(long long)));
-    CREATE_HIP(hipMalloc(&h->d_doc_counter, sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 256));
+    CREATE_HIP(hipMalloc(&h->d_doc_counter, 8 * sizeof(unsigned long long)));     // one work-queue head per kernel class
+    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 256));                                       // see META_* below
     mm.alpha = h->d_alpha;
     mm.inactive = h->d_inactive;
     h->h_alpha.assign((size_t)M * (K + 1), 0.0);
@@ -178,6 +184,10 @@ extern "C" int mvhdp_destroy(mvhdp_handle h)
     if (h->d_overflow2) hipFree(h->d_overflow2);
     if (h->d_ovf_meta) hipFree(h->d_ovf_meta);
     for (auto& e : h->ev) if (e) hipEventDestroy(e);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (auto& e : h->ev_join) if (e) hipEventDestroy(e);
+    for (auto& st : h->side) if (st) hipStreamDestroy(st);
+    if (h->d_lists) hipFree(h->d_lists);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return MVHDP_OK;
@@ -240,6 +250,7 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
     if (h->d_overflow) { hipFree(h->d_overflow); h->d_overflow = nullptr; }
     if (h->d_overflow2) { hipFree(h->d_overflow2); h->d_overflow2 = nullptr; }
+    if (h->d_lists) { hipFree(h->d_lists); h->d_lists = nullptr; }
     h->rmax_hint = 0;
     mm.D = D;
     mm.doc_off[m] = (const int64_t*)h->d_doc_off[m];
@@ -443,17 +454,21 @@ static int64_t compute_max_doc_tokens(mvhdp_ctx* h)
         mx = std::max(mx, t); mn = std::min(mn, t);
     }
     if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
-    if (mm.D > 0 && mx > 4 * std::max<int64_t>(mn, 16) && mm.D < (1LL << 31)) {
+    h->tokens_desc.clear();
+    if (mm.D > 0 && mm.D < (1LL << 31)) {
         // counting sort by decreasing length (stable: ties keep entity order)
         std::vector<int64_t> start((size_t)mx + 2, 0);
         for (int64_t d = 0; d < mm.D; d++) start[(size_t)(mx - tot[d]) + 1]++;
         for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
         std::vector<int32_t> order((size_t)mm.D);
         for (int64_t d = 0; d < mm.D; d++) order[(size_t)start[(size_t)(mx - tot[d])]++] = (int32_t)d;
-        if (hipMalloc(&h->d_doc_order, (size_t)mm.D * sizeof(int32_t)) == hipSuccess)
+        if (hipMalloc(&h->d_doc_order, (size_t)mm.D * sizeof(int32_t)) == hipSuccess) {
             hipMemcpy(h->d_doc_order, order.data(), (size_t)mm.D * sizeof(int32_t), hipMemcpyHostToDevice);
-        else h->d_doc_order = nullptr;
+            h->tokens_desc.resize((size_t)mm.D);
+            for (int64_t q = 0; q < mm.D; q++) h->tokens_desc[(size_t)q] = tot[(size_t)order[(size_t)q]];
+        } else h->d_doc_order = nullptr;
     }
+    (void)mn;
     h->max_doc_tokens = mx;
     return mx;
 }
@@ -523,6 +538,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             HIPC(h, mvhdp_launch_slot_hist(mm, (unsigned long long*)(h->d_ovf_meta + 2), h->stream));
             HIPC(h, hipMemcpyAsync(hist, h->d_ovf_meta, sizeof hist, hipMemcpyDeviceToHost, h->stream));
             HIPC(h, hipStreamSynchronize(h->stream));
+            std::copy(hist + 1, hist + 1 + MVHDP_HIST_BINS, h->last_hist);
             h->rmax_hint = rmax_from_hist(hist + 1);
         }
         rmax = h->rmax_hint;
@@ -533,19 +549,39 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             while (rmax > 1 && 64 * (rmax / 2) >= S_cap) rmax /= 2;          // no larger than the corpus can need
         }
     }
-    // Passes of the register-resident kernel: the primary variant over every entity, then the 8- and
-    // 16-round variants over what did not fit (each only when the corpus can need it); what exceeds
-    // 1024 slots ends in the generic LDS kernel.
+    // Two ways to deal with the entities whose topic list exceeds the primary variant's 64*rmax slots.
+    //  * optimistic (few of them): the primary kernel runs over every entity and appends the ones that do
+    //    not fit to an overflow list; the 8-round, the 16-round and the generic kernel then take the rest,
+    //    one pass after another.
+    //  * classified (many of them, e.g. power-law lengths with K = 1000): only an entity with more tokens
+    //    than slots can overflow -- a static prefix of the longest-first order.  classify_kernel measures
+    //    that prefix and lists every entity for the narrowest kernel that holds it; the kernels of all
+    //    classes then run side by side on their own streams, the widest (longest entities) first, so the
+    //    long sequential chains overlap the bulk instead of following it.
+    int pc = 0;                                              // class of the primary variant: rmax == 1 << pc
+    while ((1 << pc) < rmax) pc++;
+    int64_t H = 0;                                           // entities that may exceed the primary variant
+    bool classified = false;
+    if (fast && h->d_doc_order && !h->tokens_desc.empty()) {
+        H = std::upper_bound(h->tokens_desc.begin(), h->tokens_desc.end(), (int64_t)64 * rmax, std::greater<int64_t>()) - h->tokens_desc.begin();
+        double tot = 0, beyond = 0;
+        for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b + 1 > rmax) beyond += (double)h->last_hist[b]; }
+        classified = H > 0 && beyond > 0.005 * tot;
+        if (const char* f = getenv("MVHDP_FORCE_MODE")) {                 // diagnostics / tests
+            if (!strcmp(f, "classified")) classified = H > 0;
+            else if (!strcmp(f, "optimistic")) classified = false;
+        }
+    }
     int chain[3] = {0, 0, 0}, n_chain = 0;
-    if (fast) {
+    if (fast && !classified) {
         chain[n_chain++] = rmax;
         if (rmax < 8 && S_cap > 64 * rmax) chain[n_chain++] = 8;
         if (rmax < 16 && S_cap > 512) chain[n_chain++] = 16;
     }
     struct Geo { uint32_t wave_bytes; int wpb; size_t lds; int grid; };
     auto geometry = [&](bool is_fast, int r, Geo& g) -> int {
-        // a register-resident variant never holds more than 64*r slots (longer lists overflow before any slot write)
-        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, std::min(S_cap, 64 * r)) : mvhdp_sweep_wave_bytes(M, S_cap));
+        // a register-resident variant never holds more than 64*r slots (longer lists are diverted before any slot write)
+        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, std::min(S_cap, 64 * r), r) : mvhdp_sweep_wave_bytes(M, S_cap));
         g.wpb = 4;
         while (g.wpb > 1 && sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes > h->max_lds) g.wpb >>= 1;
         g.lds = sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes;
@@ -556,7 +592,8 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * bpc));
         return MVHDP_OK;
     };
-    Geo gen{}, fst[3] = {};
+    Geo gen{}, fst[3] = {}, cls[MVHDP_N_CLASSES] = {};
+    bool cls_fast[MVHDP_N_CLASSES] = {};
     {
         // the generic kernel may need > 64 KiB of dynamic LDS
         uint32_t wb = (uint32_t)mvhdp_sweep_wave_bytes(M, S_cap);
@@ -567,21 +604,35 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         if (lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
     }
     if (geometry(false, 0, gen) != MVHDP_OK) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB");
-    if (fast && geometry(true, rmax, fst[0]) != MVHDP_OK) { fast = false; n_chain = 0; }
+    if (fast && geometry(true, rmax, fst[0]) != MVHDP_OK) { fast = false; classified = false; n_chain = 0; }
     for (int p = 1; p < n_chain; p++)
         if (geometry(true, chain[p], fst[p]) != MVHDP_OK) { n_chain = p; break; }     // later passes fall to the generic kernel
-    if (fast && !h->d_overflow && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow, (size_t)mm.D * sizeof(int32_t)));
-    if (n_chain > 1 && !h->d_overflow2 && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow2, (size_t)mm.D * sizeof(int32_t)));
+    if (classified) {
+        cls[pc] = fst[0]; cls_fast[pc] = true;
+        for (int c = pc + 1; c < MVHDP_N_CLASSES; c++) {
+            cls_fast[c] = c < 5 && geometry(true, 1 << c, cls[c]) == MVHDP_OK;
+            if (!cls_fast[c]) cls[c] = gen;                                           // no room for that variant: generic kernel
+        }
+        if (!h->d_lists) HIPC(h, hipMalloc(&h->d_lists, (size_t)MVHDP_N_CLASSES * mm.D * sizeof(int32_t)));
+        if (!h->ev_fork) HIPC(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    } else if (fast) {
+        if (!h->d_overflow && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow, (size_t)mm.D * sizeof(int32_t)));
+        if (n_chain > 1 && !h->d_overflow2 && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow2, (size_t)mm.D * sizeof(int32_t)));
+    }
     if (getenv("MVHDP_DEBUG"))
-        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) chain=%d,%d,%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
-                sweep_idx, (int)fast, rmax, h->rmax_hint, chain[0], chain[1], chain[2], S_cap, fst[0].grid, fst[0].wpb, fst[0].lds, gen.grid, gen.wpb, gen.lds);
+        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) %s H=%lld chain=%d,%d,%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
+                sweep_idx, (int)fast, rmax, h->rmax_hint, classified ? "classified" : "optimistic", (long long)H, chain[0], chain[1], chain[2], S_cap,
+                fst[0].grid, fst[0].wpb, fst[0].lds, gen.grid, gen.wpb, gen.lds);
     sl.stats = h->d_stats;
     sl.act_key = h->d_act_key;
+    // d_ovf_meta (u32 words): 0,1 = overflow counts of passes 1,2; 2..35 = u64 hist[17]; 36 = overflow count of pass 3;
+    // 40..45 = entities per class (classified mode)
+    unsigned int* class_counts = h->d_ovf_meta + 40;
     sl.doc_counter = h->d_doc_counter;
-    sl.doc_order = h->d_doc_order;
-    sl.overflow_list = h->d_overflow;
-    sl.overflow_count = h->d_ovf_meta;
-    sl.slot_hist = (unsigned long long*)(h->d_ovf_meta + 2);     // first pass only
+    sl.q_list = nullptr; sl.q_list_count = nullptr;
+    sl.q_order = h->d_doc_order; sl.q_order_start = 0; sl.q_order_count = mm.D;      // default: every entity, longest first
+    sl.overflow_list = nullptr; sl.overflow_count = nullptr;
+    sl.slot_hist = (unsigned long long*)(h->d_ovf_meta + 2);
 
     // debug buffers
     std::vector<void*> to_free;
@@ -630,11 +681,9 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     step(hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
     const long long kmax = LLONG_MAX;
     step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
-    step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
     step(hipMemsetAsync(h->d_ovf_meta, 0, 256, s));
     step(hipEventRecord(h->ev[1], s));
     unsigned long long ovf[1 + MVHDP_HIST_BINS] = {0};      // [0]: two u32 overflow counts, [1..17]: token histogram
-    // overflow counters of the passes: u32 words 0, 1 and 36 of d_ovf_meta (the histogram sits in between)
     static const int ovf_word[3] = {0, 1, 2 + 2 * MVHDP_HIST_BINS};
     auto overflow_count = [&](int pass, unsigned int& n) {
         unsigned int c = 0;
@@ -642,37 +691,90 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         step(hipStreamSynchronize(s));
         n = c;
     };
+    auto blocks_for = [&](int64_t n, const Geo& g) {
+        int64_t need = (n + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
+        return (int)std::max<int64_t>(1, std::min<int64_t>(need, g.grid));
+    };
+    step(hipMemsetAsync(h->d_doc_counter, 0, 8 * sizeof(unsigned long long), s));
     if (e == hipSuccess && mm.D > 0) {
-        if (fast) {
-            const int32_t* list = nullptr;                  // entities of the current pass (nullptr: all, in work-queue order)
+        if (classified) {
+            ClassifyArgs ca{};
+            ca.order = h->d_doc_order; ca.n = H; ca.primary = pc; ca.counts = class_counts;
+            for (int c = 0; c < MVHDP_N_CLASSES; c++) ca.lists[c] = h->d_lists + (size_t)c * mm.D;
+            step(mvhdp_launch_classify(mm, ca, s));
+            step(hipEventRecord(h->ev_fork, s));
+            // Streams: the generic and the 16-round class share side stream 4, the 8-round class has side
+            // stream 3 (the runtime multiplexes streams onto few hardware queues: more side streams only
+            // serialise behind each other); narrower classes run on the sweep's own stream ahead of the primary.
+            bool used[MVHDP_N_CLASSES] = {};
+            for (int c = MVHDP_N_CLASSES - 1; c > pc && e == hipSuccess; c--) {       // widest first
+                if (S_cap <= (32 << c)) continue;            // class c holds lists of more than 32 << c topics: not in this corpus
+                const int si = (c >= 4) ? 4 : c;
+                hipStream_t st = s;
+                if (c >= 3) {
+                    if (!h->side[si]) step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
+                    if (!h->ev_join[si]) step(hipEventCreateWithFlags(&h->ev_join[si], hipEventDisableTiming));
+                    if (e != hipSuccess) break;
+                    if (!used[si]) step(hipStreamWaitEvent(h->side[si], h->ev_fork, 0));
+                    used[si] = true;
+                    st = h->side[si];
+                }
+                SweepLaunch sc = sl;
+                sc.q_list = ca.lists[c]; sc.q_list_count = class_counts + c;
+                sc.q_order = nullptr; sc.q_order_start = 0; sc.q_order_count = 0;
+                sc.doc_counter = h->d_doc_counter + c;
+                sc.wave_bytes = cls[c].wave_bytes; sc.waves_per_block = cls[c].wpb;
+                if (cls_fast[c]) {
+                    sc.S_cap = std::min(S_cap, 64 << c);
+                    step(mvhdp_launch_sweep_fast(mm, sc, 1 << c, blocks_for(H, cls[c]), debug, st));
+                } else {
+                    sc.S_cap = S_cap;
+                    step(mvhdp_launch_sweep(mm, sc, blocks_for(H, cls[c]), debug, st));
+                }
+            }
+            for (int si = 0; si < MVHDP_N_CLASSES; si++) if (used[si]) step(hipEventRecord(h->ev_join[si], h->side[si]));
+            if (e == hipSuccess) {
+                // the primary variant: the measured entities that fit it, then everything too short to overflow
+                SweepLaunch sp = sl;
+                sp.q_list = ca.lists[pc]; sp.q_list_count = class_counts + pc;
+                sp.q_order = h->d_doc_order; sp.q_order_start = H; sp.q_order_count = mm.D - H;
+                sp.doc_counter = h->d_doc_counter + pc;
+                sp.wave_bytes = fst[0].wave_bytes; sp.waves_per_block = fst[0].wpb;
+                sp.S_cap = std::min(S_cap, 64 * rmax);
+                step(mvhdp_launch_sweep_fast(mm, sp, rmax, fst[0].grid, debug, s));
+            }
+            for (int si = 0; si < MVHDP_N_CLASSES; si++) if (used[si]) step(hipStreamWaitEvent(s, h->ev_join[si], 0));
+        } else if (fast) {
+            const int32_t* list = nullptr;                  // entities of the current pass (nullptr: all, longest first)
             unsigned int nlist = 0;
             for (int p = 0; p < n_chain && e == hipSuccess; p++) {
-                MvModel mp = mm;
                 SweepLaunch sp = sl;
                 int32_t* out = (p & 1) ? h->d_overflow2 : h->d_overflow;
+                int64_t n_pass = mm.D;
                 if (p > 0) {
-                    mp.D = (int64_t)nlist;
-                    sp.doc_order = list; sp.slot_hist = nullptr;
-                    step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
+                    n_pass = (int64_t)nlist;
+                    sp.q_list = list; sp.q_list_count = h->d_ovf_meta + ovf_word[p - 1];
+                    sp.q_order = nullptr; sp.q_order_start = 0; sp.q_order_count = 0;
+                    sp.doc_counter = h->d_doc_counter + p;
+                    sp.slot_hist = nullptr;                 // counted in pass 1 already
                 }
                 sp.overflow_list = out; sp.overflow_count = h->d_ovf_meta + ovf_word[p];
                 sp.wave_bytes = fst[p].wave_bytes; sp.waves_per_block = fst[p].wpb;
                 sp.S_cap = std::min(S_cap, 64 * chain[p]);
-                int64_t need = (mp.D + (int64_t)fst[p].wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)fst[p].wpb * MVHDP_DOC_BATCH);
-                step(mvhdp_launch_sweep_fast(mp, sp, chain[p], (int)std::max<int64_t>(1, std::min<int64_t>(need, fst[p].grid)), debug, s));
+                step(mvhdp_launch_sweep_fast(mm, sp, chain[p], blocks_for(n_pass, fst[p]), debug, s));
                 overflow_count(p, nlist);
                 list = out;
                 if (nlist == 0) break;
             }
             if (e == hipSuccess && nlist > 0) {
                 // last pass: topic lists beyond the register variants, generic LDS kernel
-                MvModel mo = mm; mo.D = (int64_t)nlist;
                 SweepLaunch so = sl;
-                so.doc_order = list; so.slot_hist = nullptr;
+                so.q_list = list; so.q_list_count = h->d_ovf_meta + ovf_word[n_chain - 1];
+                so.q_order = nullptr; so.q_order_start = 0; so.q_order_count = 0;
+                so.doc_counter = h->d_doc_counter + 4;
+                so.slot_hist = nullptr;
                 so.wave_bytes = gen.wave_bytes; so.waves_per_block = gen.wpb; so.S_cap = S_cap;
-                step(hipMemsetAsync(h->d_doc_counter, 0, sizeof(unsigned long long), s));
-                int64_t need = ((int64_t)nlist + (int64_t)gen.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)gen.wpb * MVHDP_DOC_BATCH);
-                step(mvhdp_launch_sweep(mo, so, (int)std::min<int64_t>(need, gen.grid), debug, s));
+                step(mvhdp_launch_sweep(mm, so, blocks_for((int64_t)nlist, gen), debug, s));
             }
         } else {
             sl.wave_bytes = gen.wave_bytes; sl.waves_per_block = gen.wpb;
@@ -690,9 +792,11 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         // next sweep: the smallest variant that leaves at most 0.5% of the entities to the overflow pass
         // (topic lists change slowly between sweeps); entities counted twice (overflow re-run) only
         // make the choice more conservative
+        std::copy(ovf + 1, ovf + 1 + MVHDP_HIST_BINS, h->last_hist);
         h->rmax_hint = rmax_from_hist(ovf + 1);
     }
     if (e != hipSuccess) { cleanup(); HIPC(h, e); }
+    if (hs[ST_MISCLASS]) { cleanup(); FAIL(h, MVHDP_ERR_HIP, "internal: an entity reached a sweep kernel variant that cannot hold its topic list"); }
 
     if (debug) {
         for (int m = 0; m < M; m++)

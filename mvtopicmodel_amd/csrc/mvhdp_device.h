@@ -40,12 +40,17 @@ struct SweepLaunch {
     uint32_t wave_bytes;               // per-wave LDS region
     unsigned long long* stats;         // [16] device counters
     long long* act_key;                // activation key (atomicMin)
-    unsigned long long* doc_counter;   // work queue head: waves pull entities in batches
-    const int32_t* doc_order;          // optional permutation (longest entities first), or nullptr
-    int32_t* overflow_list;            // entities whose topic list exceeds the register-resident kernel's slots
-    unsigned int* overflow_count;      //   (they are re-run by the generic kernel)
-    unsigned long long* slot_hist;     // [17] tokens of the entities with ceil(list size/64) = 1..16, >16 (sizes the next sweep's variant);
-                                       //      nullptr on the overflow passes
+    // Work queue: waves pull entities in batches from one head.  Queue position q maps to an entity through two
+    // segments: first the entities the classify pass listed for this kernel (q_list[0 .. *q_list_count)), then
+    // q_order_count entities of a static order (q_order[q_order_start + ..], or the identity when q_order is null).
+    unsigned long long* doc_counter;
+    const int32_t* q_list;
+    const unsigned int* q_list_count;  // device memory (written by classify_kernel earlier in stream order), or nullptr = 0
+    const int32_t* q_order;
+    int64_t q_order_start, q_order_count;
+    int32_t* overflow_list;            // optimistic mode: entities whose topic list exceeds this variant's slots are appended here
+    unsigned int* overflow_count;      //   and re-run by a wider kernel; nullptr in classified mode (an overflow is then an error)
+    unsigned long long* slot_hist;     // [17] tokens of the entities with ceil(list size/64) = 1..16, >16 (sizes the next sweep's variant)
     // debug
     double* tok_dbg[MVHDP_MAXM];
     int32_t n_trace;
@@ -54,7 +59,7 @@ struct SweepLaunch {
 };
 
 enum {
-    ST_TOKENS = 0, ST_CHANGED, ST_NEW, ST_DOC, ST_TREE, ST_OOV, ST_ABORT, ST_FALLBACK, ST_NEGATIVE, ST_COUNT
+    ST_TOKENS = 0, ST_CHANGED, ST_NEW, ST_DOC, ST_TREE, ST_OOV, ST_ABORT, ST_FALLBACK, ST_NEGATIVE, ST_MISCLASS, ST_COUNT
 };
 
 size_t mvhdp_sweep_wave_bytes(int M, int S_cap);
@@ -73,7 +78,17 @@ hipError_t mvhdp_launch_view_overlap(const MvModel& mm, double* out, hipStream_t
 hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
                                unsigned long long* nonzero, hipStream_t s);
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s);
-size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap);
+// Classes of the sweep kernels by topic-list size: 0..4 = the register-resident variants with 64 << c slots, 5 = the generic LDS kernel
+#define MVHDP_N_CLASSES 6
+struct ClassifyArgs {
+    const int32_t* order;              // entities to classify: order[0 .. n) (nullptr = identity)
+    int64_t n;
+    int32_t primary;                   // class of the primary kernel: narrower entities are listed there too
+    int32_t* lists[MVHDP_N_CLASSES];   // per class, capacity n
+    unsigned int* counts;              // [MVHDP_N_CLASSES]
+};
+hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipStream_t s);
+size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax);
 hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);
 int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes);
 int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes);

@@ -266,14 +266,18 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
+    const long long q_n1 = sl.q_list_count ? (long long)*sl.q_list_count : 0;
+    const long long q_total = q_n1 + sl.q_order_count;
     for (;;) {
       long long q0 = 0;
       if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)MVHDP_DOC_BATCH);
       q0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)q0);
-      if (q0 >= mm.D) break;
-      const long long q1 = (q0 + MVHDP_DOC_BATCH < mm.D) ? q0 + MVHDP_DOC_BATCH : mm.D;
+      if (q0 >= q_total) break;
+      const long long q1 = (q0 + MVHDP_DOC_BATCH < q_total) ? q0 + MVHDP_DOC_BATCH : q_total;
       for (long long q = q0; q < q1; q++) {
-        const int64_t d = sl.doc_order ? (int64_t)sl.doc_order[q] : (int64_t)q;
+        int64_t d;
+        if (q < q_n1) d = (int64_t)sl.q_list[q];
+        else { const int64_t o = sl.q_order_start + (q - q_n1); d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
         const int64_t dg = mm.doc_id_base + d;
 
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
@@ -746,6 +750,54 @@ hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, h
     int64_t blocks = (mm.D + 3) / 4;
     int grid = (int)(blocks < 4096 ? blocks : 4096);
     hipLaunchKernelGGL(slot_hist_kernel, dim3(grid), dim3(256), 0, s, mm, hist);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// classify: before a sweep, the entities that MAY hold more topics than the primary kernel variant
+// has slots (those with more tokens than slots: a static prefix of the longest-first order) are
+// measured -- the same bitmap count the sweep kernels start every entity with -- and listed for the
+// narrowest kernel that holds them.  The sweep kernels of all classes then run side by side, the
+// widest (longest entities) first, instead of one after another.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void classify_kernel(MvModel mm, ClassifyArgs ca)
+{
+    __shared__ uint32_t bm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < ca.n; q += wstride) {
+        const int64_t d = ca.order ? (int64_t)ca.order[q] : q;
+        bm[wave][lane] = 0;
+        LDS_FENCE();
+        int64_t longest = 0;
+        for (int m = 0; m < mm.M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            longest = (e - b > longest) ? e - b : longest;
+            for (int64_t i = b + lane; i < e; i += WAVE) {
+                int zz = mm.z[m][i];
+                if (zz >= 0) atomicOr(&bm[wave][zz >> 5], 1u << (zz & 31));
+            }
+        }
+        LDS_FENCE();
+        int cnt = __popc(bm[wave][lane]);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, WAVE);
+        if (lane == 0) {
+            int c = (cnt <= 64) ? 0 : (cnt <= 128) ? 1 : (cnt <= 256) ? 2 : (cnt <= 512) ? 3 : (cnt <= 1024) ? 4 : 5;
+            if (c < ca.primary) c = ca.primary;
+            if (c >= 3 && longest > 65535) c = 5;            // the 8- and 16-round variants count tokens per slot in 16 bits
+            ca.lists[c][atomicAdd(&ca.counts[c], 1u)] = (int32_t)d;
+        }
+        LDS_FENCE();
+    }
+}
+
+hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipStream_t s)
+{
+    if (ca.n <= 0) return hipSuccess;
+    int64_t blocks = (ca.n + 3) / 4;
+    int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, mm, ca);
     return hipGetLastError();
 }
 

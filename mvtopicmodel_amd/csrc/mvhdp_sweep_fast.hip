@@ -23,9 +23,13 @@
 #include "../../include/mvhdp.h"
 #include "mvhdp_wave.h"
 
-size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap)
+// The 8- and 16-round variants keep the per-view slot counts as 16-bit values (its kernel diverts an entity with
+// a view of more than 65535 tokens): 78 KB instead of 120 KB per block at K = 1000 with 5 views, i.e. the
+// two blocks per CU its 256 VGPRs allow.
+size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 {
-    size_t b = (size_t)(64 + 64 + 16 + S_cap + M * S_cap) * 4;
+    size_t counts = (size_t)M * S_cap * (rmax >= 8 ? 2 : 4);
+    size_t b = (size_t)(64 + 64 + 16 + S_cap) * 4 + counts;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -40,8 +44,11 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap)
 #ifndef MVHDP_LB4
 #define MVHDP_LB4 4
 #endif
+#ifndef MVHDP_LB8
+#define MVHDP_LB8 1          // 3 waves/SIMD (168 VGPRs) spills 100 B/lane and is 13 % slower on C5 than 2 waves at 199
+#endif
 template <int RMAX, bool DEBUG>
-__global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : 1))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : 1)))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -49,6 +56,9 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
     const int K = mm.K, M = mm.M, S = sl.S_cap;
     const int NW = (K + 31) >> 5;
     const bool exact_only = (sl.flags & MVHDP_SWEEP_EXACT_CHAIN) != 0;
+    // the wide variants hold the longest entities -- the sweep's critical path -- and share their SIMDs
+    // with the bulk kernel's waves: let the arbiter issue them first
+    if (RMAX >= 8) __builtin_amdgcn_s_setprio(3);
 
     int* nkd = (int*)smem;                                  // [M*K] n_k deltas of this block
     unsigned int* hist_s = (unsigned int*)(nkd + M * K);    // [MVHDP_HIST_BINS] tokens by topic-list size class
@@ -60,7 +70,10 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
     uint32_t* prefix = bitmap + 64;
     int* wlen = (int*)(prefix + 64);
     int* sk = wlen + 16;
+    constexpr bool PACK = RMAX >= 8;                       // per-view slot counts as 16-bit values
     int* sn = sk + S;
+#define sn_get(idx) (PACK ? (int)((const unsigned short*)sn)[(idx)] : sn[(idx)])
+#define sn_set(idx, v) do { if (PACK) ((unsigned short*)sn)[(idx)] = (unsigned short)(v); else sn[(idx)] = (v); } while (0)
 
     const int32_t* __restrict__ nwk = mm.counts;
     const int32_t* __restrict__ nk_all = mm.counts + mm.rowbase[M] * K;
@@ -69,14 +82,19 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
+    const long long q_n1 = sl.q_list_count ? (long long)*sl.q_list_count : 0;
+    const long long q_total = q_n1 + sl.q_order_count;
+    unsigned int n_misclass = 0;
     for (;;) {
       long long q0 = 0;
       if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)MVHDP_DOC_BATCH);
       q0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)q0);
-      if (q0 >= mm.D) break;
-      const long long q1 = (q0 + MVHDP_DOC_BATCH < mm.D) ? q0 + MVHDP_DOC_BATCH : mm.D;
+      if (q0 >= q_total) break;
+      const long long q1 = (q0 + MVHDP_DOC_BATCH < q_total) ? q0 + MVHDP_DOC_BATCH : q_total;
       for (long long q = q0; q < q1; q++) {
-        const int64_t d = sl.doc_order ? (int64_t)sl.doc_order[q] : (int64_t)q;
+        int64_t d;
+        if (q < q_n1) d = (int64_t)sl.q_list[q];
+        else { const int64_t o = sl.q_order_start + (q - q_n1); d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
         const int64_t dg = mm.doc_id_base + d;
 
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
@@ -106,8 +124,12 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
         // slots per lane: 1, 2 or 4 consecutive slots (slot i = lane*R_eff + r)
         const int lg = (S_used <= 64) ? 0 : (S_used <= 128) ? 1 : (S_used <= 256) ? 2 : (S_used <= 512) ? 3 : 4;
         const int R_eff = 1 << lg;
-        if (S_used > 1024 || R_eff > RMAX) {                                // too many topics for this variant:
-            if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;   // the generic kernel takes it
+        bool too_long = false;
+        if (PACK) for (int m = 0; m < M; m++) too_long |= wlen[m] > 65535;
+        if (S_used > 1024 || R_eff > RMAX || too_long) {                    // too many topics (or tokens) for this variant
+            if (sl.overflow_list) {                                         // optimistic mode: a wider kernel re-runs it
+                if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;
+            } else n_misclass++;                                            // classified mode: cannot happen; the host fails the sweep
             continue;
         }
         for (int k0 = 0; k0 < K; k0 += WAVE) {
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
             }
         }
         for (int m = 0; m < M; m++)
-            for (int i = lane; i < S_used; i += WAVE) sn[m * S + i] = 0;
+            for (int i = lane; i < S_used; i += WAVE) sn_set(m * S + i, 0);
         LDS_FENCE();
         for (int m = 0; m < M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
@@ -127,7 +149,8 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
                 if (zz >= 0) {
                     uint32_t w = bitmap[zz >> 5];
                     int slot = prefix[zz >> 5] + __popc(w & ((1u << (zz & 31)) - 1u));
-                    atomicAdd(&sn[m * S + slot], 1);                       // WRK:357
+                    if (PACK) { const int idx = m * S + slot; atomicAdd((unsigned int*)&sn[idx >> 1], 1u << ((idx & 1) * 16)); }
+                    else atomicAdd(&sn[m * S + slot], 1);                  // WRK:357
                 }
             }
         }
@@ -161,11 +184,11 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
                 const int i = lane * R_eff + r;
                 if (r < R_eff && i < S_used) {
                     const int k = skr[r] & 0x7fffffff;
-                    cn[r] = sn[m * S + i];
+                    cn[r] = sn_get(m * S + i);
                     double acc = 0.0;
                     for (int j = 0; j < M; j++) {
                         if (j == m) continue;
-                        const int cj = sn[j * S + i];
+                        const int cj = sn_get(j * S + i);
                         if (cj != 0) onz |= 1u << r;
                         const int lj = wlen[j];
                         if (lj != 0)
@@ -458,7 +481,7 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
 #pragma unroll
             for (int r = 0; r < RMAX; r++) {
                 const int i = lane * R_eff + r;
-                if (r < R_eff && i < S_used) sn[m * S + i] = cn[r];
+                if (r < R_eff && i < S_used) sn_set(m * S + i, cn[r]);
             }
             LDS_FENCE();
         }
@@ -481,8 +504,12 @@ __global__ __launch_bounds__(256, (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB
         if (n_oov) atomicAdd(&sl.stats[ST_OOV], (unsigned long long)n_oov);
         if (n_abort) atomicAdd(&sl.stats[ST_ABORT], (unsigned long long)n_abort);
         if (n_fb) atomicAdd(&sl.stats[ST_FALLBACK], (unsigned long long)n_fb);
+        if (n_misclass) atomicAdd(&sl.stats[ST_MISCLASS], (unsigned long long)n_misclass);
     }
 }
+
+#undef sn_get
+#undef sn_set
 
 template <int RMAX>
 static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s)

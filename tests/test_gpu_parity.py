@@ -276,11 +276,16 @@ def test_overflow_entities_are_rerun_by_the_generic_kernel():
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["optimistic", "classified", ""])
 @pytest.mark.parametrize("force", ["", "1", "2", "4", "8", "16"])
-def test_register_variants_and_three_pass_overflow_chain(force, monkeypatch):
+def test_register_variants_overflow_chain_and_classified_side_streams(force, mode, monkeypatch):
     """Topic lists of ~50 ... ~1500 distinct topics in one corpus: whatever primary variant (64*r slots,
-    r = 1..16) the sweep starts with, the entities that do not fit go to the 16-round variant and, beyond
-    1024 slots, to the generic LDS kernel -- all inside one mvhdp_sweep call, with identical results."""
+    r = 1..16) the sweep starts with, the entities that do not fit reach a wider variant and, beyond
+    1024 slots, the generic LDS kernel -- either one pass after another through overflow lists
+    ("optimistic") or measured up front and run side by side on their own streams ("classified");
+    all inside one mvhdp_sweep call, with identical results."""
+    if mode:
+        monkeypatch.setenv("MVHDP_FORCE_MODE", mode)
     K, V = 2048, [5000, 300]
     rng = np.random.RandomState(21)
     lens0 = np.array([60, 110, 150, 260, 300, 520, 700, 1100, 1500, 2600, 4000, 9, 0, 33, 64, 128, 256, 512, 1024] + [20] * 40, dtype=np.int64)
