@@ -262,195 +262,39 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
 
-                // software pipeline: n_wk values of the listed topics for the next token
-                int gn[RMAX];
-                {
-                    const int w0 = bcast_i(w_l, 0);
+                // software pipeline: the n_wk values of the listed topics are gathered NB tokens ahead, into NB
+                // register buffers used in turn (the token loop is unrolled NB times so that no buffer is ever
+                // copied while its load is in flight).  Two buffers where few waves share a SIMD and a wave's
+                // own latency is what counts; one where six waves hide it and registers are what counts.
+                constexpr int NB = (RMAX >= 4) ? 2 : 1;
+                int gn[RMAX], gn2[RMAX];
+#pragma unroll
+                for (int a = 0; a < NB; a++) {
+                    const int w0 = bcast_i(w_l, min(a, nt - 1));
                     const int64_t r0 = row0 + max(w0, 0);
                     const char* __restrict__ c0p = (const char*)(nwk + r0 * K);
 #pragma unroll
-                    for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
+                    for (int r = 0; r < RMAX; r++) {
+                        const int v = (NB == 2 || r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
+                        if (a == 0) gn[r] = v; else gn2[r] = v;
+                    }
                 }
 
-                for (int t = 0; t < nt; t++) {                              // WRK:425
-                    int g[RMAX];
-#pragma unroll
-                    for (int r = 0; r < RMAX; r++) g[r] = gn[r];
-                    if (t + 1 < nt) {
-                        const int wn = bcast_i(w_l, t + 1);
-                        const int64_t rn = row0 + max(wn, 0);
-                        const char* __restrict__ cnp = (const char*)(nwk + rn * K);
-#pragma unroll
-                        for (int r = 0; r < RMAX; r++) gn[r] = (r < R_eff) ? *(const int32_t*)(cnp + koff[r]) : 0;
+                for (int t = 0; t < nt; t += NB) {                          // WRK:425
+#define TOK_T t
+#define TOK_G gn
+#include "mvhdp_sweep_fast_token.inc"
+#undef TOK_T
+#undef TOK_G
+                    if (aborted) break;
+                    if (NB == 2 && t + 1 < nt) {
+#define TOK_T (t + 1)
+#define TOK_G gn2
+#include "mvhdp_sweep_fast_token.inc"
+#undef TOK_T
+#undef TOK_G
+                        if (aborted) break;
                     }
-                    const int w = bcast_i(w_l, t);
-                    if (w < 0) { n_oov++; continue; }                       // WRK:427-428
-                    const int so = bcast_i(so_l, t);
-                    const double u1 = bcast_d(u1_l, t);
-                    const double root = bcast_d(root_l, t);                  // tree[1]
-                    const int64_t row = row0 + w;
-
-                    // WRK:434-468 decrement the local count; drop the topic when it is gone from all views
-                    if (so >= 0) {
-                        const int rs = so & (R_eff - 1), ls = so >> lg;
-                        int csel = cn[0];
-#pragma unroll
-                        for (int r = 1; r < RMAX; r++) csel = (rs == r) ? cn[r] : csel;
-                        const int c = bcast_i(csel, ls) - 1;
-                        const bool kill = (c == 0) && !((bcast_i((int)onz, ls) >> rs) & 1);
-                        if (lane == ls) {
-#pragma unroll
-                            for (int r = 0; r < RMAX; r++) {
-                                if (rs == r) { cn[r] = c; if (kill) skr[r] |= (int)0x80000000; }
-                            }
-                        }
-                    }
-
-                    // WRK:496-513 topicDocWordMasses: terms of the lane's slots, in-lane running sum,
-                    // one DPP prefix scan of the lane totals (certified below); the reference's sequential
-                    // left-to-right sum only when a comparison is too close to call.
-                    double term[RMAX], cum[RMAX];
-#pragma unroll
-                    for (int r = 0; r < RMAX; r++) {
-                        term[r] = 0.0;
-                        if (r < R_eff && skr[r] >= 0) {
-                            double p_wt = div_inrange((double)g[r] + beta_m, den[r]);      // WRK:507
-                            term[r] = (p_mm * (double)cn[r] + oth[r]) * p_wt;              // WRK:509
-                        }
-                    }
-                    double mass, s0, s1 = 0.0, total;
-                    int branch, slot_new = -1;     // branch: 0 new-topic, 1 doc, 2 tree
-                    bool unsafe;
-                    {
-                        double lsum = term[0];
-                        cum[0] = lsum;
-#pragma unroll
-                        for (int r = 1; r < RMAX; r++) { if (r < R_eff) { lsum += term[r]; } cum[r] = lsum; }
-                        const double incl = wave_incl_scan_d_dpp(lsum);
-                        const double excl = incl - lsum;
-#pragma unroll
-                        for (int r = 0; r < RMAX; r++) cum[r] = (r == R_eff - 1) ? incl : excl + cum[r];
-                        mass = bcast_d(incl, 63);
-                    }
-                    // decision on (cum, mass); tol < 0 disables the closeness checks
-#define MVHDP_DECIDE(TOL)                                                                                   \
-                    {                                                                                       \
-                        const double tol_ = (TOL);                                                          \
-                        total = newMass + mass + root;                       /* WRK:519 */                  \
-                        s0 = u1 * total;                                                                    \
-                        unsafe = false; slot_new = -1;                                                      \
-                        if (s0 < newMass) {                                  /* WRK:522 */                  \
-                            branch = 0;                                                                     \
-                            unsafe = fabs(s0 - newMass) <= tol_ * total;                                    \
-                        } else {                                                                            \
-                            s1 = s0 - newMass;                               /* WRK:528 */                  \
-                            unsafe = (newMass != 0.0 && fabs(s1) <= tol_ * total) || (fabs(s1 - mass) <= tol_ * total); \
-                            if (s1 < mass) {                                 /* WRK:529 */                  \
-                                branch = 1;                                                                 \
-                                unsigned long long anyhit = 0, near = 0, hitr[RMAX];                        \
-                                _Pragma("unroll")                                                           \
-                                for (int r = 0; r < RMAX; r++) {             /* WRK:531 lower_bound over the live list */ \
-                                    hitr[r] = 0;                                                            \
-                                    if (r < R_eff) {                                                        \
-                                        const bool live = skr[r] >= 0;                                      \
-                                        const double diff = cum[r] - s1;     /* sign-exact: diff >= 0 <=> cum >= s1 */ \
-                                        near |= __builtin_amdgcn_ballot_w64(live && fabs(diff) <= tol_ * total); \
-                                        hitr[r] = __builtin_amdgcn_ballot_w64(live && diff >= 0.0);         \
-                                        anyhit |= hitr[r];                                                  \
-                                    }                                                                       \
-                                }                                                                           \
-                                if (near) unsafe = true;                                                    \
-                                if (anyhit) {                                                               \
-                                    const int hl = (int)__builtin_ctzll(anyhit);                            \
-                                    int rr = 0;                                                             \
-                                    _Pragma("unroll")                                                       \
-                                    for (int r = RMAX - 1; r >= 0; r--) if ((hitr[r] >> hl) & 1ull) rr = r; \
-                                    slot_new = hl * R_eff + rr;                                             \
-                                }                                                                           \
-                            } else {                                                                        \
-                                branch = 2;                                                                 \
-                            }                                                                               \
-                        }                                                                                   \
-                    }
-                    // Certified scan: any summation order of the same non-negative terms differs from the
-                    // sequential one by < 2n ulp-units of the total; if no comparison is closer than that the
-                    // decisions equal the reference's bit for bit, otherwise the sequential sum decides.
-                    MVHDP_DECIDE((double)(4 * S_used + 16) * 0x1.0p-53)
-                    if (__builtin_expect(unsafe || exact_only, 0)) {
-                        if (unsafe) n_fb++;
-                        double c = 0.0;
-                        for (int i = 0; i < S_used; i++) {                   // WRK:501-513, dense order
-                            const int li = i >> lg, ri = i & (R_eff - 1);
-                            double tsel = term[0];
-#pragma unroll
-                            for (int r = 1; r < RMAX; r++) tsel = (ri == r) ? term[r] : tsel;
-                            c += bcast_d(tsel, li);
-                            if (lane == li) {
-#pragma unroll
-                                for (int r = 0; r < RMAX; r++) if (ri == r) cum[r] = c;
-                            }
-                        }
-                        mass = c;
-                        MVHDP_DECIDE(-1.0)
-                    }
-#undef MVHDP_DECIDE
-
-                    if (DEBUG) {
-                        if (sl.tok_dbg[m] && lane == 0) {
-                            double* gdb = sl.tok_dbg[m] + (base + c0 + t) * 4;
-                            gdb[0] = newMass; gdb[1] = mass; gdb[2] = root; gdb[3] = s0;
-                        }
-                        for (int q = 0; q < sl.n_trace; q++) {
-                            if (sl.trace_doc[q] == d && sl.trace_view[q] == m && sl.trace_pos[q] == c0 + t) {
-                                double* out = sl.trace_out + (int64_t)q * (K + 1);
-                                const double* tr = mm.trees + row * 2 * K;
-                                for (int k = lane; k < K; k += WAVE) out[k] = tr[K + k] / total;
-                                __threadfence();
-#pragma unroll
-                                for (int r = 0; r < RMAX; r++)
-                                    if (r < R_eff && skr[r] >= 0) out[skr[r]] += term[r] / total;
-                                if (lane == 0) out[K] = newMass / total;
-                                __threadfence();
-                            }
-                        }
-                    }
-
-                    int znew;
-                    if (branch == 0) {                                       // WRK:523-526
-                        c_new++;
-                        znew = mm.first_inactive;
-                    } else if (branch == 1) {                                // WRK:530-531
-                        c_doc++;
-                        if (slot_new < 0) { aborted = true; break; }         // lower_bound == -1 -> exception, Q11
-                        const int rn = slot_new & (R_eff - 1), ln = slot_new >> lg;
-                        int ksel = skr[0];
-#pragma unroll
-                        for (int r = 1; r < RMAX; r++) ksel = (rn == r) ? skr[r] : ksel;
-                        znew = bcast_i(ksel, ln);
-                    } else {                                                 // WRK:533-535
-                        c_tree++;
-                        znew = bcast_i(zt_l, t);
-                        slot_new = bcast_i(st_l, t);
-                    }
-                    if (znew < 0) znew = K - 1;                              // WRK:549-552
-                    znew = uniform_i(znew);
-
-                    // WRK:557-560
-                    if (lane == t) znew_l = znew;
-                    if (branch == 0) {
-                        uint32_t wbit = bitmap[znew >> 5];
-                        slot_new = ((wbit >> (znew & 31)) & 1u) ? (int)(prefix[znew >> 5] + __popc(wbit & ((1u << (znew & 31)) - 1u))) : -1;
-                        slot_new = uniform_i(slot_new);
-                    }
-                    if (slot_new >= 0) {
-                        const int rn = slot_new & (R_eff - 1), ln = slot_new >> lg;
-                        if (lane == ln) {
-#pragma unroll
-                            for (int r = 0; r < RMAX; r++) if (rn == r) cn[r]++;
-                        }
-                    }
-                    n_tok++;
-
                 }
 
                 // WRK:587-589 + UPD:197-218 for the whole chunk at once: lane t owns token t (old topic z_l,
