@@ -301,8 +301,9 @@ def test_register_variants_overflow_chain_and_classified_side_streams(force, mod
     if force:
         monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
     s = make_native(c, hy, z0)
-    for it in range(3):
-        ro = o.sweep(it, 31); rs = s.sweep(it, 31)
+    for it in range(4):
+        ro = o.sweep(it, 31)
+        rs = s.sweep(it, 31, flags=SWEEP_EXACT_CHAIN if it == 3 else 0)      # last sweep: the sequential-sum path of every kernel
         assert rs.tokens == c.total_tokens == ro["stats"]["tokens"]
         assert rs.changed == ro["stats"]["changed"]
         assert_same_state(o, s, 2)
