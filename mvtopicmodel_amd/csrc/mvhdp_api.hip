@@ -607,25 +607,9 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     if (fast && geometry(true, rmax, fst[0]) != MVHDP_OK) { fast = false; classified = false; n_chain = 0; }
     for (int p = 1; p < n_chain; p++)
         if (geometry(true, chain[p], fst[p]) != MVHDP_OK) { n_chain = p; break; }     // later passes fall to the generic kernel
-    int cls_team[MVHDP_N_CLASSES] = {};      // > 0: the class runs one workgroup per entity with that many slot rounds per lane
     if (classified) {
         cls[pc] = fst[0]; cls_fast[pc] = true;
-        const bool teams = !getenv("MVHDP_NO_TEAM");
         for (int c = pc + 1; c < MVHDP_N_CLASSES; c++) {
-            if (teams && (c == 3 || c == 4)) {
-                // 257..1024 slots: one workgroup per entity (the long entities are the sweep's critical path)
-                Geo g{};
-                g.wave_bytes = (uint32_t)mvhdp_sweep_team_bytes(M, std::min(S_cap, 64 << c));
-                g.wpb = 1;
-                g.lds = sl.block_shared_bytes + (size_t)g.wave_bytes;
-                if (g.lds <= h->max_lds) {
-                    const int rt = (c == 3) ? 2 : 4;
-                    int bpc = mvhdp_sweep_team_occupancy(rt, debug, g.lds);
-                    g.grid = h->num_cus * std::max(bpc, 1);
-                    cls[c] = g; cls_team[c] = rt;
-                    continue;
-                }
-            }
             cls_fast[c] = c < 5 && geometry(true, 1 << c, cls[c]) == MVHDP_OK;
             if (!cls_fast[c]) cls[c] = gen;                                           // no room for that variant: generic kernel
         }
@@ -740,10 +724,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
                 sc.q_order = nullptr; sc.q_order_start = 0; sc.q_order_count = 0;
                 sc.doc_counter = h->d_doc_counter + c;
                 sc.wave_bytes = cls[c].wave_bytes; sc.waves_per_block = cls[c].wpb;
-                if (cls_team[c]) {
-                    sc.S_cap = std::min(S_cap, 64 << c);
-                    step(mvhdp_launch_sweep_team(mm, sc, cls_team[c], blocks_for(H, cls[c]), debug, st));
-                } else if (cls_fast[c]) {
+                if (cls_fast[c]) {
                     sc.S_cap = std::min(S_cap, 64 << c);
                     step(mvhdp_launch_sweep_fast(mm, sc, 1 << c, blocks_for(H, cls[c]), debug, st));
                 } else {

@@ -91,10 +91,6 @@ hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipS
 size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax);
 hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);
 int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes);
-// one workgroup (four waves) per entity: 256*rt topic slots (mvhdp_sweep_team.hip); sl.wave_bytes = the team's LDS region
-size_t mvhdp_sweep_team_bytes(int M, int S_cap);
-hipError_t mvhdp_launch_sweep_team(const MvModel& mm, const SweepLaunch& sl, int rt, int grid_blocks, bool debug, hipStream_t s);
-int mvhdp_sweep_team_occupancy(int rt, bool debug, size_t lds_bytes);
 int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes);
 
 #define MVHDP_DOC_BATCH 2
