@@ -248,11 +248,21 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     if (act) root_l = tr[1];
                     double u = u2_l * root_l;                                // FT:120
                     int i = 1;
+                    // two levels per round of loads: tree[2i] and the left children of both candidates
+                    // (tree[4i], tree[4i+2]) are fetched together, halving the dependent round trips
                     while (__builtin_amdgcn_ballot_w64(act && i < K)) {      // FT:122
                         if (act && i < K) {
-                            const double l = tr[2 * i];
-                            if (u < l) i = 2 * i;                            // FT:124-125
-                            else { u = u - l; i = 2 * i + 1; }               // FT:127-128
+                            const int iL = 2 * i, iR = 2 * i + 1;
+                            const double l = tr[iL];
+                            const double ll = (iL < K) ? tr[2 * iL] : 0.0;
+                            const double lr = (iR < K) ? tr[2 * iR] : 0.0;
+                            if (u < l) i = iL;                               // FT:124-125
+                            else { u = u - l; i = iR; }                      // FT:127-128
+                            if (i < K) {
+                                const double l2 = (i == iL) ? ll : lr;
+                                if (u < l2) i = 2 * i;
+                                else { u = u - l2; i = 2 * i + 1; }
+                            }
                         }
                     }
                     if (act) {

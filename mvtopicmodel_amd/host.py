@@ -1,6 +1,9 @@
 """ctypes view of the C++ host mirror of FastQMVWVParallelTopicModel
 (csrc/host/, hooks declared in include/mvtm_host.h)."""
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 import numpy as np
 
@@ -17,6 +20,16 @@ HOST_SYMBOLS = [
 ]
 
 _ready = False
+_live = weakref.WeakSet()          # open models, closed at exit while the HIP runtime is still alive
+
+
+@atexit.register
+def _close_all():
+    for m in list(_live):
+        try:
+            m.close()
+        except Exception:
+            pass
 
 
 def _lib():
@@ -115,6 +128,7 @@ class FastQMVWVParallelTopicModel:
         self.p = self.L.mvtm_model_new(self.K, self.M, float(alpha), float(beta))
         if not self.p:
             raise ValueError(self.L.mvtm_last_error().decode())
+        _live.add(self)
         self._cfg = dict(numIterations=1000, burninPeriod=200, optimizeInterval=50, randomSeed=-1, device=0, docIdBase=0)
         self.V = None
 
@@ -124,6 +138,8 @@ class FastQMVWVParallelTopicModel:
             self.p = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -3,7 +3,10 @@
 numpy-typed wrapper over the C ABI (include/mvhdp.h).  One instance = one model
 shard on one MI355X.  All compute happens in libmvhdp.so on the GPU.
 """
+import atexit
 import ctypes as C
+import sys
+import weakref
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -22,6 +25,18 @@ BUF_DELTA = 1
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+_live = weakref.WeakSet()          # open samplers, closed at exit while the HIP runtime is still alive
+
+
+@atexit.register
+def _close_all():
+    for s in list(_live):
+        try:
+            s.close()
+        except Exception:
+            pass
 
 
 @dataclass
@@ -87,6 +102,7 @@ class NativeSampler:
         cfg.doc_id_base = int(doc_id_base)
         self.h = C.c_void_p()
         rc = self.L.mvhdp_create(C.byref(cfg), C.byref(self.h))
+        _live.add(self)
         if rc != 0:
             msg = self.L.mvhdp_last_error(None).decode()
             self.h = None
@@ -101,6 +117,10 @@ class NativeSampler:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: handles still open then were closed by
+        # the atexit hook below, while the runtime was alive
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
