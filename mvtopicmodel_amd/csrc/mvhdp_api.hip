@@ -144,6 +144,19 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMemset(mm.delta, 0, cbytes));
     CREATE_HIP(hipMalloc(&mm.trees, (size_t)nrows * 2 * K * sizeof(double)));
     CREATE_HIP(hipMalloc(&mm.root, (size_t)nrows * sizeof(double)));
+    {
+        // descent table layout (MvModel::dtab): internal levels nlev, first block dt_f levels, then blocks of three
+        const int nlev = (K > 1) ? (32 - __builtin_clz((unsigned)(K - 1))) : 0;
+        mm.dt_f = nlev ? ((nlev - 1) % 3) + 1 : 0;
+        mm.dt_nbd = 1; mm.dt_base[0] = 0; mm.dt_depth[0] = 0;
+        int nblk = 1;
+        for (int dep = mm.dt_f; nlev && dep < nlev; dep += 3) {
+            mm.dt_base[mm.dt_nbd] = nblk; mm.dt_depth[mm.dt_nbd] = dep; mm.dt_nbd++;
+            nblk += 1 << dep;
+        }
+        mm.dt_nblk = nblk;
+        CREATE_HIP(hipMalloc(&mm.dtab, (size_t)nrows * nblk * 8 * sizeof(double)));
+    }
     CREATE_HIP(hipMalloc(&h->d_alpha, (size_t)M * (K + 1) * sizeof(double)));
     CREATE_HIP(hipMalloc(&h->d_inactive, (size_t)K));
     CREATE_HIP(hipMemset(h->d_inactive, 0, (size_t)K));
@@ -173,6 +186,7 @@ extern "C" int mvhdp_destroy(mvhdp_handle h)
     if (h->mm.delta) hipFree(h->mm.delta);
     if (h->mm.trees) hipFree(h->mm.trees);
     if (h->mm.root) hipFree(h->mm.root);
+    if (h->mm.dtab) hipFree(h->mm.dtab);
     if (h->mm.p) hipFree(h->mm.p);
     if (h->d_alpha) hipFree(h->d_alpha);
     if (h->d_inactive) hipFree(h->d_inactive);

@@ -22,6 +22,14 @@ struct MvModel {
     int32_t* delta;
     double* trees;                     // [sumV][2K]  FTree.tree (FT:21)
     double* root;                      // [sumV]      tree[1]
+    // Descent table: what FTree.sample (FT:118-132) reads -- tree[1] and the left-child sums tree[2i] of the
+    // internal nodes i -- regrouped so that three consecutive levels of one path share a 64-byte block
+    // (8 doubles: L[b]; L[2b], L[2b+1]; L[4b..4b+3]; spare, = tree[1] in block 0; L[i] = tree[2i]).
+    // A descent reads ceil(levels/3) sectors instead of one per level.  The first block holds dt_f = 1..3
+    // levels so that every later block is full; blocks rooted at depth dt_depth[j] start at block dt_base[j].
+    double* dtab;                      // [sumV][dt_nblk][8]
+    int32_t dt_nblk, dt_nbd, dt_f;
+    int32_t dt_base[6], dt_depth[6];
     const double* alpha;               // [M][K+1]
     const uint8_t* inactive;           // [K]
     double alpha_sum[MVHDP_MAXM], beta[MVHDP_MAXM], beta_sum[MVHDP_MAXM], gamma[MVHDP_MAXM];

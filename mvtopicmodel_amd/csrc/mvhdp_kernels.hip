@@ -104,6 +104,23 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         double* out = mm.trees + row * 2 * K;
         for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
         if (lane == 0) mm.root[row] = t[1];
+        // the same numbers once more, grouped for the descent (see MvModel::dtab)
+        double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
+        for (int x = lane; x < mm.dt_nblk; x += WAVE) {
+            int bd = 0;
+            while (bd + 1 < mm.dt_nbd && x >= mm.dt_base[bd + 1]) bd++;
+            const int b = (1 << mm.dt_depth[bd]) + (x - mm.dt_base[bd]);
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                const int node = (q == 0) ? b : (q < 3) ? 2 * b + (q - 1) : 4 * b + (q - 3);
+                v[q] = (node < K) ? t[2 * node] : 0.0;
+            }
+            v[7] = (x == 0) ? t[1] : 0.0;
+            double2* o = (double2*)(dt + (int64_t)x * 8);
+            o[0] = make_double2(v[0], v[1]); o[1] = make_double2(v[2], v[3]);
+            o[2] = make_double2(v[4], v[5]); o[3] = make_double2(v[6], v[7]);
+        }
         __syncthreads();
     }
 }

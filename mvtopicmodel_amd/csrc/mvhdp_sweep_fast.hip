@@ -244,24 +244,29 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 int zt_l = -1, st_l = -1;
                 {
                     const bool act = tvalid && w_l >= 0;
-                    const double* __restrict__ tr = mm.trees + (row0 + max(w_l, 0)) * 2 * K;
-                    if (act) root_l = tr[1];
-                    double u = u2_l * root_l;                                // FT:120
+                    const double* __restrict__ dt = mm.dtab + (row0 + max(w_l, 0)) * (int64_t)mm.dt_nblk * 8;
+                    double u = 0.0;
                     int i = 1;
-                    // two levels per round of loads: tree[2i] and the left children of both candidates
-                    // (tree[4i], tree[4i+2]) are fetched together, halving the dependent round trips
-                    while (__builtin_amdgcn_ballot_w64(act && i < K)) {      // FT:122
-                        if (act && i < K) {
-                            const int iL = 2 * i, iR = 2 * i + 1;
-                            const double l = tr[iL];
-                            const double ll = (iL < K) ? tr[2 * iL] : 0.0;
-                            const double lr = (iR < K) ? tr[2 * iR] : 0.0;
-                            if (u < l) i = iL;                               // FT:124-125
-                            else { u = u - l; i = iR; }                      // FT:127-128
-                            if (i < K) {
-                                const double l2 = (i == iL) ? ll : lr;
-                                if (u < l2) i = 2 * i;
-                                else { u = u - l2; i = 2 * i + 1; }
+                    // descent by 64-byte blocks of the descent table: three levels of the path per sector
+                    // (the first block: tree[1] and dt_f levels), every lane on its own word's table
+                    for (int bd = 0; bd < mm.dt_nbd; bd++) {
+                        if (act && (bd == 0 || i < K)) {
+                            const double2* __restrict__ blk = (const double2*)(dt + (int64_t)(mm.dt_base[bd] + (i - (1 << mm.dt_depth[bd]))) * 8);
+                            const double2 q0 = blk[0], q1 = blk[1], q2 = blk[2], q3 = blk[3];
+                            const int levels = (bd == 0) ? mm.dt_f : 3;
+                            if (bd == 0) { root_l = q3.y; u = u2_l * root_l; }       // FT:120
+                            int path = 0;
+                            if (i < K && levels > 0) {                                // FT:122-130, level 1 of the block
+                                const double l = q0.x;
+                                if (u < l) { i = 2 * i; } else { u = u - l; i = 2 * i + 1; path = 1; }
+                            }
+                            if (i < K && levels > 1) {
+                                const double l = path ? q1.x : q0.y;
+                                if (u < l) { i = 2 * i; path = 2 * path; } else { u = u - l; i = 2 * i + 1; path = 2 * path + 1; }
+                                if (i < K && levels > 2) {
+                                    const double l3 = (path == 0) ? q1.y : (path == 1) ? q2.x : (path == 2) ? q2.y : q3.x;
+                                    if (u < l3) { i = 2 * i; } else { u = u - l3; i = 2 * i + 1; }
+                                }
                             }
                         }
                     }
