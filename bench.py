@@ -158,7 +158,7 @@ def main():
         dt = float(tt.item())
 
     value = total_tokens * args.steps / dt
-    # roofline of the dominant kernel (sweep_kernel) on this rank: algorithmic bytes per launch /
+    # roofline of the dominant kernel (sweep_fast_kernel<R>) on this rank: algorithmic bytes per launch /
     # its average duration, measured with hipEvents on the library's stream
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     bpt = algorithmic_bytes_per_token(K)
@@ -188,7 +188,7 @@ def main():
                    "sharding": f"documents/{world}, per-sweep int32 all-reduce of n_wk,n_k deltas" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                     "kernel": "sweep_kernel", "bytes_per_token": bpt, "tokens_per_launch": local_tokens,
+                     "kernel": "sweep kernels of one mvhdp_sweep (dominant: sweep_fast_kernel<R>)", "bytes_per_token": bpt, "tokens_per_launch": local_tokens,
                      "avg_kernel_ms": avg_kernel_s * 1e3},
         "sweep": {"changed_frac": last.changed / max(1, last.tokens),
                   "branch_frac": {"new": last.new_mass_cnt / max(1, last.tokens),

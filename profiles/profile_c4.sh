@@ -14,20 +14,23 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/sq -- python3 $R/bench.py $ARGS > $OUT/sq.log 2>&1 || exit 1
 cd $R
 python3 - <<PY
-import csv, glob, json
+import csv, glob, json, collections
 out = {}
 tok = 147225025
+# the dominant sweep kernel of the run (largest total time in the --stats pass)
+stats = list(csv.DictReader(open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0])))
+dom = max((r for r in stats if "sweep" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))["Name"]
+out["dominant_kernel"] = dom
 for d in ("fetch", "write", "sq"):
     f = glob.glob("$OUT/%s/*/*_counter_collection.csv" % d)[0]
-    agg = {}
+    agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "sweep" in r["Kernel_Name"]:
-            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if r["Kernel_Name"] == dom:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         v = v[2:] if len(v) > 2 else v          # drop the warm-up sweeps
         out[k] = sum(v) / len(v)
-f = glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]
-out["kernel_stats_csv"] = open(f).read()
+out["kernel_stats_csv"] = open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]).read()
 out["tokens_per_launch"] = tok
 print(json.dumps({k: v for k, v in out.items() if k != "kernel_stats_csv"}, indent=1))
 open("$OUT/summary.json", "w").write(json.dumps(out, indent=1))
