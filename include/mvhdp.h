@@ -149,6 +149,10 @@ int mvhdp_get_count_histogram(mvhdp_handle h, int32_t m, int32_t* hist, int32_t 
 int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums /*[M][M]*/);
 /* modelLogLikelihood PTM:3322-3452, one value per view. */
 int mvhdp_model_log_likelihood(mvhdp_handle h, double* log_likelihood /*[M]*/);
+/* printDocumentTopics PTM:2871-2899 (and the inferencer's INF:383-411): topic proportions of entities [d0, d1),
+ * out[(d-d0)*K + k] = sum_m w[m]*(n_dk[m][k] + gamma[m]*alpha[m][k])/(len[m] + gamma[m]*alphaSum[m]) / sum_m w[m],
+ * w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m].  A view the entity lacks counts as an empty one. */
+int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_weights /*[M]*/, int64_t d0, int64_t d1, double* out /*[d1-d0][K]*/);
 
 /* ---- the hot path ---- */
 /* One Gibbs sweep over every entity: replaces "submit updaters + submit

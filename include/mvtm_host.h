@@ -53,6 +53,9 @@ int   mvtm_mallet_next_gamma_stream(int64_t seed, double alpha, double beta, int
 int   mvtm_model_get_perplexities(void* model, int m, double* out, int cap);
 /* printState PTM:3269-3320 (text; gzip when the name ends in .gz) */
 int   mvtm_model_print_state(void* model, const char* filename);
+/* printDocumentTopics PTM:2820-2960 (text half; no JDBC): discr_weight[M] / p_mean[M][M] replace the model's when non-NULL */
+int   mvtm_model_print_document_topics(void* model, const char* filename, double threshold, int max,
+                                       const double* discr_weight, const double* p_mean);
 int   mvtm_java_double_to_string(double v, char* out, int cap);
 void* mvtm_model_native_handle(void* model);
 /* PTM:465-515 on CSR arrays: initial topic draw order of addInstances with java.util.Random(seed) */

@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "mvhdp_set_hyper", "mvhdp_get_alpha", "mvhdp_build_counts", "mvhdp_build_trees",
     "mvhdp_build_inference_trees", "mvhdp_init_assignments_from_trees",
     "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
-    "mvhdp_get_count_histogram", "mvhdp_view_overlap_sums", "mvhdp_model_log_likelihood",
+    "mvhdp_get_count_histogram", "mvhdp_view_overlap_sums", "mvhdp_model_log_likelihood", "mvhdp_doc_topic_proportions",
     "mvhdp_sweep", "mvhdp_apply_delta", "mvhdp_get_view_weights",
     "mvhdp_device_buffer", "mvhdp_set_stream", "mvhdp_synchronize",
 ]
@@ -88,6 +88,7 @@ def load_library():
     L.mvhdp_get_count_histogram.argtypes = [vp, i32, vp, i32]
     L.mvhdp_view_overlap_sums.argtypes = [vp, vp]
     L.mvhdp_model_log_likelihood.argtypes = [vp, vp]
+    L.mvhdp_doc_topic_proportions.argtypes = [vp, vp, i64, i64, vp]
     L.mvhdp_sweep.argtypes = [vp, u32, u64, u32, vp, C.POINTER(DebugC), C.POINTER(SweepStatsC)]
     L.mvhdp_apply_delta.argtypes = [vp, i32, i32]
     L.mvhdp_get_view_weights.argtypes = [vp, vp]

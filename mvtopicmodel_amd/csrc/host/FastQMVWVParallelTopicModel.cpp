@@ -531,6 +531,49 @@ std::string FastQMVWVParallelTopicModel::printStateToString()
     return out.str();
 }
 
+std::string FastQMVWVParallelTopicModel::printDocumentTopicsToString(double threshold, int max)
+{
+    const int M = numModalities, K = numTopics;
+    if (!h_) throw std::runtime_error("printDocumentTopics() before addInstances()");
+    if (pMean.empty()) throw std::runtime_error("printDocumentTopics: pMean is not set (optimizeP has not run; PTM:134)");
+    if (discrWeightPerModality.empty()) discrWeightPerModality.assign(M, 1.0);
+    pushHyper();
+    std::vector<double> w((size_t)M);
+    for (int m = 0; m < M; m++) w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m];   // PTM:2895
+    if (max < 0 || max > K) max = K;                                                 // PTM:2834-2836
+    std::string out = "#doc name topic proportion ...\n";                            // PTM:2823
+    const int64_t D = (int64_t)data.size();
+    const int64_t batch = std::max<int64_t>(1, (int64_t)(64 << 20) / (K * 8));      // 64 MB of proportions at a time
+    std::vector<double> prop;
+    std::vector<int> order((size_t)K);
+    for (int64_t d0 = 0; d0 < D; d0 += batch) {
+        const int64_t d1 = std::min(D, d0 + batch);
+        prop.assign((size_t)(d1 - d0) * K, 0.0);
+        check(mvhdp_doc_topic_proportions(h_, w.data(), d0, d1, prop.data()), "mvhdp_doc_topic_proportions");
+        for (int64_t doc = d0; doc < d1; doc++) {
+            const double* pr = prop.data() + (size_t)(doc - d0) * K;
+            for (int k = 0; k < K; k++) order[k] = k;
+            // Arrays.sort(IDSorter[]): descending weight, stable (PTM:2902)
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pr[a] > pr[b]; });
+            std::string builder = std::to_string(doc) + "\t" + data[(size_t)doc].EntityId + "\t";     // PTM:2862-2869
+            for (int i = 0; i < max; i++) {
+                if (pr[order[i]] < threshold) break;                                  // PTM:2905
+                builder += std::to_string(order[i]) + "\t" + javaDoubleToString(pr[order[i]]) + "\t";
+                out += builder; out += "\n";                                          // PTM:2909: the whole builder, every time
+            }
+        }
+    }
+    return out;
+}
+
+void FastQMVWVParallelTopicModel::printDocumentTopics(const std::string& filename, double threshold, int max)
+{
+    const std::string text = printDocumentTopicsToString(threshold, max);
+    std::ofstream f(filename, std::ios::binary);
+    if (!f) throw std::runtime_error("printDocumentTopics: cannot open " + filename);
+    f << text;
+}
+
 void FastQMVWVParallelTopicModel::printState(const std::string& filename)
 {
     const std::string text = printStateToString();
@@ -825,6 +868,21 @@ int mvtm_model_get_perplexities(void* p, int m, double* out, int cap)
     int n = std::min<int>(cap, (int)model->perplexities[m].size());
     for (int i = 0; i < n; i++) out[i] = model->perplexities[m][i];
     return n;
+}
+
+int mvtm_model_print_document_topics(void* p, const char* filename, double threshold, int max, const double* discr_weight, const double* p_mean)
+{
+    auto* mdl = (FastQMVWVParallelTopicModel*)p;
+    try {
+        const int M = mdl->numModalities;
+        if (discr_weight) mdl->discrWeightPerModality.assign(discr_weight, discr_weight + M);
+        if (p_mean) {
+            mdl->pMean.assign(M, std::vector<double>(M, 0.0));
+            for (int a = 0; a < M; a++) for (int b = 0; b < M; b++) mdl->pMean[a][b] = p_mean[a * M + b];
+        }
+        mdl->printDocumentTopics(filename, threshold, max);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
 }
 
 int mvtm_model_print_state(void* p, const char* filename)

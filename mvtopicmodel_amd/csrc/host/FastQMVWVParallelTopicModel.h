@@ -138,6 +138,15 @@ public:
     bool printLogLikelihood = true;                             // PTM:128
     std::vector<std::string> notes;
 
+    // printDocumentTopics PTM:2820-2960 without its JDBC half: per entity the topic proportions
+    //   sum_m (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m] * (n_dk + gamma*alpha) / (len + gamma*alphaSum) / sum_m (...)
+    // (device kernel), sorted by weight (stable: ties by topic id), cut at `threshold` and `max`.  The text is the
+    // reference's, including its habit of printing the growing line once per retained topic (PTM:2905-2909).
+    // discrWeightPerModality comes from the diagnostics (PTM:1370), which are outside this build: all 1 unless set.
+    std::vector<double> discrWeightPerModality;                 // PTM:164
+    std::string printDocumentTopicsToString(double threshold, int max);
+    void printDocumentTopics(const std::string& filename, double threshold, int max);
+
     // the text state format of printState (PTM:3269-3320); gz when the name ends in ".gz".
     // Java's Double.toString is approximated by the shortest round-trip decimal in Java's layout.
     void printState(const std::string& filename);

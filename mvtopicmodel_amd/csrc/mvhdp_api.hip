@@ -924,6 +924,29 @@ extern "C" int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums)
     return MVHDP_OK;
 }
 
+extern "C" int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_weights, int64_t d0, int64_t d1, double* out)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    int rc = require_corpus(h); if (rc) return rc;
+    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "doc_topic_proportions before set_hyper");
+    if (!view_weights || !out || d0 < 0 || d1 > mm.D || d0 > d1) FAIL(h, MVHDP_ERR_INVALID_ARG, "doc_topic_proportions: bad range or null buffer");
+    if (d1 == d0) return MVHDP_OK;
+    HIPC(h, hipSetDevice(h->device));
+    double *d_w = nullptr, *d_out = nullptr;
+    const size_t n = (size_t)(d1 - d0) * mm.K;
+    hipError_t e = hipMalloc(&d_w, (size_t)mm.M * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_out, n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_w, view_weights, (size_t)mm.M * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = mvhdp_launch_doc_topic_prop(mm, d_w, d0, d1, d_out, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (d_w) hipFree(d_w);
+    if (d_out) hipFree(d_out);
+    HIPC(h, e);
+    return MVHDP_OK;
+}
+
 extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
 {
     CHECK_H(h);

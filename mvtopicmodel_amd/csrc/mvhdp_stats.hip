@@ -193,3 +193,46 @@ hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double
                        mm.beta[m], partial, nonzero);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// doc_topic_prop: the per-entity topic proportions of printDocumentTopics (PTM:2871-2899, the same lines in
+// the inferencer INF:383-411): per view the topic counts of the entity's assignments, then for every topic
+//   sum_m w[m] * (n_dk[m][k] + gamma[m]*alpha[m][k]) / (len[m] + gamma[m]*alphaSum[m])  /  sum_m w[m]
+// with w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m], products and quotient in the
+// reference's left-to-right order.  One wave per entity, counts in LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void doc_topic_prop_kernel(MvModel mm, const double* __restrict__ w, int64_t d0, int64_t d1, double* out)
+{
+    extern __shared__ int ndk[];                           // [M][K]
+    const int lane = threadIdx.x, K = mm.K, M = mm.M;
+    for (int64_t d = d0 + blockIdx.x; d < d1; d += gridDim.x) {
+        for (int i = lane; i < M * K; i += WAVE) ndk[i] = 0;
+        __syncthreads();
+        for (int m = 0; m < M; m++) {
+            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            for (int64_t i = b + lane; i < e; i += WAVE) { const int zz = mm.z[m][i]; if (zz >= 0 && zz < K) atomicAdd(&ndk[m * K + zz], 1); }
+        }
+        __syncthreads();
+        double norm = 0;
+        for (int m = 0; m < M; m++) norm += w[m];
+        double* o = out + (d - d0) * K;
+        for (int k = lane; k < K; k += WAVE) {
+            double tp = 0;
+            for (int m = 0; m < M; m++) {
+                const int len = (int)(mm.doc_off[m][d + 1] - mm.doc_off[m][d]);
+                tp += w[m] * ((double)ndk[m * K + k] + mm.gamma[m] * mm.alpha[(int64_t)m * (K + 1) + k]) / (len + mm.gamma[m] * mm.alpha_sum[m]);
+            }
+            o[k] = tp / norm;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const double* w_dev, int64_t d0, int64_t d1, double* out_dev, hipStream_t s)
+{
+    if (d1 <= d0) return hipSuccess;
+    int64_t n = d1 - d0;
+    int grid = (int)(n < 16384 ? n : 16384);
+    hipLaunchKernelGGL(doc_topic_prop_kernel, dim3(grid), dim3(64), (size_t)mm.M * mm.K * sizeof(int), s, mm, w_dev, d0, d1, out_dev);
+    return hipGetLastError();
+}

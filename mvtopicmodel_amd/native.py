@@ -231,6 +231,14 @@ class NativeSampler:
         self._ck(self.L.mvhdp_model_log_likelihood(self.h, _ptr(ll)))
         return ll
 
+    def doc_topic_proportions(self, view_weights, d0=0, d1=None):
+        """PTM:2871-2899: [d1-d0][K] topic proportions, view_weights[m] = (m==0 ? 1 : discrWeight[m]) * pMean[0][m]."""
+        d1 = self.D if d1 is None else int(d1)
+        w = np.ascontiguousarray(view_weights, dtype=np.float64)
+        out = np.zeros((max(d1 - int(d0), 0), self.K), dtype=np.float64)
+        self._ck(self.L.mvhdp_doc_topic_proportions(self.h, _ptr(w), int(d0), d1, _ptr(out)))
+        return out
+
     # -- the hot path ---------------------------------------------------------
     def sweep(self, sweep_idx, seed, flags=0, p=None, want_dbg=False, trace=None) -> SweepStats:
         st = SweepStatsC()

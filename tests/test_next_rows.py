@@ -148,3 +148,45 @@ def test_inferencer_frozen_model_mode():
             assert np.array_equal(a, model[m][0]) and np.array_equal(b, model[m][1])      # frozen model
     assert (s.get_assignments(0)[::17] == 0).all()              # OOV tokens are never resampled
     s.close()
+
+
+@pytest.mark.gpu
+def test_doc_topic_proportions_and_print_document_topics(tmp_path):
+    """printDocumentTopics PTM:2820-2960 (text half): device proportions bit-exact against the numpy restatement, and the
+    host mirror's text -- descending weight, ties by topic id, cut at threshold/max, the growing line printed once per
+    retained topic -- against the same text assembled in Python."""
+    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, java_double_to_string
+    from mvtopicmodel_amd import synth
+    from oracle import doc_topics as dto
+    K, V = 12, [150, 30]
+    c = synth.generate(K, V, 40, [25, 4], seed=77, chunk_docs=4096)
+    training = [(np.arange(c.D, dtype=np.int64) + 1000, c.doc_off[m], c.tokens[m], V[m]) for m in range(2)]
+    model = FastQMVWVParallelTopicModel(K, 2, 0.1, 0.01)
+    model.setNumIterations(3); model.setBurninPeriod(200); model.setOptimizeInterval(50); model.setRandomSeed(11)
+    model.addInstances(training)
+    model.estimate()
+    z = [model.get_view(m)[3] for m in range(2)]
+    hy = Hyper.defaults(K, V)
+    pmean = np.array([[1.0, 0.4], [0.4, 1.0]]); discr = np.array([1.0, 0.7])
+    w = [1.0 * pmean[0, 0], discr[1] * pmean[0, 1]]
+    want = dto.doc_topic_proportions(K, c.doc_off, z, hy.alpha, hy.alpha_sum, hy.gamma, w)
+    assert np.allclose(want.sum(axis=1), 1.0)
+
+    from mvtopicmodel_amd import NativeSampler
+    s = NativeSampler(K, V)
+    for m in range(2):
+        s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z[m])
+    s.set_hyper(hy)
+    got = s.doc_topic_proportions(w)
+    assert np.array_equal(got, want)
+    assert np.array_equal(s.doc_topic_proportions(w, 7, 19), want[7:19])
+    s.close()
+
+    f = tmp_path / "doc_topics.txt"
+    model.printDocumentTopics(f, 0.05, 4, discr_weight=discr, p_mean=pmean)
+    text = f.read_text()
+    assert text == dto.print_document_topics(want, [str(1000 + d) for d in range(c.D)], 0.05, 4, java_double_to_string)
+    lines = text.splitlines()
+    assert lines[0] == "#doc name topic proportion ..." and lines[1].startswith("0\t1000\t")
+    assert lines[2].startswith(lines[1])                                # the builder keeps growing within an entity
+    model.close()
