@@ -810,6 +810,11 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         h->rmax_hint = rmax_from_hist(ovf + 1);
     }
     if (e != hipSuccess) { cleanup(); HIPC(h, e); }
+    if (getenv("MVHDP_DEBUG") && hs[ST_T_TOTAL])
+        fprintf(stderr, "[mvhdp] wave cycles: queue %.1f%% prologue %.1f%% view setup %.1f%% chunk head %.1f%% tokens %.1f%% chunk end %.1f%% | %.0f cycles per token per wave\n",
+                100.0 * hs[ST_T_QUEUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_PROLOGUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_VIEW] / hs[ST_T_TOTAL],
+                100.0 * hs[ST_T_CHUNK_HEAD] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_TOKENS] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_CHUNK_END] / hs[ST_T_TOTAL],
+                (double)hs[ST_T_TOTAL] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
     if (hs[ST_MISCLASS]) { cleanup(); FAIL(h, MVHDP_ERR_HIP, "internal: an entity reached a sweep kernel variant that cannot hold its topic list"); }
 
     if (debug) {

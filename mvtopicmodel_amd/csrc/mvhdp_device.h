@@ -67,7 +67,9 @@ struct SweepLaunch {
 };
 
 enum {
-    ST_TOKENS = 0, ST_CHANGED, ST_NEW, ST_DOC, ST_TREE, ST_OOV, ST_ABORT, ST_FALLBACK, ST_NEGATIVE, ST_MISCLASS, ST_COUNT
+    ST_TOKENS = 0, ST_CHANGED, ST_NEW, ST_DOC, ST_TREE, ST_OOV, ST_ABORT, ST_FALLBACK, ST_NEGATIVE, ST_MISCLASS,
+    // wave cycles by segment, summed over waves; filled only by a -DMVHDP_TIMING build (diagnostics)
+    ST_T_QUEUE, ST_T_PROLOGUE, ST_T_VIEW, ST_T_CHUNK_HEAD, ST_T_TOKENS, ST_T_CHUNK_END, ST_T_TOTAL, ST_COUNT
 };
 
 size_t mvhdp_sweep_wave_bytes(int M, int S_cap);

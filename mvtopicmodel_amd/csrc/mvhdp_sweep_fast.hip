@@ -85,6 +85,15 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     const long long q_n1 = sl.q_list_count ? (long long)*sl.q_list_count : 0;
     const long long q_total = q_n1 + sl.q_order_count;
     unsigned int n_misclass = 0;
+#ifdef MVHDP_TIMING
+    // diagnostics: where a wave's cycles go (s_memtime stamps at the segment borders; the stamps cost ~10 %)
+    unsigned long long tq = 0, tp = 0, tv = 0, th = 0, tt = 0, te = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long t_last = t_begin;
+#define MVHDP_TSEG(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - t_last; t_last = now_; } while (0)
+#else
+#define MVHDP_TSEG(acc) do { } while (0)
+#endif
     for (;;) {
       long long q0 = 0;
       if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)MVHDP_DOC_BATCH);
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         else { const int64_t o = sl.q_order_start + (q - q_n1); d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
         const int64_t dg = mm.doc_id_base + d;
 
+        MVHDP_TSEG(tq);
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
         bitmap[lane] = 0;
         LDS_FENCE();
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             koff[r] = (skr[r] & 0x7fffffff) << 2;                          // byte offset of the topic inside an n_wk row
         }
 
+        MVHDP_TSEG(tp);
         const double* pd = (M > 1) ? (mm.p + d * M * M) : nullptr;        // WRK:327-337
         bool aborted = false;
 
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             const int64_t row0 = mm.rowbase[m];
             const int Vm = mm.V[m];
 
+            MVHDP_TSEG(tv);
             for (int c0 = 0; c0 < lenm && !aborted; c0 += WAVE) {
                 // one lane per token of the chunk: token id, old topic, its slot, RNG, tree root
                 const int ti = c0 + lane;
@@ -277,6 +289,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
 
+                MVHDP_TSEG(th);
                 // software pipeline: the n_wk values of the listed topics are gathered NB tokens ahead, into NB
                 // register buffers used in turn (the token loop is unrolled NB times so that no buffer is ever
                 // copied while its load is in flight).  Two buffers where few waves share a SIMD and a wave's
@@ -312,6 +325,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
 
+                MVHDP_TSEG(tt);
                 // WRK:587-589 + UPD:197-218 for the whole chunk at once: lane t owns token t (old topic z_l,
                 // new topic znew_l), so the FastQDelta records of up to 64 tokens become two wave-wide
                 // atomic instructions on the delta rows plus two on the block's n_k table.  Issued after
@@ -334,6 +348,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
                 if (tvalid) mm.z[m][base + ti] = znew_l;                     // coalesced write-back of the chunk
+                MVHDP_TSEG(te);
             }
 
             // the view's counts go back to LDS: later views read them (WRK:404) and test them (WRK:445)
@@ -364,6 +379,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         if (n_abort) atomicAdd(&sl.stats[ST_ABORT], (unsigned long long)n_abort);
         if (n_fb) atomicAdd(&sl.stats[ST_FALLBACK], (unsigned long long)n_fb);
         if (n_misclass) atomicAdd(&sl.stats[ST_MISCLASS], (unsigned long long)n_misclass);
+#ifdef MVHDP_TIMING
+        atomicAdd(&sl.stats[ST_T_QUEUE], tq); atomicAdd(&sl.stats[ST_T_PROLOGUE], tp); atomicAdd(&sl.stats[ST_T_VIEW], tv);
+        atomicAdd(&sl.stats[ST_T_CHUNK_HEAD], th); atomicAdd(&sl.stats[ST_T_TOKENS], tt); atomicAdd(&sl.stats[ST_T_CHUNK_END], te);
+        atomicAdd(&sl.stats[ST_T_TOTAL], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+#endif
     }
 }
 
