@@ -538,10 +538,8 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     sl.flags = flags; sl.S_cap = S_cap;
     sl.block_shared_bytes = (uint32_t)((((size_t)M * K + MVHDP_HIST_BINS) * sizeof(int) + 15) & ~(size_t)15);
     const bool debug = dbg != nullptr;
-    // Kernel variant.  The register-resident kernel holds 64*rmax topic slots per entity; rmax is
-    // sized from the largest topic list the previous sweep saw (or, first time, from the expected
-    // number of distinct topics of the longest entity), and entities that still exceed it are
-    // handed to the generic LDS kernel through the overflow list.
+    // Primary kernel variant: the register-resident kernel with 64*rmax topic slots per entity that is
+    // cheapest for the topic-list histogram of the previous sweep (first time: of a probe pass over z).
     bool fast = !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
     int rmax = 0;
     if (fast) {
