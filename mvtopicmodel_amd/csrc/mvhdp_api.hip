@@ -536,7 +536,10 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     SweepLaunch sl{};
     sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
     sl.flags = flags; sl.S_cap = S_cap;
-    sl.block_shared_bytes = (uint32_t)((((size_t)M * K + MVHDP_HIST_BINS) * sizeof(int) + 15) & ~(size_t)15);
+    // the block's private n_k delta table: in LDS up to 24 KiB (C5: 20 KB), beyond that (e.g. K = 2048 with 8 views:
+    // 64 KB, which would not leave room for the slot state) the deltas go straight to the delta buffer
+    sl.nk_global = ((size_t)M * K * sizeof(int) > 24 * 1024) ? 1 : 0;
+    sl.block_shared_bytes = (uint32_t)((((size_t)(sl.nk_global ? 0 : M * K) + MVHDP_HIST_BINS) * sizeof(int) + 15) & ~(size_t)15);
     const bool debug = dbg != nullptr;
     // Primary kernel variant: the register-resident kernel with 64*rmax topic slots per entity that is
     // cheapest for the topic-list histogram of the previous sweep (first time: of a probe pass over z).

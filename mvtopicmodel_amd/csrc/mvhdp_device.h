@@ -44,7 +44,8 @@ struct SweepLaunch {
     uint32_t flags;                    // MVHDP_SWEEP_EXACT_CHAIN
     int32_t  S_cap;                    // dense-slot capacity per wave (multiple of 64)
     int32_t  waves_per_block;
-    uint32_t block_shared_bytes;       // n_k delta table
+    uint32_t block_shared_bytes;       // n_k delta table (unless nk_global) + the topic-list histogram
+    int32_t  nk_global;                // 1: the n_k deltas go straight to the delta buffer (M*K too large to privatise in LDS)
     uint32_t wave_bytes;               // per-wave LDS region
     unsigned long long* stats;         // [16] device counters
     long long* act_key;                // activation key (atomicMin)

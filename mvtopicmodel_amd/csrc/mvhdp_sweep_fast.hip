@@ -60,9 +60,13 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     // with the bulk kernel's waves: let the arbiter issue them first
     if (RMAX >= 8) __builtin_amdgcn_s_setprio(3);
 
-    int* nkd = (int*)smem;                                  // [M*K] n_k deltas of this block
-    unsigned int* hist_s = (unsigned int*)(nkd + M * K);    // [MVHDP_HIST_BINS] tokens by topic-list size class
-    for (int i = threadIdx.x; i < M * K + MVHDP_HIST_BINS; i += blockDim.x) nkd[i] = 0;
+    // [M*K] n_k deltas of this block, privatised in LDS -- or none, the deltas going straight to the delta buffer,
+    // when M*K is too large for that (sl.nk_global); then [MVHDP_HIST_BINS] tokens by topic-list size class
+    const int nkd_len = sl.nk_global ? 0 : M * K;
+    int* nkd = (int*)smem;
+    unsigned int* hist_s = (unsigned int*)(nkd + nkd_len);
+    for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS; i += blockDim.x) nkd[i] = 0;
+    int32_t* const dnk_g = mm.delta + mm.rowbase[M] * K;    // n_k part of the delta buffer
     __syncthreads();
 
     unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
@@ -337,10 +341,12 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                         const int64_t rowK = (row0 + w_l) * K;
                         if (z_l >= 0) {
                             __hip_atomic_fetch_add(&dnwk[rowK + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_fetch_add(&nkd[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (sl.nk_global) __hip_atomic_fetch_add(&dnk_g[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else __hip_atomic_fetch_add(&nkd[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         __hip_atomic_fetch_add(&dnwk[rowK + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(&nkd[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (sl.nk_global) __hip_atomic_fetch_add(&dnk_g[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else __hip_atomic_fetch_add(&nkd[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (mm.first_inactive >= 0 && mm.inactive[znew_l]) {          // UPD:263
                             long long key = (dg << 34) | ((long long)m << 31) | ((long long)ti << 11) | (long long)znew_l;
                             atomicMin(sl.act_key, key);
@@ -365,9 +371,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     }
 
     __syncthreads();
-    int32_t* dnk = mm.delta + mm.rowbase[M] * K;
-    for (int i = threadIdx.x; i < M * K; i += blockDim.x)
-        if (nkd[i]) atomicAdd(&dnk[i], nkd[i]);
+    for (int i = threadIdx.x; i < nkd_len; i += blockDim.x)
+        if (nkd[i]) atomicAdd(&dnk_g[i], nkd[i]);
     if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
     if (lane == 0) {
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);

@@ -316,6 +316,10 @@ def test_register_variants_overflow_chain_and_classified_side_streams(force, mod
     (63, [200], 40, [80]), (64, [200], 40, [80]), (65, [200], 40, [80]),   # around one slot round / one bitmap word pair
     (1000, [900, 60, 60, 60, 60], 24, [96, 7, 7, 7, 7]),  # C5 shape (5 views, K=1000): generic kernel territory
     (2048, [300], 12, [40]),                             # MVHDP_MAX_TOPICS
+    (2048, [900] + [50] * 7, 10, [3000] + [5] * 7),      # both maxima at once (K=2048, 8 views), lists beyond 1024 slots:
+                                                         #   the n_k deltas no longer fit LDS and go straight to the delta buffer
+    (1500, [900] + [50] * 5, 10, [500] + [5] * 5),
+    (7, [900] + [50] * 7, 10, [300] + [5] * 7),
 ])
 def test_edge_shapes(K, V, D, lam):
     c = small_corpus(K, V, D, lam, 1000 + K)
