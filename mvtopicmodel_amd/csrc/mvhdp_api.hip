@@ -723,7 +723,9 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             // serialise behind each other); narrower classes run on the sweep's own stream ahead of the primary.
             bool used[MVHDP_N_CLASSES] = {};
             for (int c = MVHDP_N_CLASSES - 1; c > pc && e == hipSuccess; c--) {       // widest first
-                if (S_cap <= (32 << c)) continue;            // class c holds lists of more than 32 << c topics: not in this corpus
+                // class c holds lists of more than 32 << c topics: skipped when the corpus has none -- except that the
+                // generic class also takes the entities with a view too long for the 16-bit counts of the wide variants
+                if (S_cap <= (32 << c) && !(c == 5 && mdt > 65535)) continue;
                 const int si = (c >= 4) ? 4 : c;
                 hipStream_t st = s;
                 if (c >= 3) {

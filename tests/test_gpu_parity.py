@@ -310,6 +310,28 @@ def test_register_variants_overflow_chain_and_classified_side_streams(force, mod
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["optimistic", "classified"])
+def test_views_longer_than_16_bit_counts_take_the_generic_kernel(mode, monkeypatch):
+    """The 8- and 16-round variants count tokens per slot in 16 bits: an entity with a view of more than 65535 tokens
+    is sent to the generic kernel instead (by the overflow chain, or by the classify pass even when this corpus has no
+    topic list beyond 1024 slots)."""
+    monkeypatch.setenv("MVHDP_FORCE_MODE", mode)
+    K, V = 600, [2000, 40]
+    rng = np.random.RandomState(3)
+    lens0 = np.array([70000, 5, 0, 300, 66000], dtype=np.int64); lens1 = np.array([3, 0, 0, 7, 2], dtype=np.int64)
+    off = [np.concatenate([[0], np.cumsum(l)]) for l in (lens0, lens1)]
+    from mvtopicmodel_amd.synth import Corpus
+    c = Corpus(K, V, off, [rng.randint(0, V[m], off[m][-1]).astype(np.int32) for m in range(2)])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    for it in range(2):
+        ro = o.sweep(it, 5); rs = s.sweep(it, 5)
+        assert rs.tokens == c.total_tokens == ro["stats"]["tokens"]
+        assert_same_state(o, s, 2)
+    s.close()
+
+
 @pytest.mark.parametrize("K,V,D,lam", [
     (1, [30], 20, [6]),                                  # a single topic: FTree of size 1 (no descent)
     (2, [30, 7], 30, [9, 3]),
