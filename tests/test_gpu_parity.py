@@ -366,3 +366,53 @@ def test_eight_views():
         o.sweep(it, 3); s.sweep(it, 3)
         assert_same_state(o, s, 8)
     s.close()
+
+
+@pytest.mark.parametrize("mode,force", [("optimistic", "1"), ("optimistic", "16"), ("classified", "1"), ("classified", "4"), ("classified", "16")])
+def test_inactive_topic_activation_across_kernel_classes(mode, force, monkeypatch):
+    """The truncated-HDP branch with entities spread over several kernel classes: the first delta on an inactive
+    topic (in entity, view, position order, UPD:263-270) is found by atomicMin over every kernel of the sweep."""
+    monkeypatch.setenv("MVHDP_FORCE_MODE", mode); monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
+    K, V = 700, [3000, 60]
+    rng = np.random.RandomState(8)
+    lens0 = np.array([900, 40, 1500, 10, 300, 80, 2500] + [25] * 30, dtype=np.int64)
+    lens1 = rng.randint(0, 9, len(lens0)).astype(np.int64)
+    off = [np.concatenate([[0], np.cumsum(l)]) for l in (lens0, lens1)]
+    from mvtopicmodel_amd.synth import Corpus
+    c = Corpus(K, V, off, [rng.randint(0, V[m], off[m][-1]).astype(np.int32) for m in range(2)])
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[650, 660, 699]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive); hy.alpha[:, K] = 40.0
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(2)]
+    for m in range(2):
+        z0[m][np.isin(z0[m], [650, 660, 699])] = 2
+        o.set_assignments(m, z0[m])
+    o.build_counts()
+    s = make_native(c, hy, z0)
+    activated = []
+    for it in range(3):
+        ro = o.sweep(it, 13); rs = s.sweep(it, 13)
+        assert (ro["stats"]["activated_topic"], ro["stats"]["activated_modality"]) == (rs.activated_topic, rs.activated_modality)
+        assert ro["stats"]["new_mass_cnt"] == rs.new_mass_cnt
+        activated.append(rs.activated_topic)
+        assert_same_state(o, s, 2)
+    assert activated[0] == 650
+    s.close()
+
+
+def test_no_entities_and_a_view_without_tokens():
+    from mvtopicmodel_amd import NativeSampler
+    from mvtopicmodel_amd.synth import Corpus
+    s = NativeSampler(10, [20, 5])
+    for m in range(2):
+        s.set_corpus(m, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32)); s.set_assignments(m, np.zeros(0, dtype=np.int32))
+    s.set_hyper(Hyper.defaults(10, [20, 5])); s.build_counts()
+    assert s.sweep(0, 1).tokens == 0
+    s.close()
+    c = small_corpus(30, [100, 20], 25, [20, 3], 5)
+    c2 = Corpus(30, [100, 20], [c.doc_off[0], np.zeros(c.D + 1, dtype=np.int64)], [c.tokens[0], np.zeros(0, dtype=np.int32)])
+    hy = Hyper.defaults(30, [100, 20])
+    o = make_oracle(c2, hy); s = make_native(c2, hy, [o.get_assignments(m) for m in range(2)])
+    for it in range(2):
+        o.sweep(it, 2); s.sweep(it, 2); assert_same_state(o, s, 2)
+    s.close()
