@@ -553,8 +553,9 @@ std::string FastQMVWVParallelTopicModel::printDocumentTopicsToString(double thre
         for (int64_t doc = d0; doc < d1; doc++) {
             const double* pr = prop.data() + (size_t)(doc - d0) * K;
             for (int k = 0; k < K; k++) order[k] = k;
-            // Arrays.sort(IDSorter[]): descending weight, stable (PTM:2902)
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pr[a] > pr[b]; });
+            // Arrays.sort(IDSorter[]) PTM:2902 with MALLET 2.0.8's IDSorter.compareTo (class file): descending weight,
+            // equal weights by DESCENDING id
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return pr[a] > pr[b] || (pr[a] == pr[b] && a > b); });
             std::string builder = std::to_string(doc) + "\t" + data[(size_t)doc].EntityId + "\t";     // PTM:2862-2869
             for (int i = 0; i < max; i++) {
                 if (pr[order[i]] < threshold) break;                                  // PTM:2905

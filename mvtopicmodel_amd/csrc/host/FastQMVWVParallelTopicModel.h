@@ -140,7 +140,7 @@ public:
 
     // printDocumentTopics PTM:2820-2960 without its JDBC half: per entity the topic proportions
     //   sum_m (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m] * (n_dk + gamma*alpha) / (len + gamma*alphaSum) / sum_m (...)
-    // (device kernel), sorted by weight (stable: ties by topic id), cut at `threshold` and `max`.  The text is the
+    // (device kernel), sorted by IDSorter.compareTo (descending weight, ties by descending topic id), cut at `threshold` and `max`.  The text is the
     // reference's, including its habit of printing the growing line once per retained topic (PTM:2905-2909).
     // discrWeightPerModality comes from the diagnostics (PTM:1370), which are outside this build: all 1 unless set.
     std::vector<double> discrWeightPerModality;                 // PTM:164

@@ -34,7 +34,8 @@ def print_document_topics(prop, names, threshold, max_topics, fmt):
         max_topics = K
     lines = ["#doc name topic proportion ..."]
     for d in range(D):
-        order = sorted(range(K), key=lambda k: -prop[d, k])        # stable: ties keep topic order
+        # cc.mallet.types.IDSorter.compareTo (mallet-2.0.8 class file): weight descending, equal weights by id DESCENDING
+        order = sorted(range(K), key=lambda k: (-prop[d, k], -k))
         builder = f"{d}\t{names[d]}\t"
         for i in range(max_topics):
             k = order[i]

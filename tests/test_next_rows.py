@@ -153,7 +153,7 @@ def test_inferencer_frozen_model_mode():
 @pytest.mark.gpu
 def test_doc_topic_proportions_and_print_document_topics(tmp_path):
     """printDocumentTopics PTM:2820-2960 (text half): device proportions bit-exact against the numpy restatement, and the
-    host mirror's text -- descending weight, ties by topic id, cut at threshold/max, the growing line printed once per
+    host mirror's text -- descending weight, ties by descending topic id (IDSorter.compareTo), cut at threshold/max, the growing line printed once per
     retained topic -- against the same text assembled in Python."""
     from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, java_double_to_string
     from mvtopicmodel_amd import synth
@@ -182,6 +182,10 @@ def test_doc_topic_proportions_and_print_document_topics(tmp_path):
     assert np.array_equal(s.doc_topic_proportions(w, 7, 19), want[7:19])
     s.close()
 
+    # threshold 0, every topic: the many topics an entity does not hold have equal weights and come out by descending id
+    f0 = tmp_path / "doc_topics_all.txt"
+    model.printDocumentTopics(f0, 0.0, -1, discr_weight=discr, p_mean=pmean)
+    assert f0.read_text() == dto.print_document_topics(want, [str(1000 + d) for d in range(c.D)], 0.0, -1, java_double_to_string)
     f = tmp_path / "doc_topics.txt"
     model.printDocumentTopics(f, 0.05, 4, discr_weight=discr, p_mean=pmean)
     text = f.read_text()
