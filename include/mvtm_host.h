@@ -52,6 +52,9 @@ int   mvtm_random_samplers_stream(int64_t seed, int kind, double a, double b, in
 int   mvtm_mallet_next_gamma_stream(int64_t seed, double alpha, double beta, int n, double* out);
 int   mvtm_model_get_perplexities(void* model, int m, double* out, int cap);
 /* printState PTM:3269-3320 (text; gzip when the name ends in .gz) */
+/* displayTopWords PTM:1852-1890 (returns the text length; copies at most cap-1 bytes) and the NumberFormat it uses */
+int   mvtm_model_display_top_words(void* model, int numWords, int usingNewLines, char* out, int cap);
+int   mvtm_number_format5(double v, char* out, int cap);
 int   mvtm_model_print_state(void* model, const char* filename);
 /* printDocumentTopics PTM:2820-2960 (text half; no JDBC): discr_weight[M] / p_mean[M][M] replace the model's when non-NULL */
 int   mvtm_model_print_document_topics(void* model, const char* filename, double threshold, int max,

@@ -531,6 +531,83 @@ std::string FastQMVWVParallelTopicModel::printStateToString()
     return out.str();
 }
 
+// java.text.NumberFormat.getInstance() (en-US DecimalFormat "#,##0.###") with setMaximumFractionDigits(5): HALF_EVEN on
+// the exact binary value, trailing zeros dropped, grouping commas in the integer part, "-0" for a negative that rounds to 0
+std::string FastQMVWVParallelTopicModel::numberFormat5(double v)
+{
+    if (std::isnan(v)) return "\xEF\xBF\xBD";                      // DecimalFormatSymbols NaN = U+FFFD
+    if (std::isinf(v)) return v < 0 ? "-\xE2\x88\x9E" : "\xE2\x88\x9E";
+    char buf[400];
+    snprintf(buf, sizeof buf, "%.5f", std::fabs(v));               // glibc rounds the exact value, ties to even
+    std::string t(buf);
+    std::string ip = t.substr(0, t.find('.')), fp = t.substr(t.find('.') + 1);
+    while (!fp.empty() && fp.back() == '0') fp.pop_back();
+    std::string g;
+    for (size_t i = 0; i < ip.size(); i++) {
+        if (i && (ip.size() - i) % 3 == 0) g += ',';
+        g += ip[i];
+    }
+    std::string out = (std::signbit(v) ? "-" : "") + g;
+    if (!fp.empty()) out += "." + fp;
+    return out;
+}
+
+std::vector<std::vector<std::pair<int32_t, int32_t>>> FastQMVWVParallelTopicModel::getSortedWords(int modality)
+{
+    const int K = numTopics, Vm = numTypes[modality];
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> topicSortedWords((size_t)K);
+    const std::vector<int32_t>& ttc = typeTopicCounts[modality];
+    for (int type = 0; type < Vm; type++)
+        for (int topic = 0; topic < K; topic++) {
+            const int cnt = ttc[(size_t)type * K + topic];
+            if (cnt > 0) topicSortedWords[topic].emplace_back(type, cnt);              // PTM:1803-1806
+        }
+    for (auto& v : topicSortedWords)                                                    // TreeSet<IDSorter>: IDSorter.compareTo
+        std::sort(v.begin(), v.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
+            return a.second > b.second || (a.second == b.second && a.first > b.first);
+        });
+    return topicSortedWords;
+}
+
+std::string FastQMVWVParallelTopicModel::displayTopWords(int numWords, int numLabels, bool usingNewLines)
+{
+    (void)numLabels;
+    const int M = numModalities, K = numTopics;
+    typeTopicCounts.resize(M);
+    for (int m = 0; m < M; m++) {                                                      // the counts only (not z)
+        typeTopicCounts[m].resize((size_t)numTypes[m] * K);
+        check(mvhdp_get_counts(h_, m, typeTopicCounts[m].data(), tokensPerTopic[m].data()), "mvhdp_get_counts");
+    }
+    std::vector<std::vector<std::vector<std::pair<int32_t, int32_t>>>> topicSortedWords;
+    for (int m = 0; m < M; m++) topicSortedWords.push_back(getSortedWords(m));
+    auto word_of = [&](int m, int type) {
+        return (m < (int)alphabet.size() && type < (int)alphabet[m].size()) ? alphabet[m][type] : std::to_string(type);
+    };
+    std::string out;
+    for (int topic = 0; topic < K; topic++) {
+        for (int m = 0; m < M; m++) {
+            const auto& sortedWords = topicSortedWords[m][topic];
+            int word = 1;
+            size_t it = 0;
+            if (usingNewLines) {
+                out += std::to_string(topic) + "\t" + numberFormat5(alpha[m][topic]) + "\n";
+                while (it < sortedWords.size() && word < numWords) {                   // PTM:1869: numWords - 1 of them
+                    out += word_of(m, sortedWords[it].first) + "\t" + numberFormat5((double)sortedWords[it].second) + "\n";
+                    it++; word++;
+                }
+            } else {
+                out += std::to_string(topic) + "\t" + numberFormat5(alpha[m][topic]) + "\t";
+                while (it < sortedWords.size() && word < numWords) {
+                    out += word_of(m, sortedWords[it].first) + "; ";
+                    it++; word++;
+                }
+            }
+        }
+        out += "\n";
+    }
+    return out;
+}
+
 std::string FastQMVWVParallelTopicModel::printDocumentTopicsToString(double threshold, int max)
 {
     const int M = numModalities, K = numTopics;
@@ -610,6 +687,8 @@ void FastQMVWVParallelTopicModel::estimate()
     iterationLog.clear();
     for (int iteration = 1; iteration <= numIterations; iteration++) {   // PTM:1146
         auto t0 = std::chrono::steady_clock::now();
+        if (showTopicsInterval != 0 && iteration != 0 && iteration % showTopicsInterval == 0)   // PTM:1150-1152
+            topWordsLog.emplace_back(iteration, "\n" + displayTopWords(wordsPerTopic, 5, false));
         if (iteration < burninPeriod && M > 1) {                      // PTM:1166-1171
             double v = std::min((double)iteration / 100 + 0.3, 1.1);
             for (int i = 0; i < M; i++) std::fill(p_a[i].begin(), p_a[i].end(), v);
@@ -884,6 +963,23 @@ int mvtm_model_print_document_topics(void* p, const char* filename, double thres
         mdl->printDocumentTopics(filename, threshold, max);
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_model_display_top_words(void* p, int numWords, int usingNewLines, char* out, int cap)
+{
+    try {
+        const std::string t = ((FastQMVWVParallelTopicModel*)p)->displayTopWords(numWords, 5, usingNewLines != 0);
+        if (out && cap > 0) { const int n = std::min<int>((int)t.size(), cap - 1); memcpy(out, t.data(), (size_t)n); out[n] = 0; }
+        return (int)t.size();
+    } catch (const std::exception& e) { g_host_err = e.what(); return -1; }
+}
+
+int mvtm_number_format5(double v, char* out, int cap)
+{
+    const std::string t = FastQMVWVParallelTopicModel::numberFormat5(v);
+    if (cap <= (int)t.size()) return -1;
+    memcpy(out, t.c_str(), t.size() + 1);
+    return (int)t.size();
 }
 
 int mvtm_model_print_state(void* p, const char* filename)

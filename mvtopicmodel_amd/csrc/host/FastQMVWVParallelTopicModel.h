@@ -147,6 +147,17 @@ public:
     std::string printDocumentTopicsToString(double threshold, int max);
     void printDocumentTopics(const std::string& filename, double threshold, int max);
 
+    // getSortedWords PTM:1792-1811 / displayTopWords PTM:1852-1890, what estimate() logs every showTopicsInterval
+    // iterations (PTM:1150-1152).  Order: cc.mallet.types.IDSorter.compareTo of MALLET 2.0.8 (count descending, equal
+    // counts by DESCENDING type id); alpha through java.text.NumberFormat.getInstance() with at most 5 fraction digits
+    // (PTM:221-222; en-US: grouping commas, HALF_EVEN).  Words print as alphabet strings, or the type index when none.
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> getSortedWords(int modality);   // per topic: (type, count)
+    std::string displayTopWords(int numWords, int numLabels, bool usingNewLines);
+    static std::string numberFormat5(double v);
+    int showTopicsInterval = 50;                                // PTM:117
+    int wordsPerTopic = 15;                                     // PTM:118
+    std::vector<std::pair<int, std::string>> topWordsLog;       // (iteration, text) of the PTM:1151 log lines
+
     // the text state format of printState (PTM:3269-3320); gz when the name ends in ".gz".
     // Java's Double.toString is approximated by the shortest round-trip decimal in Java's layout.
     void printState(const std::string& filename);

@@ -14,7 +14,7 @@ HOST_SYMBOLS = [
     "mvtm_model_add_instances", "mvtm_model_estimate", "mvtm_model_num_entities",
     "mvtm_model_view_tokens", "mvtm_model_get_view", "mvtm_model_get_counts",
     "mvtm_model_get_log", "mvtm_model_native_handle", "mvtm_init_assignments",
-    "mvtm_model_print_state", "mvtm_model_print_document_topics", "mvtm_java_double_to_string", "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
+    "mvtm_model_print_state", "mvtm_model_display_top_words", "mvtm_number_format5", "mvtm_model_print_document_topics", "mvtm_java_double_to_string", "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
     "mvtm_model_seed_host_samplers", "mvtm_model_optimize_dp", "mvtm_model_optimize_gamma",
     "mvtm_cokus_stream", "mvtm_rand_antoniak_seq", "mvtm_random_samplers_stream", "mvtm_mallet_next_gamma_stream",
 ]
@@ -51,6 +51,8 @@ def _lib():
         L.mvtm_model_native_handle.argtypes = [vp]; L.mvtm_model_native_handle.restype = vp
         L.mvtm_init_assignments.argtypes = [i32, i32, i64, vp, i64, vp]
         L.mvtm_model_print_state.argtypes = [vp, C.c_char_p]
+        L.mvtm_model_display_top_words.argtypes = [vp, i32, i32, C.c_char_p, i32]
+        L.mvtm_number_format5.argtypes = [dbl, C.c_char_p, i32]
         L.mvtm_model_print_document_topics.argtypes = [vp, C.c_char_p, dbl, i32, vp, vp]
         L.mvtm_java_double_to_string.argtypes = [dbl, C.c_char_p, i32]
         L.mvtm_model_optimize_p.argtypes = [vp, vp, vp]
@@ -66,6 +68,13 @@ def _lib():
         L.mvtm_mallet_next_gamma_stream.argtypes = [i64, dbl, dbl, i32, vp]
         _ready = True
     return L
+
+
+def number_format5(v):
+    """java.text.NumberFormat.getInstance() with at most 5 fraction digits (PTM:221-222)."""
+    buf = C.create_string_buffer(512)
+    n = _lib().mvtm_number_format5(float(v), buf, 512)
+    return buf.value[:n].decode()
 
 
 def java_double_to_string(v):
@@ -199,6 +208,14 @@ class FastQMVWVParallelTopicModel:
     def printState(self, filename):
         if self.L.mvtm_model_print_state(self.p, str(filename).encode()):
             raise RuntimeError(self.L.mvtm_last_error().decode())
+
+    def displayTopWords(self, numWords, usingNewLines=False):
+        n = self.L.mvtm_model_display_top_words(self.p, int(numWords), int(bool(usingNewLines)), None, 0)
+        if n < 0:
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        buf = C.create_string_buffer(n + 1)
+        self.L.mvtm_model_display_top_words(self.p, int(numWords), int(bool(usingNewLines)), buf, n + 1)
+        return buf.value.decode()
 
     def printDocumentTopics(self, filename, threshold, max_topics, discr_weight=None, p_mean=None):
         dw = None if discr_weight is None else np.ascontiguousarray(discr_weight, dtype=np.float64)

@@ -230,3 +230,37 @@ def test_print_state_format(tmp_path):
     assert java_double_to_string(1e-4) == "1.0E-4" and java_double_to_string(0.001) == "0.001"
     assert java_double_to_string(1e7) == "1.0E7" and java_double_to_string(9999999.0) == "9999999.0"
     model.close()
+
+
+def test_number_format_and_display_top_words():
+    """displayTopWords PTM:1852-1890: per topic and view `topic<TAB>alpha<TAB>` then the numWords-1 most frequent types,
+    ordered as MALLET's IDSorter orders them (count descending, equal counts by descending type id), alpha through
+    NumberFormat with at most five fraction digits."""
+    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, number_format5
+    for v, want in [(0.1, "0.1"), (1234567.891234, "1,234,567.89123"), (0.000004, "0"), (0.000005, "0.00001"), (2.5e-6, "0"),
+                    (12.0, "12"), (1000.0, "1,000"), (-0.5, "-0.5"), (999999.999999, "1,000,000"),
+                    (0.123455, "0.12345")]:      # the double below 0.123455: JDK >= 8 rounds the exact binary value (JDK-7131459)
+        assert number_format5(v) == want, (v, number_format5(v), want)
+    K, V = 6, [40, 9]
+    rng = np.random.RandomState(2)
+    lens = [rng.randint(5, 30, 25), rng.randint(0, 4, 25)]
+    training = []
+    for m in range(2):
+        off = np.concatenate([[0], np.cumsum(lens[m])]).astype(np.int64)
+        training.append((np.arange(25, dtype=np.int64), off, rng.randint(0, V[m], off[-1]).astype(np.int32), V[m]))
+    model = FastQMVWVParallelTopicModel(K, 2, 0.1, 0.01)
+    model.setNumIterations(2); model.setRandomSeed(4)
+    model.addInstances(training)
+    model.estimate()
+    text = model.displayTopWords(4)
+    counts = [model.get_counts(m)[0] for m in range(2)]
+    want = ""
+    for topic in range(K):
+        for m in range(2):
+            order = sorted([w for w in range(V[m]) if counts[m][w, topic] > 0], key=lambda w: (-counts[m][w, topic], -w))
+            want += f"{topic}\t0.1\t" + "".join(f"{w}; " for w in order[:3])
+        want += "\n"
+    assert text == want
+    lines = model.displayTopWords(3, usingNewLines=True).splitlines()
+    assert lines[0] == "0\t0.1"
+    model.close()
