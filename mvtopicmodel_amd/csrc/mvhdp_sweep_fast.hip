@@ -1,24 +1,25 @@
-// mvhdp_sweep_fast.hip — the register-resident form of the sweep kernel for
-// entities whose topic list fits 64*RMAX slots (RMAX <= 4: every BASELINE
-// config except the K=1000 power-law one, which takes the generic LDS kernel
-// of mvhdp_kernels.hip).  Same arithmetic, same order, same results as the
-// generic kernel; what changes is where the per-entity state lives:
+// mvhdp_sweep_fast.hip — the register-resident form of the sweep kernel for entities whose topic list
+// fits 64*RMAX slots (RMAX = 1, 2, 4, 8, 16; longer lists take the generic LDS kernel of
+// mvhdp_kernels.hip).  Same arithmetic, same order, same results as the generic kernel; what changes is
+// where the per-entity state lives and when things are fetched:
 //
-//   slot i = lane*R + r  (R = 1,2 or 4 slots per lane, R <= RMAX)  -> lane registers
-//     skr[r]  topic of the slot, sign bit = removed from the list (WRK:451-468)
+//   slot i = lane*R + r  (R = 1 .. 16 slots per lane, R <= RMAX)  -> lane registers
+//     skr[r]  topic of the slot, sign bit = removed from the list (WRK:451-468) or never used
 //     cn[r]   localTopicCounts[m][topic] of the view being sampled (WRK:357,437,560)
 //     oth[r]  totalMassOtherModalities[topic]                       (WRK:399-410)
 //     den[r]  tokensPerTopic[m][topic] + betaSum[m]                 (WRK:507)
 //     onz     bit r: some other view still holds the topic (for WRK:441-448)
-//   g[r]/gn[r] the n_wk values of the listed topics for this token / the next one:
-//     the gather for token t+1 is issued before token t is sampled, so its HBM/L2
-//     latency hides behind a whole token of work (legal because the sweep reads a
-//     snapshot of n_wk: the deltas go to a separate buffer).
-//   topicDocWordMasses (WRK:511) = an in-lane running sum over the lane's R slots plus ONE DPP
-//     prefix scan of the lane totals per token, never stored.
+//   per 64-token chunk, one lane per token ("chunk head"): type, old topic and its slot, the Philox draw, and the
+//     whole F+tree descent of the token's type through the descent table (MvModel::dtab) -- none of it depends
+//     on the entity's state, so 64 descents run side by side instead of one per tree-branch token
+//   per token (mvhdp_sweep_fast_token.inc): the n_wk values of the listed topics, gathered one token ahead (two
+//     for the wide variants, in two register buffers used in turn) -- legal because the sweep reads a snapshot
+//     of n_wk, the deltas go to a separate buffer; topicDocWordMasses (WRK:511) = an in-lane running sum over
+//     the lane's R slots plus ONE DPP prefix scan of the lane totals, never stored
+//   per chunk end: the deltas of the chunk's tokens as two wave-wide atomics, z written back coalesced
 //
-// LDS per wave shrinks to bitmap + prefix + slot->topic + per-view counts
-// (~3.6 KB at K=400, M=3), so occupancy is bound by VGPRs, not LDS.
+// LDS per wave: bitmap + prefix + slot->topic + per-view slot counts (2.6 KB at K=400, M=3; 16-bit counts in
+// the 8- and 16-round variants), so occupancy is bound by VGPRs, not LDS.
 #include "mvhdp_device.h"
 #include "../../include/mvhdp.h"
 #include "mvhdp_wave.h"
