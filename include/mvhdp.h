@@ -99,7 +99,8 @@ typedef struct {
 
 /* sweep flags */
 #define MVHDP_SWEEP_REUSE_TREES 0x1u  /* do not rebuild the F+trees from the counts first (PTM:1209 cadence is the host's) */
-#define MVHDP_SWEEP_NO_APPLY    0x2u  /* leave the deltas unapplied (multi-GPU: all-reduce MVHDP_BUF_DELTA, then mvhdp_apply_delta) */
+#define MVHDP_SWEEP_NO_APPLY    0x2u  /* leave the deltas unapplied (multi-GPU: all-reduce MVHDP_BUF_DELTA, then mvhdp_apply_delta).
+                                       * The delta buffer may be written by the caller only between such a sweep and mvhdp_apply_delta. */
 #define MVHDP_SWEEP_EXACT_CHAIN 0x4u  /* always use the sequential WRK:501-513 sum (test mode for the certified scan) */
 #define MVHDP_SWEEP_GENERIC_KERNEL 0x8u /* force the LDS-resident kernel even when the register-resident one applies (test mode) */
 #define MVHDP_SWEEP_FROZEN      0x10u /* the inferencer's call of the same worker (INF:211-294: nst=1, nut=0): sample against the

@@ -41,6 +41,9 @@ struct mvhdp_ctx {
     std::vector<double> h_alpha;
     std::vector<uint8_t> h_inactive;
     bool have_hyper = false, have_counts = false, have_trees = false;
+    bool full_trees = false;                 // the FTree.tree arrays are current too (a sweep may refresh only the descent table)
+    bool trees_inference = false;            // leaves of the last build: p_wt alone (INF:576)
+    bool delta_clean = false;                // the delta buffer is known to be all zero
 
     unsigned long long* d_stats = nullptr;   // [ST_COUNT]
     long long* d_act_key = nullptr;
@@ -357,15 +360,26 @@ extern "C" int mvhdp_build_counts(mvhdp_handle h)
     return MVHDP_OK;
 }
 
+// The trees are current (have_trees) but the last sweep refreshed only the descent table: write the FTree.tree
+// arrays as well, from the same counts and hyper-parameters (nothing has changed them since, or have_trees were false).
+static int ensure_full_trees(mvhdp_ctx* h)
+{
+    if (!h->have_trees || h->full_trees) return MVHDP_OK;
+    HIPC(h, mvhdp_launch_build_trees(h->mm, h->trees_inference, true, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->full_trees = true;
+    return MVHDP_OK;
+}
+
 extern "C" int mvhdp_build_trees(mvhdp_handle h)
 {
     CHECK_H(h);
     if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "build_trees before set_hyper");
     if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "build_trees before build_counts/set_counts");
     HIPC(h, hipSetDevice(h->device));
-    HIPC(h, mvhdp_launch_build_trees(h->mm, false, h->stream));
+    HIPC(h, mvhdp_launch_build_trees(h->mm, false, true, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
-    h->have_trees = true;
+    h->have_trees = true; h->full_trees = true; h->trees_inference = false;
     return MVHDP_OK;
 }
 
@@ -375,9 +389,9 @@ extern "C" int mvhdp_build_inference_trees(mvhdp_handle h)
     if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "build_inference_trees before set_hyper");
     if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "build_inference_trees before build_counts/set_counts");
     HIPC(h, hipSetDevice(h->device));
-    HIPC(h, mvhdp_launch_build_trees(h->mm, true, h->stream));
+    HIPC(h, mvhdp_launch_build_trees(h->mm, true, true, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
-    h->have_trees = true;
+    h->have_trees = true; h->full_trees = true; h->trees_inference = true;
     return MVHDP_OK;
 }
 
@@ -387,6 +401,7 @@ extern "C" int mvhdp_init_assignments_from_trees(mvhdp_handle h, uint64_t seed)
     int rc = require_corpus(h); if (rc) return rc;
     if (!h->have_trees) FAIL(h, MVHDP_ERR_STATE, "init_assignments_from_trees before build_trees/build_inference_trees");
     HIPC(h, hipSetDevice(h->device));
+    { int rc2 = ensure_full_trees(h); if (rc2) return rc2; }
     HIPC(h, mvhdp_launch_init_from_trees(h->mm, (uint32_t)seed, (uint32_t)(seed >> 32), h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     h->rmax_hint = 0;
@@ -427,6 +442,7 @@ extern "C" int mvhdp_get_tree(mvhdp_handle h, int32_t m, int32_t type, double* t
     if (m < 0 || m >= mm.M || type < 0 || type >= mm.V[m] || !tree) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_tree: bad argument");
     if (!h->have_trees) FAIL(h, MVHDP_ERR_STATE, "get_tree before build_trees");
     HIPC(h, hipSetDevice(h->device));
+    { int rc2 = ensure_full_trees(h); if (rc2) return rc2; }
     HIPC(h, hipStreamSynchronize(h->stream));
     HIPC(h, hipMemcpy(tree, mm.trees + (mm.rowbase[m] + type) * 2 * mm.K, (size_t)2 * mm.K * sizeof(double), hipMemcpyDeviceToHost));
     return MVHDP_OK;
@@ -498,6 +514,7 @@ extern "C" int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_
     HIPC(h, hipMemcpyAsync(&neg, h->d_stats + ST_NEGATIVE, sizeof neg, hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     h->have_trees = false;
+    h->delta_clean = true;                                       // apply_delta_kernel zeroes what it adds
     if (activated_topic >= 0) {                                  // UPD:263-270
         if (activated_topic >= mm.K || activated_modality < 0 || activated_modality >= mm.M)
             FAIL(h, MVHDP_ERR_INVALID_ARG, "apply_delta: bad activation");
@@ -691,8 +708,24 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, s));
         }
     }
-    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) { step(mvhdp_launch_build_trees(mm, false, s)); h->have_trees = true; }
-    step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
+    // FTree.tree itself is read by the generic kernel (and the debug trace) only: when no entity can reach it, the
+    // rebuild refreshes just the descent table (0.13 instead of 0.24 ms at C4)
+    bool need_full = !fast || debug;
+    if (fast && classified) {
+        for (int c = pc + 1; c < MVHDP_N_CLASSES; c++)
+            if (!(S_cap <= (32 << c) && !(c == 5 && mdt > 65535)) && !cls_fast[c]) need_full = true;
+    } else if (fast) {
+        need_full = need_full || n_chain == 0 || S_cap > 64 * chain[n_chain - 1] || mdt > 65535;
+    }
+    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) {
+        step(mvhdp_launch_build_trees(mm, false, need_full, s));
+        h->have_trees = true; h->full_trees = need_full; h->trees_inference = false;
+    } else if (need_full && !h->full_trees) {
+        step(mvhdp_launch_build_trees(mm, h->trees_inference, true, s));
+        h->full_trees = true;
+    }
+    if (!h->delta_clean) step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
+    h->delta_clean = false;
     step(hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
     const long long kmax = LLONG_MAX;
     step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));

@@ -66,7 +66,7 @@ hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens,
 // by level (children always have larger indices, so descending depth is safe)
 // and written out whole, coalesced.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves)
+__global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves, bool write_full)
 {
     extern __shared__ double t[];                  // 2K doubles
     const int K = mm.K, lane = threadIdx.x;
@@ -101,9 +101,11 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
                 __syncthreads();
             }
         }
-        double* out = mm.trees + row * 2 * K;
-        for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
-        if (lane == 0) mm.root[row] = t[1];
+        if (write_full) {                                      // FTree.tree itself: generic kernel, get_tree, init_from_trees
+            double* out = mm.trees + row * 2 * K;
+            for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
+            if (lane == 0) mm.root[row] = t[1];
+        }
         // the same numbers once more, grouped for the descent (see MvModel::dtab)
         double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
         for (int x = lane; x < mm.dt_nblk; x += WAVE) {
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
     }
 }
 
-hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, hipStream_t s)
+hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s)
 {
     int64_t nrows = mm.rowbase[mm.M];
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves);
+    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full);
     return hipGetLastError();
 }
 
