@@ -25,12 +25,16 @@ CASES = {
     "m1_k100": (100, [900], 64, [90], 102, 8, None),
     "m3_k20": (20, [250, 40, 30], 64, [30, 4, 6], 103, 9, None),
     "m3_k100_inactive": (100, [800, 90, 70], 64, [60, 7, 9], 104, 10, [97, 98, 99]),
+    # C5 shape: five views, K=1000, power-law text lengths (a few entities with several hundred topics: the wide kernel
+    # variants and both dispatch modes see this one)
+    "m5_k1000_powerlaw": (1000, [4000, 300, 300, 300, 300], 96, [96, 7, 7, 7, 7], 105, 11, None),
 }
+POWER_LAW = {"m5_k1000_powerlaw"}
 
 
 def build(name):
     K, V, D, lam, cseed, sseed, inactive = CASES[name]
-    c = synth.generate(K, V, D, lam, cseed, chunk_docs=4096)
+    c = synth.generate(K, V, D, lam, cseed, chunk_docs=4096, power_law_text=name in POWER_LAW)
     ina = None
     if inactive:
         ina = np.zeros(K, dtype=np.uint8); ina[inactive] = 1
