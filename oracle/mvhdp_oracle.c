@@ -396,8 +396,12 @@ void orc_build_counts(orc_model* o)
         for (int64_t i = 0; i < o->N[m]; i++) {
             int topic = o->z[m][i];
             if (topic == -1) continue;                               /* PTM:634 */
-            o->nk[(size_t)m * K + topic]++;                          /* PTM:640 */
             int type = o->tokens[m][i];
+            /* A type outside the alphabet cannot occur here in the reference (it would index past typeTopicCounts,
+             * PTM:643); it only exists at inference, where the counts are given.  Both this oracle and the
+             * library leave such a token out of the counts. */
+            if (type < 0 || type >= o->V[m] || topic < 0 || topic >= K) continue;
+            o->nk[(size_t)m * K + topic]++;                          /* PTM:640 */
             o->nwk[(size_t)(o->rowbase[m] + type) * K + topic]++;    /* PTM:643 */
         }
     }

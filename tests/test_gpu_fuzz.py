@@ -1,0 +1,72 @@
+"""Seeded random shapes against the oracle: topics, views, vocabulary sizes, entity lengths (with empty views and
+entities), unassigned tokens, inactive topics, out-of-vocabulary types, primary kernel variant and dispatch mode all
+drawn at random; integers must agree after every sweep."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import assert_same_state, make_native, make_oracle
+from mvtopicmodel_amd.native import Hyper, SWEEP_EXACT_CHAIN, SWEEP_GENERIC_KERNEL
+from mvtopicmodel_amd.synth import Corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.RandomState(seed)
+    M = int(rng.choice([1, 1, 2, 3, 3, 5, 8]))
+    K = int(rng.choice([1, 2, 3, 17, 64, 65, 100, 129, 300, 511, 700, 1200, 2048]))
+    V = [int(rng.randint(1, 3000))] + [int(rng.randint(1, 120)) for _ in range(M - 1)]
+    D = int(rng.randint(1, 40))
+    scale = [int(rng.choice([3, 30, 200, 900]))] + [int(rng.choice([1, 4, 12])) for _ in range(M - 1)]
+    offs, toks = [], []
+    for m in range(M):
+        lens = rng.poisson(scale[m], D).astype(np.int64)
+        lens[rng.rand(D) < 0.15] = 0                                  # entities that lack this view
+        if m == 0 and rng.rand() < 0.5:
+            lens[rng.randint(D)] = int(rng.choice([1500, 2600]))      # one long entity: wide variants / generic kernel
+        off = np.concatenate([[0], np.cumsum(lens)])
+        tk = rng.randint(0, V[m], off[-1]).astype(np.int32)
+        if len(tk) and rng.rand() < 0.2:
+            tk[rng.rand(len(tk)) < 0.05] = V[m] + int(rng.randint(0, 5))   # types outside the vocabulary (WRK:427-428)
+        offs.append(off); toks.append(tk)
+    c = Corpus(K, V, offs, toks)
+    inactive = None
+    if K >= 17 and rng.rand() < 0.4:
+        inactive = np.zeros(K, dtype=np.uint8); inactive[rng.choice(K, size=min(3, K - 1), replace=False)] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive)
+    if inactive is not None:
+        hy.alpha[:, K] = float(rng.choice([0.5, 8.0, 40.0]))
+    hy.gamma[:] = rng.uniform(0.3, 2.0, M)
+    hy.beta[:] = rng.choice([0.01, 0.05, 0.2], M); hy.beta_sum[:] = hy.beta * np.array(V)
+    flags = int(rng.choice([0, 0, 0, SWEEP_EXACT_CHAIN, SWEEP_GENERIC_KERNEL]))
+    env = {"MVHDP_FORCE_MODE": str(rng.choice(["", "optimistic", "classified"])),
+           "MVHDP_FORCE_RMAX": str(rng.choice(["", "", "1", "2", "4", "8", "16"]))}
+    return c, hy, inactive, flags, env, rng
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MVHDP_FUZZ_CASES", "40"))))
+def test_random_shapes(seed, monkeypatch):
+    c, hy, inactive, flags, env, rng = _case(1000 + seed)
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    for m in range(c.M):
+        if inactive is not None:
+            z0[m][np.isin(z0[m], np.flatnonzero(inactive))] = int(np.flatnonzero(inactive == 0)[0])
+        if len(z0[m]) and rng.rand() < 0.3:
+            z0[m][rng.rand(len(z0[m])) < 0.1] = -1                    # UNASSIGNED_TOPIC PTM:63
+        o.set_assignments(m, z0[m])
+    o.build_counts()
+    s = make_native(c, hy, z0)
+    for it in range(3):
+        ro = o.sweep(it, 77 + seed); rs = s.sweep(it, 77 + seed, flags=flags)
+        st = ro["stats"]
+        assert (rs.tokens, rs.changed, rs.new_mass_cnt, rs.topic_doc_mass_cnt, rs.word_ftree_mass_cnt, rs.aborted_docs, rs.oov_skipped) == \
+               (st["tokens"], st["changed"], st["new_mass_cnt"], st["topic_doc_mass_cnt"], st["word_ftree_mass_cnt"], st["aborted_docs"], st["oov_skipped"])
+        assert (rs.activated_topic, rs.activated_modality) == (st["activated_topic"], st["activated_modality"])
+        assert_same_state(o, s, c.M)
+    s.close()
