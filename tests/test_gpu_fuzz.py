@@ -70,3 +70,69 @@ def test_random_shapes(seed, monkeypatch):
         assert (rs.activated_topic, rs.activated_modality) == (st["activated_topic"], st["activated_modality"])
         assert_same_state(o, s, c.M)
     s.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MVHDP_FUZZ_CASES", "40")) // 2))
+def test_random_shapes_statistics_and_shards(seed):
+    """The statistics either side of the sweep (countHistogram, topic/length histograms, view overlap sums, log-likelihood,
+    topic proportions) and the document-shard identity on the same kind of random shapes."""
+    from mvtopicmodel_amd import NativeSampler, synth
+    from mvtopicmodel_amd.native import SWEEP_NO_APPLY
+    from oracle import doc_topics as dto
+    c, hy, inactive, flags, env, rng = _case(5000 + seed)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    if inactive is not None:
+        for m in range(c.M):
+            z0[m][np.isin(z0[m], np.flatnonzero(inactive))] = int(np.flatnonzero(inactive == 0)[0])
+            o.set_assignments(m, z0[m])
+        o.build_counts()
+    s = make_native(c, hy, z0)
+    o.sweep(0, 9); s.sweep(0, 9)
+    M, K = c.M, c.K
+    for m in range(M):
+        mx = int(max(o.get_counts(m)[0].max(), 1))
+        assert np.array_equal(o.count_histogram(m, mx + 1), s.get_count_histogram(m, mx + 1))
+        hl = int(np.diff(c.doc_off[m]).max()) + 1
+        ho, lo_ = o.get_doc_topic_hist(m, hl, hl); hs, ls_ = s.get_doc_topic_hist(m, hl, hl)
+        assert np.array_equal(ho, hs) and np.array_equal(lo_, ls_)
+    if M > 1:
+        assert np.array_equal(o.optimize_p_sums(), s.view_overlap_sums())
+    llo, lls = o.model_log_likelihood(), s.model_log_likelihood()
+    assert np.allclose(llo, lls, rtol=1e-11, atol=1e-9), (llo, lls)
+    w = rng.uniform(0.2, 1.0, M)
+    z = [s.get_assignments(m) for m in range(M)]
+    if all((zz >= 0).all() for zz in z):
+        alpha_now = s.get_alpha()[0]                  # a topic activated by the sweep took over alpha[m][K] (UPD:268)
+        want = dto.doc_topic_proportions(K, c.doc_off, z, alpha_now, hy.alpha_sum, hy.gamma, w)
+        assert np.array_equal(s.doc_topic_proportions(w), want)
+
+    # two or three document shards on the same GPU, deltas summed on the host, against the single sampler
+    n_sh = int(rng.choice([2, 3]))
+    if c.D >= n_sh:
+        tot = sum(np.diff(c.doc_off[m]) for m in range(M))
+        bounds = synth.shard_bounds(tot, n_sh)
+        glob = [s.get_counts(m) for m in range(M)]
+        shards = []
+        for lo, hi in bounds:
+            sub = c.slice_docs(lo, hi)
+            sh = make_native(sub, hy, [z[m][c.doc_off[m][lo]:c.doc_off[m][hi]] for m in range(M)], doc_id_base=lo)
+            for m in range(M):
+                sh.set_counts(m, *glob[m])
+            shards.append(sh)
+        if inactive is not None:                      # replicas must hold the single sampler's alpha / inactive set too
+            a, ina = s.get_alpha()
+            hy2 = Hyper.defaults(K, c.V, inactive=ina); hy2.alpha[:] = a; hy2.alpha_sum[:] = hy.alpha_sum
+            hy2.gamma[:] = hy.gamma; hy2.beta[:] = hy.beta; hy2.beta_sum[:] = hy.beta_sum
+            for sh in shards:
+                sh.set_hyper(hy2)
+        st1 = s.sweep(1, 9, flags=SWEEP_NO_APPLY)
+        sts = [sh.sweep(1, 9, flags=SWEEP_NO_APPLY) for sh in shards]
+        assert sum(x.tokens for x in sts) == st1.tokens and sum(x.changed for x in sts) == st1.changed
+        keys = [x.activation_key for x in sts if x.activated_topic >= 0]
+        assert (min(keys) if keys else None) == (st1.activation_key if st1.activated_topic >= 0 else None)
+        for m in range(M):
+            assert np.array_equal(np.concatenate([sh.get_assignments(m) for sh in shards]), s.get_assignments(m))
+        for sh in shards:
+            sh.close()
+    s.close()
