@@ -95,74 +95,90 @@ def test_single_view_is_plain_lda_path():
     model.close()
 
 
-def test_estimate_with_optimize_steps_matches_oracle_schedule():
-    """Past burn-in, every optimizeInterval iterations estimate() runs optimizeP, optimizeDP, optimizeGamma and
-    optimizeBeta (PTM:1173-1210) before the sweep; the same schedule replayed on the oracle (C sweep + the
-    Python restatement of the two randomised steps, same injected streams) gives the same integers and the
-    same hyper-parameters bit for bit."""
+def _run_schedule(K, V, D, lam, cseed, seed, iters, burnin, interval, alpha=0.1):
+    """estimate() of the host mirror against the same schedule replayed on the oracle (C sweep + the Python restatement
+    of the two randomised steps under the same injected streams).  Returns (model, oracle, hyper state) after `iters`."""
     import math
     from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
     from oracle.binding import Oracle
     from oracle import dp_samplers as dps
     from mvtopicmodel_amd import synth
-    K, V = 30, [400, 50, 40]
-    c = synth.generate(K, V, 150, [40, 6, 5], seed=321, chunk_docs=4096)
-    training = [(np.arange(c.D, dtype=np.int64), c.doc_off[m], c.tokens[m], V[m]) for m in range(3)]
-    model = FastQMVWVParallelTopicModel(K, 3, 0.1, 0.01)
-    model.setNumIterations(10); model.setBurninPeriod(2); model.setOptimizeInterval(2); model.setRandomSeed(5)
+    M = len(V)
+    c = synth.generate(K, V, D, lam, seed=cseed, chunk_docs=4096)
+    training = [(np.arange(c.D, dtype=np.int64), c.doc_off[m], c.tokens[m], V[m]) for m in range(M)]
+    model = FastQMVWVParallelTopicModel(K, M, alpha, 0.01)
+    model.setNumIterations(iters); model.setBurninPeriod(burnin); model.setOptimizeInterval(interval); model.setRandomSeed(seed)
     model.addInstances(training)
 
     o = Oracle(K, V)
-    for m in range(3):
+    for m in range(M):
         o.set_corpus(m, c.doc_off[m], c.tokens[m])
     hy = Hyper.defaults(K, V, p_a=0.2)
+    hy.alpha[:] = alpha; hy.alpha_sum[:] = K * alpha
     inactive = np.zeros(K, dtype=np.uint8)
     push = lambda: o.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, inactive)
     push()
-    o.init_assignments(5)
+    o.init_assignments(seed)
     o.build_counts()
-    present = [c.D] * 3        # every view lists every entity (some with an empty FeatureSequence): totalDocsPerModality PTM:624
-    max_type_count = [int(np.bincount(c.tokens[m], minlength=V[m]).max()) for m in range(3)]
-    hist_len = [int(np.diff(c.doc_off[m]).max()) + 1 for m in range(3)]
+    present = [c.D] * M       # every view lists every entity (some with an empty FeatureSequence): totalDocsPerModality PTM:624
+    max_type_count = [int(np.bincount(c.tokens[m], minlength=V[m]).max()) for m in range(M)]
+    hist_len = [int(np.diff(c.doc_off[m]).max()) + 1 for m in range(M)]
     # the host mirror seeds its stand-ins for the reference's unseedable streams from randomSeed: samp <- seed+1, random <- seed
-    dp = dps.DPState(K, 3, hy.alpha, hy.gamma)
-    statics, samp, rnd = dps.StaticSamplers(), dps.RandomSamplers(dps.JavaRandom(6)), dps.JavaRandom(5)
-    ll_at_10 = None
-    n_opt = 0
-    for it in range(1, 11):
-        if it < 2:
+    dp = dps.DPState(K, M, hy.alpha, hy.gamma)
+    statics, samp, rnd = dps.StaticSamplers(), dps.RandomSamplers(dps.JavaRandom(seed + 1)), dps.JavaRandom(seed)
+    state = dict(n_opt=0, ll=None, activations=0, inactive_seen=0)
+
+    def optimize_round():
+        sums = o.optimize_p_sums()                                   # PTM:2784-2812
+        for m in range(M):
+            for i in range(m + 1, M):
+                pmean = sums[m, i] / min(present[m], present[i])
+                a = 5000 if pmean == 1 else (0.0 if pmean == 0 else -1.0 / math.log(pmean))     # Java: -1.0 / log(0) = -1.0 / -Infinity = 0.0
+                hy.p_a[m, i] = hy.p_a[i, m] = min(a, 100.0)
+                hy.p_b[m, i] = hy.p_b[i, m] = 1.0
+        hists = [o.get_doc_topic_hist(m, hist_len[m], hist_len[m]) for m in range(M)]
+        dp.alpha = [list(map(float, a)) for a in hy.alpha]; dp.gamma = list(map(float, hy.gamma))
+        dp.inactive = set(np.flatnonzero(inactive).tolist())
+        dps.optimize_dp(dp, [h[0] for h in hists], statics, rnd)     # PTM:1184
+        dps.optimize_gamma(dp, [h[1] for h in hists], samp)         # PTM:1185
+        hy.alpha[:] = np.array(dp.alpha); hy.alpha_sum[:] = dp.alphaSum; hy.gamma[:] = dp.gamma
+        inactive[:] = 0; inactive[sorted(dp.inactive)] = 1
+        state["inactive_seen"] = max(state["inactive_seen"], int(inactive.sum()))
+        for m in range(M):                                           # PTM:2293-2366
+            b, bs = o.optimize_beta(m, max_type_count[m])
+            hy.beta[m], hy.beta_sum[m] = b, bs
+
+    for it in range(1, iters + 1):
+        if it < burnin and M > 1:
             hy.p_a[:] = min(it / 100 + 0.3, 1.1)
-        elif it > 2 and it % 2 == 0:
-            n_opt += 1
-            sums = o.optimize_p_sums()                                   # PTM:2784-2812
-            for m in range(3):
-                for i in range(m + 1, 3):
-                    pmean = sums[m, i] / min(present[m], present[i])
-                    a = 5000 if pmean == 1 else -1.0 / math.log(pmean)
-                    hy.p_a[m, i] = hy.p_a[i, m] = min(a, 100.0)
-                    hy.p_b[m, i] = hy.p_b[i, m] = 1.0
-            hists = [o.get_doc_topic_hist(m, hist_len[m], hist_len[m]) for m in range(3)]
-            dp.alpha = [list(map(float, a)) for a in hy.alpha]; dp.gamma = list(map(float, hy.gamma))
-            dp.inactive = set(np.flatnonzero(inactive).tolist())
-            dps.optimize_dp(dp, [h[0] for h in hists], statics, rnd)     # PTM:1184
-            dps.optimize_gamma(dp, [h[1] for h in hists], samp)         # PTM:1185
-            hy.alpha[:] = np.array(dp.alpha); hy.alpha_sum[:] = dp.alphaSum; hy.gamma[:] = dp.gamma
-            inactive[:] = 0; inactive[sorted(dp.inactive)] = 1
-            for m in range(3):                                           # PTM:2293-2366
-                b, bs = o.optimize_beta(m, max_type_count[m])
-                hy.beta[m], hy.beta_sum[m] = b, bs
+        elif it > burnin and interval != 0 and it % interval == 0:
+            state["n_opt"] += 1
+            optimize_round()
         push()
-        r = o.sweep(it, 5)
-        if r["stats"]["activated_topic"] >= 0:                           # UPD:263-270 changed alpha / the inactive set
+        r = o.sweep(it, seed)
+        if r["stats"]["activated_topic"] >= 0:                       # UPD:263-270 changed alpha / the inactive set
             hy.alpha[:] = o.get_alpha(); inactive[:] = o.get_inactive()
-        if it == 10:
-            ll_at_10 = o.model_log_likelihood()
-    assert n_opt == 4
+            state["activations"] += 1
+        if it % 10 == 0:
+            state["ll"] = o.model_log_likelihood()
     model.estimate()
-    for m in range(3):
+    for m in range(M):
         assert np.array_equal(model.get_view(m)[3], o.get_assignments(m)), f"assignments differ in view {m}"
         a, b = model.get_counts(m)
         assert np.array_equal(a, o.get_counts(m)[0]) and np.array_equal(b, o.get_counts(m)[1])
+    return model, o, c, hy, inactive, dp, statics, samp, rnd, optimize_round, state, max_type_count, present, hist_len
+
+
+def test_estimate_with_optimize_steps_matches_oracle_schedule():
+    """Past burn-in, every optimizeInterval iterations estimate() runs optimizeP, optimizeDP, optimizeGamma and
+    optimizeBeta (PTM:1173-1210) before the sweep; the same schedule replayed on the oracle (C sweep + the
+    Python restatement of the two randomised steps, same injected streams) gives the same integers and the
+    same hyper-parameters bit for bit."""
+    from oracle import dp_samplers as dps
+    K, V = 30, [400, 50, 40]
+    model, o, c, hy, inactive, dp, statics, samp, rnd, optimize_round, state, max_type_count, present, hist_len = \
+        _run_schedule(K, V, 150, [40, 6, 5], 321, 5, 10, 2, 2)
+    assert state["n_opt"] == 4
     # one more round of every step, state read back: same numbers as the oracle's next round
     pa, pm = model.optimizeP()
     alpha, asum, ina, tables = model.optimizeDP()
@@ -188,7 +204,22 @@ def test_estimate_with_optimize_steps_matches_oracle_schedule():
     tok = [int(c.doc_off[m][-1]) for m in range(3)]
     for m in range(3):
         per = model.perplexities(m)
-        assert len(per) == 2 and abs(per[1] - ll_at_10[m] / tok[m]) < 1e-9 * abs(per[1])
+        assert len(per) == 2 and abs(per[1] - state["ll"][m] / tok[m]) < 1e-9 * abs(per[1])
+    model.close()
+
+
+@pytest.mark.parametrize("K,V,D,lam,iters,burnin,interval", [
+    (60, [120], 40, [12], 12, 3, 3),                     # one view; far more topics than the corpus can hold: optimizeDP
+                                                         #   leaves topics inactive and the new-topic branch brings some back
+    (8, [300, 30], 120, [25, 4], 9, 2, 2),               # two views, few topics
+    (200, [500, 60, 40, 30, 20], 30, [60, 5, 4, 3, 2], 8, 1, 3),   # five views, entities with a few hundred tokens
+])
+def test_estimate_schedule_on_more_shapes(K, V, D, lam, iters, burnin, interval):
+    model, o, c, hy, inactive, dp, statics, samp, rnd, optimize_round, state, *_ = \
+        _run_schedule(K, V, D, lam, 900 + K, 7, iters, burnin, interval)
+    assert state["n_opt"] >= 2
+    if K == 60:
+        assert state["inactive_seen"] > 0                # optimizeDP did find topics without documents
     model.close()
 
 
