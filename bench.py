@@ -78,8 +78,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the
+            # GPU (torch is not even imported yet); the ranks are children of torch.distributed.run, rank 0
+            # prints the JSON line on the inherited stdout, and this process exits with the launcher's code.
+            import socket
+            import subprocess
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd))
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     import torch
@@ -168,12 +178,14 @@ def main():
     traffic = None
     traffic_note = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc_summary.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_pmc_summary.json")))
         if args.workload == "C4":
             bpt_meas = pm["fetch_bytes_per_token"] + pm["write_bytes_per_token"]
             traffic = local_tokens * bpt_meas / avg_kernel_s / 1e9
-            traffic_note = (f"{bpt_meas:.0f} B/token (FETCH_SIZE+WRITE_SIZE, raw counters, Infinity-Cache hits included) "
-                            "recorded by profiles/profile_c4.sh, not re-measured in this run")
+            traffic_note = (f"{bpt_meas:.0f} B/token = TCC_EA0_RDREQ x 128 B (= 2 x FETCH_SIZE: the gfx950 correction, calibrated "
+                            "on this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits "
+                            "included; PMC passes of profiles/calib.sh on this workload, a rocprofv3 run of its own: the "
+                            "per-token figure is a constant of the kernel build, the rate is this run's")
     except Exception:
         pass
     out = {

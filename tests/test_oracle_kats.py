@@ -221,3 +221,45 @@ def test_philox_p_matches_contract():
     sub = c.slice_docs(10, 20)
     o2 = make_oracle(sub, Hyper.defaults(K, V))
     assert np.array_equal(o2.draw_p_philox(77, 3, doc_id_base=10), p[10:20])
+
+
+def _kat7_run_oracle(seed, with_inactive, m_t, pos_t):
+    from tests import kat7
+    doc_off, toks, z = kat7.corpus()
+    hy = kat7.hyper(with_inactive); p = kat7.view_weights(); nwk, nk = kat7.global_counts()
+    o = binding.Oracle(kat7.K, kat7.V)
+    for m in range(kat7.M):
+        o.set_corpus(m, doc_off[m], toks[m]); o.set_assignments(m, z[m])
+    o.set_hyper(hy["alpha"], hy["alpha_sum"], hy["beta"], hy["beta_sum"], hy["gamma"],
+                np.full((3, 3), 0.31), np.ones((3, 3)), hy["inactive"])
+    for m in range(kat7.M):
+        o.set_counts(m, nwk[m], nk[m])
+    res = o.sweep(0, seed, p=p, flags=binding.SWEEP_NO_APPLY, trace=[(0, m_t, pos_t)])
+    za = [o.get_assignments(m) for m in range(kat7.M)]
+    want, facts = kat7.expected_conditional(hy, p, nwk, nk, kat7.entity_slices(doc_off, z),
+                                            kat7.entity_slices(doc_off, za), m_t, pos_t)
+    return res["trace"][0], want, facts
+
+
+@pytest.mark.parametrize("with_inactive,m_t,pos_t,seed", [(False, 1, 3, 150), (False, 2, 1, 9), (True, 1, 4, 12), (True, 2, 1, 5)])
+def test_kat7_multi_view_mid_document_conditional(with_inactive, m_t, pos_t, seed):
+    """KAT-7 (tests/kat7.py): the multi-view full conditional at a mid-document token of a later view, after a topic
+    has been removed from the dense list (WRK:441-468), a topic outside the list has been entered (Q1) and the removed
+    topic re-sampled (Q2) -- derived in numpy from SURVEY §8a step 4 without the oracle; with_inactive adds a non-empty
+    inActiveTopicIndex (newTopicMass WRK:413-418,515; zero leaves PTM:2670-2671)."""
+    got, want, facts = _kat7_run_oracle(seed, with_inactive, m_t, pos_t)
+    assert facts["removed"] and facts["entered_outside_list"] and facts["reentered_removed"]      # the scenario really is the hard one
+    assert abs(want.sum() - 1.0) < 1e-12
+    assert (want[7] > 0) == with_inactive
+    assert np.allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_kat7_every_history():
+    """The same derivation against 120 different sampled histories (seeds), every later-view position."""
+    worst = 0.0
+    for seed in range(40):
+        for with_inactive in (False, True):
+            for (m_t, pos_t) in ((0, 5), (1, 0), (1, 4), (2, 2)):
+                got, want, _ = _kat7_run_oracle(seed, with_inactive, m_t, pos_t)
+                worst = max(worst, float(np.abs(got - want).max()))
+    assert worst < 1e-12
