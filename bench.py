@@ -69,6 +69,11 @@ def main():
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=60000)
+    ap.add_argument("--live", action="store_true",
+                    help="MVHDP_SWEEP_LIVE: atomics straight on the shared counts (the reference's update discipline); "
+                         "not bit-reproducible, so not the default")
+    ap.add_argument("--live-segments", type=int, default=0, help="F+tree rebuilds per live sweep (0 = library default)")
+    ap.add_argument("--live-steps", type=int, default=5, help="live sweeps timed after the K steps for the 'live' object (0 = none)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks all on cuda:0 with the gloo backend (host-staged all-reduce): exercises the "
                          "sharding logic on a 1-GPU box; not a performance number")
@@ -97,7 +102,7 @@ def main():
     from mvtopicmodel_amd import NativeSampler, synth
     from mvtopicmodel_amd.dist import GpuShard, build_counts_all_reduce, sweep_all_reduce
     from mvtopicmodel_amd.host import init_assignments
-    from mvtopicmodel_amd.native import Hyper
+    from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sweep has no CPU fallback")
@@ -125,12 +130,13 @@ def main():
     total_tokens = int(doc_tokens.sum())
     # initial assignments: the addInstances draw order over the whole corpus (it depends on
     # entity lengths only), of which this rank keeps its slice
+    inactive, K_init = synth.config_inactive(args.workload)
     if lo == 0:
-        z0 = init_assignments(K, corpus.doc_off, seed=1)
+        z0 = init_assignments(K_init, corpus.doc_off, seed=1)
     else:
         lens = synth._doc_lengths(V, 0, hi, cfg["lam"], cfg["seed"], [1.0] + [0.8] * (M - 1), cfg.get("power_law_text", False))
         offs = [np.concatenate([[0], np.cumsum(L)]).astype(np.int64) for L in lens]
-        zfull = init_assignments(K, offs, seed=1)
+        zfull = init_assignments(K_init, offs, seed=1)
         z0 = [zfull[m][offs[m][lo]:offs[m][hi]] for m in range(M)]
         del zfull, lens, offs
 
@@ -138,7 +144,10 @@ def main():
     for m in range(M):
         s.set_corpus(m, corpus.doc_off[m], corpus.tokens[m])
         s.set_assignments(m, z0[m])
-    s.set_hyper(Hyper.defaults(K, V))
+    s.set_hyper(Hyper.defaults(K, V, inactive=inactive))
+    sweep_flags = 0
+    if args.live:
+        sweep_flags = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(args.live_segments)
     shard = GpuShard(s, device, host_staged=args.rehearse_on_one_gpu)
     build_counts_all_reduce(shard)
     local_tokens = corpus.total_tokens
@@ -152,13 +161,14 @@ def main():
             torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        sweep_all_reduce(shard, w, args.seed)
+        sweep_all_reduce(shard, w, args.seed, flags=sweep_flags)
     barrier()
     kernel_ms = []
+    phases = {}
     t0 = time.perf_counter()
     last = None
     for k in range(args.steps):
-        last = sweep_all_reduce(shard, args.warmup + k, args.seed)
+        last = sweep_all_reduce(shard, args.warmup + k, args.seed, flags=sweep_flags, timings=phases)
         kernel_ms.append(last.sweep_kernel_ms)
     barrier()
     dt = time.perf_counter() - t0
@@ -208,10 +218,36 @@ def main():
                                   "tree": last.word_ftree_mass_cnt / max(1, last.tokens)},
                   "exact_fallbacks": last.exact_fallbacks, "total_ms_last": last.total_ms},
         "setup_s": setup_s,
+        # rank 0's milliseconds per step by phase (mvtopicmodel_amd.dist.sweep_all_reduce): host wall time of the
+        # sweep call (view weights, F+tree rebuild, kernels, statistics read-back), of which device time in the sweep
+        # kernels; the collective (device time by events on the shared stream); apply (waits for the collective)
+        "phase_ms": {k: v / max(1, phases.get("n", 1)) for k, v in phases.items() if k != "n"},
+        "update_mode": ("live, %d tree rebuilds per sweep" % (args.live_segments or 4)) if args.live else "deferred (snapshot sweep, bit-reproducible)",
     }
     # order-independent fingerprint of the final global counts: must not depend on the number of shards
     nk_fp = [int(np.asarray(s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]
     out["final_nk_fingerprint"] = nk_fp
+    if not args.live and args.live_steps > 0:
+        # The other update mode, timed after (and outside) the K steps above: MVHDP_SWEEP_LIVE, the reference's own
+        # discipline.  profiles/r02_ll_curves.md: a live sweep is worth one sweep of the CPU reference (0.93-1.0 sweeps
+        # needed per reference sweep on C3), a deferred sweep 0.4-0.7 of one -- quote tokens/s with that in mind.
+        lf = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(args.live_segments)
+        sweep_all_reduce(shard, args.warmup + args.steps, args.seed, flags=lf)
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(args.live_steps):
+            sweep_all_reduce(shard, args.warmup + args.steps + 1 + k, args.seed, flags=lf)
+        barrier()
+        dl = time.perf_counter() - t1
+        if world > 1:
+            tl = torch.tensor([dl], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            dl = float(tl.item())
+        out["live"] = {"value": total_tokens * args.live_steps / dl, "unit": "tokens/s", "steps": args.live_steps,
+                       "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
+                       "note": "MVHDP_SWEEP_LIVE (atomics on the shared n_wk, UPD:197-207), timed after the K deferred steps; "
+                               "sweep-for-sweep equal to the CPU reference (profiles/r02_ll_curves.md), not bit-reproducible"}
+    shard.close()
     s.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample_docs, D_total), 2, args.seed)

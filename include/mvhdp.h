@@ -78,10 +78,23 @@ typedef struct {
     int64_t exact_fallbacks;      /* tokens that left the certified scan for the sequential sum */
     int32_t activated_topic;      /* UPD:263-270: topic leaving inActiveTopicIndex, -1 if none */
     int32_t activated_modality;   /*   and the view whose alpha[m][k] took alpha[m][K] */
-    int64_t activation_key;       /* ordering key (global doc<<24 | view<<20.. see DESIGN.md) of that first delta; INT64_MAX if none */
+    int64_t activation_key;       /* ordering key of that first delta, MVHDP_ACT_KEY(doc, view, pos, topic); INT64_MAX if none */
     double  sweep_kernel_ms;      /* device time of the sweep kernel alone (hipEvents on the handle's stream) */
     double  total_ms;             /* device time of the whole call: trees + view weights + sweep + apply */
 } mvhdp_sweep_stats;
+
+/* Activation key: the FastQDelta that activates a topic first in (global entity, view, position) order wins (UPD:263-270
+ * with a single updater).  One definition for the kernels, the host and any binding (multi-GPU: MIN-all-reduce the key). */
+#define MVHDP_ACT_DOC_SHIFT   34
+#define MVHDP_ACT_VIEW_SHIFT  31
+#define MVHDP_ACT_POS_SHIFT   11
+#define MVHDP_ACT_TOPIC_MASK  0x7ffLL
+#define MVHDP_ACT_VIEW_MASK   0x7LL
+#define MVHDP_ACT_KEY(doc, view, pos, topic) \
+    (((int64_t)(doc) << MVHDP_ACT_DOC_SHIFT) | ((int64_t)(view) << MVHDP_ACT_VIEW_SHIFT) | ((int64_t)(pos) << MVHDP_ACT_POS_SHIFT) | (int64_t)(topic))
+#define MVHDP_ACT_KEY_TOPIC(key) ((int32_t)((key) & MVHDP_ACT_TOPIC_MASK))
+#define MVHDP_ACT_KEY_VIEW(key)  ((int32_t)(((key) >> MVHDP_ACT_VIEW_SHIFT) & MVHDP_ACT_VIEW_MASK))
+#define MVHDP_ACT_KEY_NONE INT64_MAX
 
 /* Optional debug outputs of a sweep (parity tests only; slows the kernel). */
 typedef struct {
@@ -105,6 +118,19 @@ typedef struct {
 #define MVHDP_SWEEP_GENERIC_KERNEL 0x8u /* force the LDS-resident kernel even when the register-resident one applies (test mode) */
 #define MVHDP_SWEEP_FROZEN      0x10u /* the inferencer's call of the same worker (INF:211-294: nst=1, nut=0): sample against the
                                          stored trees and counts, queue no deltas (WRK:587), leave the model untouched */
+
+/* The reference's own update discipline (UPD:197-218 applied WHILE the workers sample; PTM:84-87: racy reads by design):
+ * the sweep's n_wk atomics go straight to the shared count array and every later token of the sweep reads them.  Not
+ * reproducible run to run (like the reference); counts stay consistent with z.  The entities are cut into
+ * MVHDP_SWEEP_LIVE_SEGMENTS(n) interleaved segments (n = 1..255, 0 = library default 4); at each segment boundary the
+ * tokensPerTopic updates of the segment (privatised per workgroup: M*K hot words) land and the F+trees are rebuilt from
+ * the live counts (with REUSE_TREES: no rebuild at all, the host's PTM:1209 cadence).
+ * With NO_APPLY the delta buffer receives (counts after - counts before) of this shard and counts are restored, so the
+ * multi-GPU sequence all-reduce + mvhdp_apply_delta is the same as for a deferred sweep.  Not combinable with FROZEN.
+ * (LIVE_SEGMENTS without LIVE cuts a deferred sweep into the same segments: same integers as one segment.)
+ * A topic activation (UPD:263-270) still takes effect at the end of the sweep, as in the deferred mode. */
+#define MVHDP_SWEEP_LIVE        0x20u
+#define MVHDP_SWEEP_LIVE_SEGMENTS(n) (((uint32_t)(n) & 0xffu) << 16)
 
 /* device buffers a host may hand to a collective (RCCL through torch.distributed or directly) */
 typedef enum {
@@ -174,6 +200,9 @@ int mvhdp_get_view_weights(mvhdp_handle h, double* p /*[D][M][M]*/);
 
 /* ---- interop for collectives and stream sharing ---- */
 int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** dev_ptr, size_t* bytes);
+/* The caller has written MVHDP_BUF_COUNTS through the device pointer (e.g. the all-reduce of the shards' initial
+ * counts): the counts are now valid, any F+trees built from the old values are not. */
+int mvhdp_counts_written(mvhdp_handle h);
 int mvhdp_set_stream(mvhdp_handle h, void* hip_stream /* hipStream_t, NULL = library's own */);
 int mvhdp_synchronize(mvhdp_handle h);
 

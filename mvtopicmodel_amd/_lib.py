@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
     "mvhdp_get_count_histogram", "mvhdp_view_overlap_sums", "mvhdp_model_log_likelihood", "mvhdp_doc_topic_proportions",
     "mvhdp_sweep", "mvhdp_apply_delta", "mvhdp_get_view_weights",
-    "mvhdp_device_buffer", "mvhdp_set_stream", "mvhdp_synchronize",
+    "mvhdp_device_buffer", "mvhdp_counts_written", "mvhdp_set_stream", "mvhdp_synchronize",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library():
     L.mvhdp_apply_delta.argtypes = [vp, i32, i32]
     L.mvhdp_get_view_weights.argtypes = [vp, vp]
     L.mvhdp_device_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.mvhdp_counts_written.argtypes = [vp]
     L.mvhdp_set_stream.argtypes = [vp, vp]
     L.mvhdp_synchronize.argtypes = [vp]
     for name in ABI_SYMBOLS:

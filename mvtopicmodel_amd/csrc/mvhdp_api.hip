@@ -44,6 +44,7 @@ struct mvhdp_ctx {
     bool full_trees = false;                 // the FTree.tree arrays are current too (a sweep may refresh only the descent table)
     bool trees_inference = false;            // leaves of the last build: p_wt alone (INF:576)
     bool delta_clean = false;                // the delta buffer is known to be all zero
+    bool delta_pending = false;              // a NO_APPLY sweep has left deltas that mvhdp_apply_delta has not consumed yet
 
     unsigned long long* d_stats = nullptr;   // [ST_COUNT]
     long long* d_act_key = nullptr;
@@ -503,6 +504,24 @@ static int64_t compute_max_doc_tokens(mvhdp_ctx* h)
     return mx;
 }
 
+// UPD:263-270: the topic leaves inActiveTopicIndex and its alpha[m][k] takes alpha[m][K]
+static int apply_activation(mvhdp_ctx* h, int32_t activated_topic, int32_t activated_modality)
+{
+    MvModel& mm = h->mm;
+    if (activated_topic < 0) return MVHDP_OK;
+    if (activated_topic >= mm.K || activated_modality < 0 || activated_modality >= mm.M)
+        FAIL(h, MVHDP_ERR_INVALID_ARG, "apply_delta: bad activation");
+    if (h->h_inactive[activated_topic]) {
+        h->h_inactive[activated_topic] = 0;
+        h->h_alpha[(size_t)activated_modality * (mm.K + 1) + activated_topic] = h->h_alpha[(size_t)activated_modality * (mm.K + 1) + mm.K];
+        mm.first_inactive = -1;
+        for (int k = 0; k < mm.K; k++) if (h->h_inactive[k]) { mm.first_inactive = k; break; }
+        HIPC(h, hipMemcpy(h->d_alpha, h->h_alpha.data(), h->h_alpha.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPC(h, hipMemcpy(h->d_inactive, h->h_inactive.data(), (size_t)mm.K, hipMemcpyHostToDevice));
+    }
+    return MVHDP_OK;
+}
+
 extern "C" int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_t activated_modality)
 {
     CHECK_H(h);
@@ -515,18 +534,8 @@ extern "C" int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_
     HIPC(h, hipStreamSynchronize(h->stream));
     h->have_trees = false;
     h->delta_clean = true;                                       // apply_delta_kernel zeroes what it adds
-    if (activated_topic >= 0) {                                  // UPD:263-270
-        if (activated_topic >= mm.K || activated_modality < 0 || activated_modality >= mm.M)
-            FAIL(h, MVHDP_ERR_INVALID_ARG, "apply_delta: bad activation");
-        if (h->h_inactive[activated_topic]) {
-            h->h_inactive[activated_topic] = 0;
-            h->h_alpha[(size_t)activated_modality * (mm.K + 1) + activated_topic] = h->h_alpha[(size_t)activated_modality * (mm.K + 1) + mm.K];
-            mm.first_inactive = -1;
-            for (int k = 0; k < mm.K; k++) if (h->h_inactive[k]) { mm.first_inactive = k; break; }
-            HIPC(h, hipMemcpy(h->d_alpha, h->h_alpha.data(), h->h_alpha.size() * sizeof(double), hipMemcpyHostToDevice));
-            HIPC(h, hipMemcpy(h->d_inactive, h->h_inactive.data(), (size_t)mm.K, hipMemcpyHostToDevice));
-        }
-    }
+    h->delta_pending = false;
+    { int rc = apply_activation(h, activated_topic, activated_modality); if (rc) return rc; }
     if (neg) FAIL(h, MVHDP_ERR_NEGATIVE_COUNT, "a topic count went below zero (UPD:202-215)");
     return MVHDP_OK;
 }
@@ -541,7 +550,18 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "sweep before build_counts/set_counts");
     if (flags & MVHDP_SWEEP_FROZEN) flags |= MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY;   // nut == 0: the model is read-only
     if ((flags & MVHDP_SWEEP_REUSE_TREES) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES / FROZEN without trees");
-    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL | MVHDP_SWEEP_FROZEN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL | MVHDP_SWEEP_FROZEN |
+                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff))) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+    const bool live = (flags & MVHDP_SWEEP_LIVE) != 0;
+    if (live && (flags & MVHDP_SWEEP_FROZEN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: LIVE and FROZEN exclude each other");
+    if (h->delta_pending && !(flags & MVHDP_SWEEP_FROZEN))
+        FAIL(h, MVHDP_ERR_STATE, "sweep: the previous NO_APPLY sweep's deltas have not been applied (mvhdp_apply_delta)");
+    // live sweep: the entities are cut into nseg interleaved segments of the longest-first order, the trees are rebuilt
+    // from the live counts before each
+    // (a deferred sweep accepts a segment count too: same integers as one segment, the trees being those of the snapshot)
+    int nseg = (int)((flags >> 16) & 0xffu);
+    if (nseg == 0) nseg = live ? 4 : 1;
+    if ((int64_t)nseg > mm.D) nseg = (int)std::max<int64_t>(1, mm.D);
     const int K = mm.K, M = mm.M;
     HIPC(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -552,9 +572,13 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     S_cap = (S_cap + 63) / 64 * 64;
     SweepLaunch sl{};
     sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
-    sl.flags = flags; sl.S_cap = S_cap;
+    sl.flags = flags & 0xffffu; sl.S_cap = S_cap;
+    sl.q_order_stride = 1;
     // the block's private n_k delta table: in LDS up to 24 KiB (C5: 20 KB), beyond that (e.g. K = 2048 with 8 views:
-    // 64 KB, which would not leave room for the slot state) the deltas go straight to the delta buffer
+    // 64 KB, which would not leave room for the slot state) the deltas go straight to the delta buffer.  A live sweep
+    // keeps the private table too: M*K hot words would take every token's two atomics one after the other at the
+    // memory side (measured on C3: 28 ms per sweep instead of 5.7), so tokensPerTopic becomes current at each
+    // segment end -- together with the trees -- while n_wk is updated in place (UPD:197-207).
     sl.nk_global = ((size_t)M * K * sizeof(int) > 24 * 1024) ? 1 : 0;
     sl.block_shared_bytes = (uint32_t)((((size_t)(sl.nk_global ? 0 : M * K) + MVHDP_HIST_BINS) * sizeof(int) + 15) & ~(size_t)15);
     const bool debug = dbg != nullptr;
@@ -710,22 +734,32 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     }
     // FTree.tree itself is read by the generic kernel (and the debug trace) only: when no entity can reach it, the
     // rebuild refreshes just the descent table (0.13 instead of 0.24 ms at C4)
-    bool need_full = !fast || debug;
+    const bool generic_reachable = S_cap > 1024 || mdt > 65535;      // lists beyond the 16-round variant, or views beyond its 16-bit counts
+    bool need_full = !fast || debug || generic_reachable;
     if (fast && classified) {
         for (int c = pc + 1; c < MVHDP_N_CLASSES; c++)
             if (!(S_cap <= (32 << c) && !(c == 5 && mdt > 65535)) && !cls_fast[c]) need_full = true;
     } else if (fast) {
-        need_full = need_full || n_chain == 0 || S_cap > 64 * chain[n_chain - 1] || mdt > 65535;
+        need_full = need_full || n_chain == 0 || S_cap > 64 * chain[n_chain - 1];
     }
-    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) {
+    auto rebuild_trees = [&]() {
         step(mvhdp_launch_build_trees(mm, false, need_full, s));
         h->have_trees = true; h->full_trees = need_full; h->trees_inference = false;
-    } else if (need_full && !h->full_trees) {
+    };
+    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) rebuild_trees();
+    else if (need_full && !h->full_trees) {
         step(mvhdp_launch_build_trees(mm, h->trees_inference, true, s));
         h->full_trees = true;
     }
-    if (!h->delta_clean) step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
-    h->delta_clean = false;
+    // where the sweep's atomics land: the delta replica (deferred), or the shared counts themselves (live)
+    MvModel mk = mm;
+    if (live) {
+        mk.delta = mm.counts;
+        if (flags & MVHDP_SWEEP_NO_APPLY) { step(mvhdp_launch_live_helper(mm, 0, h->d_stats, s)); h->delta_clean = false; }
+    } else if (!(flags & MVHDP_SWEEP_FROZEN)) {                  // a frozen sweep queues nothing (WRK:587) and leaves the buffer alone
+        if (!h->delta_clean) step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
+        h->delta_clean = false;
+    }
     step(hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
     const long long kmax = LLONG_MAX;
     step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
@@ -733,21 +767,31 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     step(hipEventRecord(h->ev[1], s));
     unsigned long long ovf[1 + MVHDP_HIST_BINS] = {0};      // [0]: two u32 overflow counts, [1..17]: token histogram
     static const int ovf_word[3] = {0, 1, 2 + 2 * MVHDP_HIST_BINS};
-    auto overflow_count = [&](int pass, unsigned int& n) {
-        unsigned int c = 0;
-        step(hipMemcpyAsync(&c, h->d_ovf_meta + ovf_word[pass], sizeof c, hipMemcpyDeviceToHost, s));
-        step(hipStreamSynchronize(s));
-        n = c;
-    };
     auto blocks_for = [&](int64_t n, const Geo& g) {
         int64_t need = (n + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
         return (int)std::max<int64_t>(1, std::min<int64_t>(need, g.grid));
     };
-    step(hipMemsetAsync(h->d_doc_counter, 0, 8 * sizeof(unsigned long long), s));
-    if (e == hipSuccess && mm.D > 0) {
+    // entities of the longest-first order with more than `tokens` tokens: a prefix of that order (0 without the order)
+    auto longer_than = [&](int64_t tokens) -> int64_t {
+        if (h->tokens_desc.empty()) return mm.D;
+        return std::upper_bound(h->tokens_desc.begin(), h->tokens_desc.end(), tokens, std::greater<int64_t>()) - h->tokens_desc.begin();
+    };
+    for (int seg = 0; seg < nseg && e == hipSuccess && mm.D > 0; seg++) {
+        // segment seg = positions seg, seg + nseg, ... of the order; a prefix [0, P) of the order holds share(P) of them
+        auto share = [&](int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
+        const int64_t n_seg = share(mm.D);
+        if (seg > 0) {
+            if (live && !(flags & MVHDP_SWEEP_REUSE_TREES)) rebuild_trees();             // from the live counts
+            step(hipMemsetAsync(h->d_ovf_meta, 0, 2 * sizeof(unsigned int), s));         // overflow counts of passes 1, 2
+            step(hipMemsetAsync(h->d_ovf_meta + ovf_word[2], 0, sizeof(unsigned int), s));
+            step(hipMemsetAsync(class_counts, 0, MVHDP_N_CLASSES * sizeof(unsigned int), s));
+        }
+        step(hipMemsetAsync(h->d_doc_counter, 0, 8 * sizeof(unsigned long long), s));
+        if (e != hipSuccess) break;
         if (classified) {
+            const int64_t H_seg = share(H);
             ClassifyArgs ca{};
-            ca.order = h->d_doc_order; ca.n = H; ca.primary = pc; ca.counts = class_counts;
+            ca.order = h->d_doc_order; ca.n = H_seg; ca.start = seg; ca.stride = nseg; ca.primary = pc; ca.counts = class_counts;
             for (int c = 0; c < MVHDP_N_CLASSES; c++) ca.lists[c] = h->d_lists + (size_t)c * mm.D;
             step(mvhdp_launch_classify(mm, ca, s));
             step(hipEventRecord(h->ev_fork, s));
@@ -759,6 +803,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
                 // class c holds lists of more than 32 << c topics: skipped when the corpus has none -- except that the
                 // generic class also takes the entities with a view too long for the 16-bit counts of the wide variants
                 if (S_cap <= (32 << c) && !(c == 5 && mdt > 65535)) continue;
+                if (H_seg == 0) continue;
                 const int si = (c >= 4) ? 4 : c;
                 hipStream_t st = s;
                 if (c >= 3) {
@@ -776,10 +821,10 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
                 sc.wave_bytes = cls[c].wave_bytes; sc.waves_per_block = cls[c].wpb;
                 if (cls_fast[c]) {
                     sc.S_cap = std::min(S_cap, 64 << c);
-                    step(mvhdp_launch_sweep_fast(mm, sc, 1 << c, blocks_for(H, cls[c]), debug, st));
+                    step(mvhdp_launch_sweep_fast(mk, sc, 1 << c, blocks_for(H_seg, cls[c]), debug, st));
                 } else {
                     sc.S_cap = S_cap;
-                    step(mvhdp_launch_sweep(mm, sc, blocks_for(H, cls[c]), debug, st));
+                    step(mvhdp_launch_sweep(mk, sc, blocks_for(H_seg, cls[c]), debug, st));
                 }
             }
             for (int si = 0; si < MVHDP_N_CLASSES; si++) if (used[si]) step(hipEventRecord(h->ev_join[si], h->side[si]));
@@ -787,49 +832,60 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
                 // the primary variant: the measured entities that fit it, then everything too short to overflow
                 SweepLaunch sp = sl;
                 sp.q_list = ca.lists[pc]; sp.q_list_count = class_counts + pc;
-                sp.q_order = h->d_doc_order; sp.q_order_start = H; sp.q_order_count = mm.D - H;
+                sp.q_order = h->d_doc_order; sp.q_order_start = seg + H_seg * nseg; sp.q_order_stride = nseg; sp.q_order_count = n_seg - H_seg;
                 sp.doc_counter = h->d_doc_counter + pc;
                 sp.wave_bytes = fst[0].wave_bytes; sp.waves_per_block = fst[0].wpb;
                 sp.S_cap = std::min(S_cap, 64 * rmax);
-                step(mvhdp_launch_sweep_fast(mm, sp, rmax, fst[0].grid, debug, s));
+                step(mvhdp_launch_sweep_fast(mk, sp, rmax, blocks_for(n_seg, fst[0]), debug, s));
             }
             for (int si = 0; si < MVHDP_N_CLASSES; si++) if (used[si]) step(hipStreamWaitEvent(s, h->ev_join[si], 0));
         } else if (fast) {
-            const int32_t* list = nullptr;                  // entities of the current pass (nullptr: all, longest first)
-            unsigned int nlist = 0;
-            for (int p = 0; p < n_chain && e == hipSuccess; p++) {
+            // Optimistic chain.  Each later pass reads its entity list and the list's length from device memory (written
+            // by the pass before it, earlier in stream order): no host round trip between passes.  Its grid is sized by
+            // what COULD overflow the pass before -- the entities with more tokens than that variant has slots, a static
+            // prefix of the longest-first order -- and the pass is not launched at all when nothing can.
+            const int32_t* list = nullptr;
+            int64_t bound = n_seg;                                   // upper bound of the entities the next pass can receive
+            for (int p = 0; p < n_chain && e == hipSuccess && bound > 0; p++) {
                 SweepLaunch sp = sl;
                 int32_t* out = (p & 1) ? h->d_overflow2 : h->d_overflow;
-                int64_t n_pass = mm.D;
                 if (p > 0) {
-                    n_pass = (int64_t)nlist;
                     sp.q_list = list; sp.q_list_count = h->d_ovf_meta + ovf_word[p - 1];
                     sp.q_order = nullptr; sp.q_order_start = 0; sp.q_order_count = 0;
                     sp.doc_counter = h->d_doc_counter + p;
                     sp.slot_hist = nullptr;                 // counted in pass 1 already
+                } else {
+                    sp.q_order = h->d_doc_order; sp.q_order_start = seg; sp.q_order_stride = nseg; sp.q_order_count = n_seg;
                 }
                 sp.overflow_list = out; sp.overflow_count = h->d_ovf_meta + ovf_word[p];
                 sp.wave_bytes = fst[p].wave_bytes; sp.waves_per_block = fst[p].wpb;
                 sp.S_cap = std::min(S_cap, 64 * chain[p]);
-                step(mvhdp_launch_sweep_fast(mm, sp, chain[p], blocks_for(n_pass, fst[p]), debug, s));
-                overflow_count(p, nlist);
+                step(mvhdp_launch_sweep_fast(mk, sp, chain[p], blocks_for(bound, fst[p]), debug, s));
                 list = out;
-                if (nlist == 0) break;
+                // a wide (16-bit count) variant also hands on the entities with a view beyond 65535 tokens
+                const int64_t too_long = (chain[p] >= 8 && mdt > 65535) ? share(longer_than(65535)) : 0;
+                bound = std::max<int64_t>((S_cap > 64 * chain[p]) ? share(longer_than((int64_t)64 * chain[p])) : 0, too_long);
             }
-            if (e == hipSuccess && nlist > 0) {
-                // last pass: topic lists beyond the register variants, generic LDS kernel
+            if (e == hipSuccess && bound > 0 && n_chain > 0) {
+                // last pass: topic lists (or views) beyond the register variants, generic LDS kernel
                 SweepLaunch so = sl;
                 so.q_list = list; so.q_list_count = h->d_ovf_meta + ovf_word[n_chain - 1];
                 so.q_order = nullptr; so.q_order_start = 0; so.q_order_count = 0;
                 so.doc_counter = h->d_doc_counter + 4;
                 so.slot_hist = nullptr;
                 so.wave_bytes = gen.wave_bytes; so.waves_per_block = gen.wpb; so.S_cap = S_cap;
-                step(mvhdp_launch_sweep(mm, so, blocks_for((int64_t)nlist, gen), debug, s));
+                step(mvhdp_launch_sweep(mk, so, blocks_for(bound, gen), debug, s));
             }
         } else {
-            sl.wave_bytes = gen.wave_bytes; sl.waves_per_block = gen.wpb;
-            step(mvhdp_launch_sweep(mm, sl, gen.grid, debug, s));
+            SweepLaunch sg = sl;
+            sg.q_order_start = seg; sg.q_order_stride = nseg; sg.q_order_count = n_seg;
+            sg.wave_bytes = gen.wave_bytes; sg.waves_per_block = gen.wpb;
+            step(mvhdp_launch_sweep(mk, sg, blocks_for(n_seg, gen), debug, s));
         }
+    }
+    if (live) {
+        if (flags & MVHDP_SWEEP_NO_APPLY) step(mvhdp_launch_live_helper(mm, 1, h->d_stats, s));   // delta = after - before, counts = snapshot
+        else step(mvhdp_launch_live_helper(mm, 2, h->d_stats, s));                                  // UPD:202-215
     }
     step(hipEventRecord(h->ev[2], s));
     unsigned long long hs[ST_COUNT] = {0};
@@ -839,9 +895,8 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     step(hipMemcpyAsync(ovf, h->d_ovf_meta, sizeof ovf, hipMemcpyDeviceToHost, s));
     step(hipStreamSynchronize(s));
     if (e == hipSuccess && mm.D > 0) {
-        // next sweep: the smallest variant that leaves at most 0.5% of the entities to the overflow pass
-        // (topic lists change slowly between sweeps); entities counted twice (overflow re-run) only
-        // make the choice more conservative
+        // next sweep: the variant that is cheapest for this sweep's topic-list histogram (topic lists change slowly
+        // between sweeps); entities counted twice (overflow re-run) only make the choice more conservative
         std::copy(ovf + 1, ovf + 1 + MVHDP_HIST_BINS, h->last_hist);
         h->rmax_hint = rmax_from_hist(ovf + 1);
     }
@@ -868,10 +923,21 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     st.aborted_docs = (int64_t)hs[ST_ABORT]; st.exact_fallbacks = (int64_t)hs[ST_FALLBACK];
     st.activation_key = act;
     st.activated_topic = -1; st.activated_modality = -1;
-    if (act != LLONG_MAX) { st.activated_topic = (int32_t)(act & 0x7ff); st.activated_modality = (int32_t)((act >> 31) & 0x7); }
+    if (act != LLONG_MAX) { st.activated_topic = MVHDP_ACT_KEY_TOPIC(act); st.activated_modality = MVHDP_ACT_KEY_VIEW(act); }
 
     int ret = MVHDP_OK;
-    if (!(flags & MVHDP_SWEEP_NO_APPLY)) ret = mvhdp_apply_delta(h, st.activated_topic, st.activated_modality);
+    if (flags & MVHDP_SWEEP_FROZEN) {
+        // nothing was queued (WRK:587): the delta buffer is untouched
+    } else if (flags & MVHDP_SWEEP_NO_APPLY) {
+        h->delta_pending = true;
+    } else if (live) {
+        // the counts are already updated; what is left of the updater's work is the topic activation
+        h->have_trees = false;
+        ret = apply_activation(h, st.activated_topic, st.activated_modality);
+        if (ret == MVHDP_OK && hs[ST_NEGATIVE]) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
+    } else {
+        ret = mvhdp_apply_delta(h, st.activated_topic, st.activated_modality);
+    }
     HIPC(h, hipEventRecord(h->ev[3], s));
     HIPC(h, hipEventSynchronize(h->ev[3]));
     float ms_k = 0, ms_t = 0;
@@ -900,9 +966,16 @@ extern "C" int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** de
     CHECK_H(h);
     if (!dev_ptr || !bytes) FAIL(h, MVHDP_ERR_INVALID_ARG, "device_buffer: null");
     size_t b = (size_t)counts_len(h) * sizeof(int32_t);
-    if (which == MVHDP_BUF_COUNTS) { *dev_ptr = h->mm.counts; *bytes = b; h->have_counts = true; h->have_trees = false; return MVHDP_OK; }
+    if (which == MVHDP_BUF_COUNTS) { *dev_ptr = h->mm.counts; *bytes = b; return MVHDP_OK; }
     if (which == MVHDP_BUF_DELTA) { *dev_ptr = h->mm.delta; *bytes = b; return MVHDP_OK; }
     FAIL(h, MVHDP_ERR_INVALID_ARG, "device_buffer: unknown buffer");
+}
+
+extern "C" int mvhdp_counts_written(mvhdp_handle h)
+{
+    CHECK_H(h);
+    h->have_counts = true; h->have_trees = false;
+    return MVHDP_OK;
 }
 
 // ---------------------------------------------------------------------------

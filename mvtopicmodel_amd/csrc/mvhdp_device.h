@@ -51,12 +51,14 @@ struct SweepLaunch {
     long long* act_key;                // activation key (atomicMin)
     // Work queue: waves pull entities in batches from one head.  Queue position q maps to an entity through two
     // segments: first the entities the classify pass listed for this kernel (q_list[0 .. *q_list_count)), then
-    // q_order_count entities of a static order (q_order[q_order_start + ..], or the identity when q_order is null).
+    // q_order_count entities of a static order (q_order[q_order_start + i*q_order_stride], or the identity when q_order
+    // is null).  The stride cuts the longest-first order into interleaved segments (MVHDP_SWEEP_LIVE): every segment
+    // sees the same length distribution, longest first.
     unsigned long long* doc_counter;
     const int32_t* q_list;
     const unsigned int* q_list_count;  // device memory (written by classify_kernel earlier in stream order), or nullptr = 0
     const int32_t* q_order;
-    int64_t q_order_start, q_order_count;
+    int64_t q_order_start, q_order_count, q_order_stride;
     int32_t* overflow_list;            // optimistic mode: entities whose topic list exceeds this variant's slots are appended here
     unsigned int* overflow_count;      //   and re-run by a wider kernel; nullptr in classified mode (an overflow is then an error)
     unsigned long long* slot_hist;     // [17] tokens of the entities with ceil(list size/64) = 1..16, >16 (sizes the next sweep's variant)
@@ -82,6 +84,8 @@ hipError_t mvhdp_launch_init_from_trees(const MvModel& mm, uint32_t seed_lo, uin
 hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s);
 hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s);
+// MVHDP_SWEEP_LIVE helpers: 0 = delta <- -counts, 1 = delta <- counts + delta (after - before), counts <- snapshot, 2 = count negatives
+hipError_t mvhdp_launch_live_helper(const MvModel& mm, int which, unsigned long long* stats, hipStream_t s);
 hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
                                        int32_t* doc_len_counts, int32_t len_len, hipStream_t s);
 hipError_t mvhdp_sweep_set_max_lds(size_t bytes);
@@ -94,8 +98,8 @@ hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const double* w_dev, i
 // Classes of the sweep kernels by topic-list size: 0..4 = the register-resident variants with 64 << c slots, 5 = the generic LDS kernel
 #define MVHDP_N_CLASSES 6
 struct ClassifyArgs {
-    const int32_t* order;              // entities to classify: order[0 .. n) (nullptr = identity)
-    int64_t n;
+    const int32_t* order;              // entities to classify: order[start + i*stride], i in [0, n) (nullptr = identity)
+    int64_t n, start, stride;
     int32_t primary;                   // class of the primary kernel: narrower entities are listed there too
     int32_t* lists[MVHDP_N_CLASSES];   // per class, capacity n
     unsigned int* counts;              // [MVHDP_N_CLASSES]

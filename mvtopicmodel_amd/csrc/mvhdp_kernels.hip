@@ -282,8 +282,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     double* sden = soth + S;
     double* scum = sden + S;
 
-    const int32_t* __restrict__ nwk = mm.counts;
-    const int32_t* __restrict__ nk_all = mm.counts + mm.rowbase[M] * K;
+    // no __restrict__: with MVHDP_SWEEP_LIVE the atomics below update this very array (mm.delta == mm.counts)
+    const int32_t* nwk = mm.counts;
+    const int32_t* nk_all = mm.counts + mm.rowbase[M] * K;
     int32_t* dnwk = mm.delta;
 
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
       for (long long q = q0; q < q1; q++) {
         int64_t d;
         if (q < q_n1) d = (int64_t)sl.q_list[q];
-        else { const int64_t o = sl.q_order_start + (q - q_n1); d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
+        else { const int64_t o = sl.q_order_start + (q - q_n1) * sl.q_order_stride; d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
         const int64_t dg = mm.doc_id_base + d;
 
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                         if (sl.nk_global) __hip_atomic_fetch_add(&dnk_g[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         else __hip_atomic_fetch_add(&nkd[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (mm.first_inactive >= 0 && mm.inactive[znew_l]) {          // UPD:263
-                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)ti << 11) | (long long)znew_l;
+                            long long key = (long long)MVHDP_ACT_KEY(dg, m, ti, znew_l);
                             atomicMin(sl.act_key, key);
                         }
                     }
@@ -666,6 +667,51 @@ hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(apply_delta_kernel, dim3(grid), dim3(256), 0, s, mm.counts, mm.delta, n, stats);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// MVHDP_SWEEP_LIVE helpers.  A live sweep updates `counts` in place (UPD:197-218 applied while the
+// workers sample, as the reference's updater threads do).  For document shards on several GPUs the
+// host still needs "what did THIS shard change": live_begin stores -counts in the delta buffer,
+// live_end turns it into (after - before) and puts the sweep-start snapshot back into counts, so the
+// all-reduce + mvhdp_apply_delta sequence of the deferred mode applies unchanged (AD-LDA: each
+// replica is live for its own documents and one sweep stale for the others).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void live_begin_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ delta, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) delta[i] = -counts[i];
+}
+
+__global__ __launch_bounds__(256) void live_end_kernel(int32_t* __restrict__ counts, int32_t* __restrict__ delta, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = counts[i], dl = delta[i] + c;          // after - before
+        delta[i] = dl;
+        counts[i] = c - dl;                                  // the sweep-start snapshot again
+    }
+}
+
+// UPD:202-215 logs a negative count; a live sweep has no apply pass to notice one, so it is looked for afterwards
+__global__ __launch_bounds__(256) void check_negative_kernel(const int32_t* __restrict__ counts, int64_t n, unsigned long long* stats)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int neg = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) neg += counts[i] < 0;
+    if (neg) atomicAdd(&stats[ST_NEGATIVE], (unsigned long long)neg);
+}
+
+hipError_t mvhdp_launch_live_helper(const MvModel& mm, int which, unsigned long long* stats, hipStream_t s)
+{
+    const int64_t n = mm.rowbase[mm.M] * mm.K + (int64_t)mm.M * mm.K;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    if (which == 0) hipLaunchKernelGGL(live_begin_kernel, dim3(grid), dim3(256), 0, s, mm.counts, mm.delta, n);
+    else if (which == 1) hipLaunchKernelGGL(live_end_kernel, dim3(grid), dim3(256), 0, s, mm.counts, mm.delta, n);
+    else hipLaunchKernelGGL(check_negative_kernel, dim3(grid), dim3(256), 0, s, mm.counts, n, stats);
     return hipGetLastError();
 }
 
@@ -807,7 +853,8 @@ __global__ __launch_bounds__(256) void classify_kernel(MvModel mm, ClassifyArgs 
     };
     const int64_t wstride = (int64_t)gridDim.x * 4;
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < ca.n; q += wstride) {
-        const int64_t d = ca.order ? (int64_t)ca.order[q] : q;
+        const int64_t oq = ca.start + q * ca.stride;
+        const int64_t d = ca.order ? (int64_t)ca.order[oq] : oq;
         bm[wave][lane] = 0;
         LDS_FENCE();
         int64_t longest = 0;

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #define sn_get(idx) (PACK ? (int)((const unsigned short*)sn)[(idx)] : sn[(idx)])
 #define sn_set(idx, v) do { if (PACK) ((unsigned short*)sn)[(idx)] = (unsigned short)(v); else sn[(idx)] = (v); } while (0)
 
-    const int32_t* __restrict__ nwk = mm.counts;
-    const int32_t* __restrict__ nk_all = mm.counts + mm.rowbase[M] * K;
+    // no __restrict__: with MVHDP_SWEEP_LIVE the atomics below update this very array (mm.delta == mm.counts)
+    const int32_t* nwk = mm.counts;
+    const int32_t* nk_all = mm.counts + mm.rowbase[M] * K;
     int32_t* dnwk = mm.delta;
 
     unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
       for (long long q = q0; q < q1; q++) {
         int64_t d;
         if (q < q_n1) d = (int64_t)sl.q_list[q];
-        else { const int64_t o = sl.q_order_start + (q - q_n1); d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
+        else { const int64_t o = sl.q_order_start + (q - q_n1) * sl.q_order_stride; d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
         const int64_t dg = mm.doc_id_base + d;
 
         MVHDP_TSEG(tq);
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                         if (sl.nk_global) __hip_atomic_fetch_add(&dnk_g[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         else __hip_atomic_fetch_add(&nkd[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (mm.first_inactive >= 0 && mm.inactive[znew_l]) {          // UPD:263
-                            long long key = (dg << 34) | ((long long)m << 31) | ((long long)ti << 11) | (long long)znew_l;
+                            long long key = (long long)MVHDP_ACT_KEY(dg, m, ti, znew_l);
                             atomicMin(sl.act_key, key);
                         }
                     }

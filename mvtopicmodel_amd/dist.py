@@ -7,14 +7,24 @@ the tests, where the shard is backed by the test oracle instead of the GPU).
 The reference has no counterpart (single JVM, shared arrays PTM:84-87); the
 sharding follows its worker slices PTM:1051-1098: documents are the independent
 unit, the model is shared.
+
+Stream discipline: the library's kernels and the collective share ONE HIP stream
+(a torch.cuda.Stream handed to mvhdp_set_stream), so sweep -> all-reduce ->
+apply are ordered on the device and the host never waits between them (the
+sweep's own statistics read-back is the only synchronisation per sweep).
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from .native import BUF_COUNTS, BUF_DELTA, SWEEP_NO_APPLY
 
-KEY_NONE = (1 << 63) - 1   # LLONG_MAX: "no activation"
+KEY_NONE = (1 << 63) - 1   # MVHDP_ACT_KEY_NONE: "no activation"
+# include/mvhdp.h MVHDP_ACT_*: doc << 34 | view << 31 | position << 11 | topic (pinned by tests/test_abi.py)
+ACT_DOC_SHIFT, ACT_VIEW_SHIFT, ACT_POS_SHIFT = 34, 31, 11
+ACT_TOPIC_MASK, ACT_VIEW_MASK = 0x7FF, 0x7
 
 
 class _DevArray:
@@ -36,7 +46,7 @@ def device_int32_tensor(ptr, nbytes, device):
 class GpuShard:
     """One NativeSampler (one GPU) as a shard of the global model."""
 
-    def __init__(self, sampler, device, host_staged=False):
+    def __init__(self, sampler, device, host_staged=False, share_stream=True):
         self.s = sampler
         self.device = torch.device(device)
         p, n = sampler.device_buffer(BUF_COUNTS)
@@ -46,6 +56,19 @@ class GpuShard:
         # host_staged: the collective runs on CPU copies (gloo rehearsal of the N>1 path on one GPU)
         self.host_staged = host_staged
         self._counts_host = self._delta_host = None
+        # one stream for the library's kernels and the collectives
+        self.stream = None
+        if share_stream and not host_staged:
+            self.stream = torch.cuda.Stream(device=self.device)
+            sampler.set_stream(self.stream.cuda_stream)
+
+    def close(self):
+        if self.stream is not None and getattr(self.s, "h", None):
+            self.s.set_stream(None)            # back to a stream the library owns before torch drops this one
+        self.stream = None
+
+    def on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else _NullCtx()
 
     @property
     def counts(self):
@@ -61,11 +84,23 @@ class GpuShard:
         self._delta_host = self._delta_dev.cpu()
         return self._delta_host
 
+    def has_inactive(self):
+        """inActiveTopicIndex non-empty (PTM:95)?  Every replica holds the same hyper-parameters, so every rank
+        answers alike."""
+        return bool(self.s.get_alpha()[1].any())
+
     def build_counts_local(self):
         self.s.build_counts()
 
+    def counts_written(self):
+        self.s.counts_written()
+
     def sweep_local(self, sweep_idx, seed, flags=0):
         return self.s.sweep(sweep_idx, seed, flags=flags | SWEEP_NO_APPLY)
+
+    def sweep_and_apply(self, sweep_idx, seed, flags=0):
+        """A single shard needs no exchange step: the library applies its own deltas."""
+        return self.s.sweep(sweep_idx, seed, flags=flags)
 
     def apply(self, topic, modality):
         self.s.apply_delta(topic, modality)
@@ -76,14 +111,25 @@ class GpuShard:
                 self._counts_dev.copy_(self._counts_host); self._counts_host = None
             if self._delta_host is not None:
                 self._delta_dev.copy_(self._delta_host); self._delta_host = None
-        torch.cuda.synchronize(self.device)
+            torch.cuda.synchronize(self.device)
+        elif self.stream is None:
+            torch.cuda.synchronize(self.device)
+        # shared stream: ordered on the device, nothing to wait for
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def decode_activation(key):
-    """(topic, modality) of an activation key (mvhdp.h: doc<<34 | view<<31 | pos<<11 | topic)."""
+    """(topic, modality) of an activation key (include/mvhdp.h MVHDP_ACT_KEY)."""
     if key == KEY_NONE:
         return -1, -1
-    return int(key & 0x7FF), int((key >> 31) & 0x7)
+    return int(key & ACT_TOPIC_MASK), int((key >> ACT_VIEW_SHIFT) & ACT_VIEW_MASK)
 
 
 def build_counts_all_reduce(shard, group=None):
@@ -91,27 +137,69 @@ def build_counts_all_reduce(shard, group=None):
     shard.build_counts_local()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         shard.sync()
-        t = shard.counts
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        with shard.on_stream():
+            t = shard.counts
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         shard.sync()
+        shard.counts_written()
 
 
-def sweep_all_reduce(shard, sweep_idx, seed, group=None, flags=0, has_inactive=False):
+def sweep_all_reduce(shard, sweep_idx, seed, group=None, flags=0, timings=None):
     """One global Gibbs sweep: every shard samples its entities against the same snapshot of
     n_wk / n_k, the deltas are summed across shards, every replica applies the same sum
     (AD-LDA style).  Bit-identical to the single-shard sweep: entities are independent under
-    the snapshot semantics and integer sums do not depend on the order."""
+    the snapshot semantics and integer sums do not depend on the order.  (With MVHDP_SWEEP_LIVE
+    in `flags` a shard is live for its own entities and one sweep stale for the others'.)
+
+    When inActiveTopicIndex is non-empty the first activating delta in (entity, view, position)
+    order must win on every replica alike (UPD:263-270): the 8-byte activation key is
+    MIN-all-reduced -- decided from the replicated hyper-parameters, never by the caller.
+
+    timings: optional dict, accumulates milliseconds per phase: "sweep_call" (host wall time of
+    mvhdp_sweep: view weights + trees + kernels + statistics read-back), "sweep_kernel" (device),
+    "allreduce" (host wall time until the collective is enqueued and, with a shared stream, device
+    time by events), "apply" (host wall time of mvhdp_apply_delta, which waits for the collective)."""
+    t0 = time.perf_counter()
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi and hasattr(shard, "sweep_and_apply"):
+        st = shard.sweep_and_apply(sweep_idx, seed, flags)
+        if timings is not None:
+            timings["sweep_call"] = timings.get("sweep_call", 0.0) + (time.perf_counter() - t0) * 1e3
+            timings["sweep_kernel"] = timings.get("sweep_kernel", 0.0) + st.sweep_kernel_ms
+            timings["sweep_device_total"] = timings.get("sweep_device_total", 0.0) + st.total_ms
+            timings["n"] = timings.get("n", 0) + 1
+        return st
     st = shard.sweep_local(sweep_idx, seed, flags)
+    t1 = time.perf_counter()
     topic, modality = st.activated_topic, st.activated_modality
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    ev = None
+    if multi:
+        need_key = shard.has_inactive()
         shard.sync()
-        t = shard.delta
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        if has_inactive:
-            # UPD:263-270: the first delta in (entity, view, position) order wins, on every replica alike
-            key = torch.tensor([st.activation_key], dtype=torch.int64, device=t.device)
-            dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
-            topic, modality = decode_activation(int(key.item()))
+        with shard.on_stream():
+            if timings is not None and shard.stream is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            t = shard.delta
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if need_key:
+                key = torch.tensor([st.activation_key], dtype=torch.int64, device=t.device)
+                dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
+            if ev is not None:
+                ev[1].record()
+            if need_key:
+                topic, modality = decode_activation(int(key.item()))
         shard.sync()
+    t2 = time.perf_counter()
     shard.apply(topic, modality)
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings["sweep_call"] = timings.get("sweep_call", 0.0) + (t1 - t0) * 1e3
+        timings["sweep_kernel"] = timings.get("sweep_kernel", 0.0) + st.sweep_kernel_ms
+        timings["sweep_device_total"] = timings.get("sweep_device_total", 0.0) + st.total_ms
+        timings["allreduce_host"] = timings.get("allreduce_host", 0.0) + (t2 - t1) * 1e3
+        timings["apply"] = timings.get("apply", 0.0) + (t3 - t2) * 1e3
+        if ev is not None:
+            timings["allreduce_device"] = timings.get("allreduce_device", 0.0) + ev[0].elapsed_time(ev[1])
+        timings["n"] = timings.get("n", 0) + 1
     return st

@@ -18,6 +18,11 @@ SWEEP_NO_APPLY = 0x2
 SWEEP_EXACT_CHAIN = 0x4
 SWEEP_GENERIC_KERNEL = 0x8
 SWEEP_FROZEN = 0x10
+SWEEP_LIVE = 0x20
+
+
+def SWEEP_LIVE_SEGMENTS(n):
+    return (int(n) & 0xFF) << 16
 
 BUF_COUNTS = 0
 BUF_DELTA = 1
@@ -288,6 +293,9 @@ class NativeSampler:
         nbytes = C.c_size_t()
         self._ck(self.L.mvhdp_device_buffer(self.h, int(which), C.byref(ptr), C.byref(nbytes)))
         return ptr.value, nbytes.value
+
+    def counts_written(self):
+        self._ck(self.L.mvhdp_counts_written(self.h))
 
     def set_stream(self, hip_stream):
         self._ck(self.L.mvhdp_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))

@@ -190,9 +190,22 @@ CONFIGS = {
     "C2": dict(K=100, V=[20000], D=50_000, lam=[127], seed=0x5EED0002),
     "C3": dict(K=200, V=[50000, 5000, 5000], D=200_000, lam=[127, 7, 15], seed=0x5EED0003),
     "C4": dict(K=400, V=[50000, 5000, 5000], D=1_000_000, lam=[127, 7, 15], seed=0x5EED0004),
+    # truncated HDP: the top 10 % of the topic ids start in inActiveTopicIndex (PTM:95, as optimizeDP
+    # leaves topics no document holds, PTM:2450), alpha[m][K] > 0; initial assignments use the active topics only
     "C5": dict(K=1000, V=[50000, 5000, 5000, 5000, 5000], D=1_000_000, lam=[96, 7, 7, 7, 7],
-               seed=0x5EED0005, power_law_text=True),
+               seed=0x5EED0005, power_law_text=True, inactive_from=900),
 }
+
+
+def config_inactive(name):
+    """uint8[K] membership of inActiveTopicIndex at the start (None when the config has none) and the number of
+    topics the initial assignments may use."""
+    c = CONFIGS[name]
+    if "inactive_from" not in c:
+        return None, c["K"]
+    ina = np.zeros(c["K"], dtype=np.uint8)
+    ina[c["inactive_from"]:] = 1
+    return ina, c["inactive_from"]
 
 
 def make_config(name, D=None, doc_lo=0, doc_hi=None):

@@ -59,3 +59,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert not pat.search(src), (dp, f, pat.search(src).group(0))
+
+
+def test_activation_key_layout_is_defined_once():
+    """include/mvhdp.h owns the layout of the activation key (MVHDP_ACT_*); the Python host side must agree with it
+    (a binding written from the header -- JNI, ctypes -- decodes the multi-GPU winner with these shifts)."""
+    from mvtopicmodel_amd import dist, native
+    hdr = open(os.path.join(ROOT, "include", "mvhdp.h")).read()
+    val = lambda name: int(re.search(r"#define\s+%s\s+(0x[0-9a-fA-F]+|\d+)" % name, hdr).group(1), 0)
+    assert (val("MVHDP_ACT_DOC_SHIFT"), val("MVHDP_ACT_VIEW_SHIFT"), val("MVHDP_ACT_POS_SHIFT")) == \
+           (dist.ACT_DOC_SHIFT, dist.ACT_VIEW_SHIFT, dist.ACT_POS_SHIFT) == (34, 31, 11)
+    assert val("MVHDP_ACT_TOPIC_MASK") == dist.ACT_TOPIC_MASK == 0x7FF and val("MVHDP_ACT_VIEW_MASK") == dist.ACT_VIEW_MASK == 0x7
+    # the fields do not overlap at the documented maxima: topic < 2048, position < 2^20, view < 8, entity < 2^29
+    assert val("MVHDP_MAX_TOPICS") - 1 <= dist.ACT_TOPIC_MASK and (1 << 20) - 1 < (1 << (dist.ACT_VIEW_SHIFT - dist.ACT_POS_SHIFT))
+    assert val("MVHDP_MAX_MODALITIES") - 1 <= dist.ACT_VIEW_MASK and dist.ACT_DOC_SHIFT + 29 <= 63
+    key = (123456 << dist.ACT_DOC_SHIFT) | (3 << dist.ACT_VIEW_SHIFT) | (77 << dist.ACT_POS_SHIFT) | 1999
+    assert dist.decode_activation(key) == (1999, 3) and dist.decode_activation(dist.KEY_NONE) == (-1, -1)
+    # the sweep flags of the Python mirror are the header's
+    for name in ("REUSE_TREES", "NO_APPLY", "EXACT_CHAIN", "GENERIC_KERNEL", "FROZEN", "LIVE"):
+        assert getattr(native, "SWEEP_" + name) == int(re.search(r"#define\s+MVHDP_SWEEP_%s\s+(0x[0-9a-fA-F]+)u" % name, hdr).group(1), 16)
+    assert native.SWEEP_LIVE_SEGMENTS(5) == 5 << 16

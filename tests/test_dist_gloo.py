@@ -58,6 +58,16 @@ class OracleShard:
             setattr(s, k, v)
         return s
 
+    def on_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def has_inactive(self):
+        return bool(self.o.get_inactive().any())
+
+    def counts_written(self):
+        pass
+
     def apply(self, topic, modality):
         dn, dk = self._split(self.delta)
         self.o.apply_delta(dn, dk, topic, modality)
@@ -121,7 +131,7 @@ def _worker(rank, world, port, with_inactive, out_dir):
     build_counts_all_reduce(shard)
     acts = []
     for it in range(3):
-        sweep_all_reduce(shard, it, 4242, has_inactive=with_inactive)
+        sweep_all_reduce(shard, it, 4242)          # default arguments: the key reduction is decided from the hyper-parameters
         acts.append((int(shard.o.get_inactive().sum())))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi,
              **{f"z{m}": shard.o.get_assignments(m) for m in range(c.M)},

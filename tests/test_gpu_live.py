@@ -1,0 +1,151 @@
+"""MVHDP_SWEEP_LIVE: the reference's own update discipline -- the updater applies every delta to the shared count
+arrays while the workers are still sampling (UPD:197-218, racy reads by design PTM:84-87).  A live sweep is not
+reproducible run to run, so it is tested the way the reference could be: through what must hold whatever the
+interleaving (the counts are exactly the counts of z, nothing negative, every token visited once, the branch counters
+add up), through the bit-exact deferred sweep run over the same interleaved segments, and through the statistics
+(log-likelihood after n sweeps within a whisker of the deferred sweeps')."""
+import numpy as np
+import pytest
+
+from mvtopicmodel_amd.native import Hyper, SWEEP_FROZEN, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_NO_APPLY
+from mvtopicmodel_amd._lib import MvhdpError
+from tests.helpers import assert_same_state, make_native, make_oracle, small_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _recount(c, z, K):
+    out = []
+    for m in range(c.M):
+        nwk = np.zeros((c.V[m], K), dtype=np.int64)
+        np.add.at(nwk, (c.tokens[m], z[m]), 1)
+        out.append(nwk)
+    return out
+
+
+def _check_counts_are_counts_of_z(c, s, K):
+    z = [s.get_assignments(m) for m in range(c.M)]
+    want = _recount(c, z, K)
+    for m in range(c.M):
+        nwk, nk = s.get_counts(m)
+        assert nwk.min() >= 0 and nk.min() >= 0
+        assert np.array_equal(nwk.astype(np.int64), want[m]), f"n_wk is not the count of z in view {m}"
+        assert np.array_equal(nk.astype(np.int64), want[m].sum(axis=0)), f"n_k is not the column sum in view {m}"
+
+
+@pytest.mark.parametrize("nseg", [0, 1, 3, 7])
+@pytest.mark.parametrize("K,V,D,lam,cseed", [(20, [300, 40, 50], 200, [30, 4, 6], 31), (200, [3000, 300, 300], 300, [127, 7, 15], 32)])
+def test_live_sweep_invariants(K, V, D, lam, cseed, nseg):
+    c = small_corpus(K, V, D, lam, cseed)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    for it in range(4):
+        st = s.sweep(it, 77, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(nseg))
+        assert st.tokens == c.total_tokens and st.aborted_docs == 0 and st.oov_skipped == 0
+        assert st.new_mass_cnt + st.topic_doc_mass_cnt + st.word_ftree_mass_cnt == st.tokens       # WRK:33-35
+        assert 0 < st.changed <= st.tokens
+        _check_counts_are_counts_of_z(c, s, K)
+    s.close()
+
+
+@pytest.mark.parametrize("force,mode", [("1", "optimistic"), ("2", "classified"), ("8", "optimistic"), ("", "")])
+@pytest.mark.parametrize("nseg", [2, 5])
+def test_deferred_sweep_over_segments_is_bit_exact(nseg, force, mode, monkeypatch):
+    """The segmented launch path itself (interleaved queue segments, per-segment classify / overflow chain) under the
+    deferred contract: same integers as the oracle, whatever the number of segments, variant or dispatch mode."""
+    if force:
+        monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
+    if mode:
+        monkeypatch.setenv("MVHDP_FORCE_MODE", mode)
+    K, V = 300, [2000, 200, 150]
+    c = small_corpus(K, V, 157, [200, 9, 12], 33)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    for it in range(3):
+        o.sweep(it, 5)
+        st = s.sweep(it, 5, flags=SWEEP_LIVE_SEGMENTS(nseg))
+        assert st.tokens == c.total_tokens
+        assert_same_state(o, s, c.M)
+    s.close()
+
+
+def test_live_no_apply_returns_this_shards_delta_and_restores_the_snapshot():
+    K, V = 50, [600, 80]
+    c = small_corpus(K, V, 150, [40, 6], 34)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    before = [s.get_counts(m) for m in range(c.M)]
+    st = s.sweep(0, 9, flags=SWEEP_LIVE | SWEEP_NO_APPLY)
+    assert st.tokens == c.total_tokens
+    for m in range(c.M):                                   # the counts are the sweep-start snapshot again
+        a, b = s.get_counts(m)
+        assert np.array_equal(a, before[m][0]) and np.array_equal(b, before[m][1])
+    with pytest.raises(MvhdpError):                        # the deltas are pending: the next sweep must not drop them
+        s.sweep(1, 9)
+    s.apply_delta(-1, -1)
+    _check_counts_are_counts_of_z(c, s, K)                 # snapshot + (after - before) == counts of the new z
+    s.sweep(1, 9)
+    _check_counts_are_counts_of_z(c, s, K)
+    s.close()
+
+
+def test_live_flag_errors():
+    K, V = 10, [50]
+    c = small_corpus(K, V, 20, [8], 35)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(0)])
+    s.build_trees()
+    with pytest.raises(MvhdpError):
+        s.sweep(0, 1, flags=SWEEP_LIVE | SWEEP_FROZEN)
+    s.close()
+
+
+def test_live_inactive_topic_is_activated_at_sweep_end():
+    K, V = 30, [400, 50, 60]
+    c = small_corpus(K, V, 90, [25, 4, 6], 36)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[25, 28]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive)
+    hy.alpha[:, K] = 30.0
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(c.M)]
+    for m in range(c.M):
+        z[m][np.isin(z[m], [25, 28])] = 2
+    s = make_native(c, hy, z)
+    act = 0
+    for it in range(4):
+        st = s.sweep(it, 3, flags=SWEEP_LIVE)
+        if st.activated_topic >= 0:
+            act += 1
+            a, ina = s.get_alpha()
+            assert ina[st.activated_topic] == 0 and a[st.activated_modality, st.activated_topic] == 30.0     # UPD:268
+        _check_counts_are_counts_of_z(c, s, K)
+    assert act >= 1
+    s.close()
+
+
+def test_live_and_deferred_sweeps_reach_the_same_likelihood():
+    """Statistics, small scale (the curves at C3 size are in profiles/r02_ll_curves.md): after the same number of sweeps
+    from the same start both runs improved a lot, the live run is at least as far as the deferred one (every token of a
+    deferred sweep sees sweep-start counts, so it mixes more slowly -- the smaller the corpus the more) and not far from it."""
+    K, V = 40, [1500, 200, 200]
+    c = small_corpus(K, V, 1500, [60, 6, 8], 37)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    out = {}
+    for name, flags in (("deferred", 0), ("live", SWEEP_LIVE)):
+        s = make_native(c, hy, z0)
+        ll0 = s.model_log_likelihood().sum() / c.total_tokens
+        for it in range(40):
+            s.sweep(it, 123, flags=flags)
+        out[name] = (ll0, s.model_log_likelihood().sum() / c.total_tokens)
+        s.close()
+    (a0, a1), (b0, b1) = out["deferred"], out["live"]
+    assert a0 == b0
+    assert a1 > a0 + 0.3 and b1 > b0 + 0.3
+    assert b1 > a1 - 0.005 * abs(a1)
+    assert abs(a1 - b1) < 0.06 * abs(a1)

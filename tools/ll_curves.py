@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Is a deferred (snapshot) sweep worth a reference sweep?  LL/token per view against the number of sweeps for
+
+  cpu       the reference's update discipline restated on the CPU (oracle/ref_threaded.c: sampler threads read the
+            counts and trees while updater threads apply the deltas, PTM:1036-1101, UPD:164-297)
+  deferred  the GPU sweep under the parity contract (every token sampled against the sweep-start counts)
+  live      the GPU sweep with MVHDP_SWEEP_LIVE (atomics on the shared counts, trees rebuilt n times per sweep)
+
+all from the same corpus, the same initial assignments (PTM:465-515 with java.util.Random(1)) and the same fixed
+hyper-parameters (alpha 0.1, beta 0.01, gamma 1, p_a 0.31 = iteration 1 of the burn-in schedule, PTM:1168).  The
+log-likelihood is modelLogLikelihood (PTM:3322-3452) in both implementations (they agree to 1e-12, tests/test_next_rows.py).
+
+  python tools/ll_curves.py cpu --workload C3 --docs 200000 --sweeps 100 --every 5 --out profiles/r02_ll_cpu.json
+  python tools/ll_curves.py gpu --workload C3 --docs 200000 --sweeps 100 --every 5 --out gpurun_out/r02_ll_gpu.json
+  python tools/ll_curves.py table profiles/r02_ll_cpu.json profiles/r02_ll_gpu.json > profiles/r02_ll_curves.md
+
+This is a measurement tool (it uses the oracle for the CPU leg), not product code.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def load(workload, docs):
+    from mvtopicmodel_amd import synth
+    from mvtopicmodel_amd.native import Hyper
+    c = synth.make_config(workload, D=docs)
+    inactive, K_init = synth.config_inactive(workload)
+    hy = Hyper.defaults(c.K, c.V, inactive=inactive)
+    return c, hy, K_init
+
+
+def run_cpu(args):
+    from oracle.binding import Oracle
+    c, hy, K_init = load(args.workload, args.docs)
+    o = Oracle(c.K, c.V)
+    for m in range(c.M):
+        o.set_corpus(m, c.doc_off[m], c.tokens[m])
+    o.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, hy.inactive)
+    if K_init == c.K:
+        o.init_assignments(1)
+    else:
+        from mvtopicmodel_amd.host import init_assignments
+        z0 = init_assignments(K_init, c.doc_off, seed=1)
+        for m in range(c.M):
+            o.set_assignments(m, z0[m])
+    o.build_counts()
+    ntok = np.array([int(c.doc_off[m][-1]) for m in range(c.M)], dtype=np.float64)
+    T = args.threads
+    curve = [{"sweep": 0, "ll_per_token": (o.model_log_likelihood() / ntok).tolist()}]
+    secs = 0.0
+    for it in range(1, args.sweeps + 1):
+        # one iteration per call: every call starts at iteration 1 of the burn-in schedule (p_a = 0.31) and rebuilds
+        # the trees first, like the GPU sweeps it is compared with
+        s, st = o.threaded_estimate(T, 1, args.seed + it)
+        secs += s
+        if it % args.every == 0 or it == args.sweeps:
+            curve.append({"sweep": it, "ll_per_token": (o.model_log_likelihood() / ntok).tolist(),
+                          "changed_frac": st["changed"] / max(1, st["tokens"])})
+            print(f"cpu sweep {it}: LL/token {curve[-1]['ll_per_token']}  ({secs:.0f} s)", flush=True)
+    out = {"runs": {f"cpu reference topology ({3 * T // 4} samplers + {T // 4} updaters)": curve},
+           "workload": args.workload, "docs": c.D, "tokens": c.total_tokens, "cpu_seconds": secs}
+    json.dump(out, open(args.out, "w"), indent=1)
+
+
+def run_gpu(args):
+    from mvtopicmodel_amd import NativeSampler
+    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.native import SWEEP_LIVE, SWEEP_LIVE_SEGMENTS
+    c, hy, K_init = load(args.workload, args.docs)
+    z0 = init_assignments(K_init, c.doc_off, seed=1)
+    ntok = np.array([int(c.doc_off[m][-1]) for m in range(c.M)], dtype=np.float64)
+    runs = {}
+    modes = [("gpu deferred (snapshot sweep)", 0)]
+    for n in args.live_segments:
+        modes.append((f"gpu live, {n} tree rebuild(s) per sweep", SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(n)))
+    for name, flags in modes:
+        s = NativeSampler(c.K, c.V)
+        for m in range(c.M):
+            s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z0[m])
+        s.set_hyper(hy); s.build_counts()
+        curve = [{"sweep": 0, "ll_per_token": (s.model_log_likelihood() / ntok).tolist()}]
+        ms = 0.0
+        for it in range(1, args.sweeps + 1):
+            st = s.sweep(it, args.seed, flags=flags)
+            ms += st.total_ms
+            if it % args.every == 0 or it == args.sweeps:
+                curve.append({"sweep": it, "ll_per_token": (s.model_log_likelihood() / ntok).tolist(),
+                              "changed_frac": st.changed / max(1, st.tokens), "ms_per_sweep": ms / it})
+        print(f"{name}: final LL/token {curve[-1]['ll_per_token']}  {ms / args.sweeps:.2f} ms/sweep", flush=True)
+        runs[name] = curve
+        s.close()
+    json.dump({"runs": runs, "workload": args.workload, "docs": c.D, "tokens": c.total_tokens}, open(args.out, "w"), indent=1)
+
+
+def table(args):
+    runs = {}
+    meta = None
+    for f in args.files:
+        j = json.load(open(f))
+        runs.update(j["runs"])
+        meta = meta or j
+    names = list(runs)
+    sweeps = sorted({p["sweep"] for r in runs.values() for p in r})
+    M = len(next(iter(runs.values()))[0]["ll_per_token"])
+    print(f"# LL/token against the number of sweeps: {meta['workload']}, {meta['docs']} entities, {meta['tokens']} tokens\n")
+    print("modelLogLikelihood (PTM:3322-3452) divided by the view's token count; same corpus, same initial assignments, "
+          "same fixed hyper-parameters for every run (tools/ll_curves.py).\n")
+    for m in range(M):
+        print(f"## view {m}\n")
+        print("| sweeps | " + " | ".join(names) + " |")
+        print("|---|" + "---|" * len(names))
+        for sw in sweeps:
+            row = []
+            for n in names:
+                v = [p["ll_per_token"][m] for p in runs[n] if p["sweep"] == sw]
+                row.append(f"{v[0]:.4f}" if v else "")
+            print(f"| {sw} | " + " | ".join(row) + " |")
+        print()
+    # how many sweeps of each run reach the LL the cpu run has after n sweeps (view 0)
+    cpu = [n for n in names if n.startswith("cpu")]
+    if cpu:
+        ref = runs[cpu[0]]
+        print("## sweeps needed to reach the LL/token of the CPU run (view 0, linear interpolation between samples)\n")
+        others = [n for n in names if n not in cpu]
+        print("| cpu sweeps | cpu LL/token | " + " | ".join(others) + " |")
+        print("|---|---|" + "---|" * len(others))
+        for p in ref:
+            if p["sweep"] == 0:
+                continue
+            target = p["ll_per_token"][0]
+            row = []
+            for n in others:
+                xs = [q["sweep"] for q in runs[n]]
+                ys = [q["ll_per_token"][0] for q in runs[n]]
+                hit = ""
+                for i in range(1, len(xs)):
+                    if ys[i] >= target > ys[i - 1]:
+                        hit = f"{xs[i - 1] + (target - ys[i - 1]) / (ys[i] - ys[i - 1]) * (xs[i] - xs[i - 1]):.1f}"
+                        break
+                if not hit:
+                    hit = "0" if ys[0] >= target else f">{xs[-1]}"
+                row.append(hit)
+            print(f"| {p['sweep']} | {target:.4f} | " + " | ".join(row) + " |")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    for name in ("cpu", "gpu"):
+        p = sub.add_parser(name)
+        p.add_argument("--workload", default="C3")
+        p.add_argument("--docs", type=int, default=200000)
+        p.add_argument("--sweeps", type=int, default=100)
+        p.add_argument("--every", type=int, default=5)
+        p.add_argument("--seed", type=int, default=20260101)
+        p.add_argument("--out", required=True)
+        if name == "cpu":
+            p.add_argument("--threads", type=int, default=8)
+        else:
+            p.add_argument("--live-segments", type=int, nargs="*", default=[1, 4, 16])
+    p = sub.add_parser("table")
+    p.add_argument("files", nargs="+")
+    args = ap.parse_args()
+    {"cpu": run_cpu, "gpu": run_gpu, "table": table}[args.cmd](args)
+
+
+if __name__ == "__main__":
+    main()
