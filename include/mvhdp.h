@@ -178,7 +178,9 @@ int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums /*[M][M]*/);
 int mvhdp_model_log_likelihood(mvhdp_handle h, double* log_likelihood /*[M]*/);
 /* printDocumentTopics PTM:2871-2899 (and the inferencer's INF:383-411): topic proportions of entities [d0, d1),
  * out[(d-d0)*K + k] = sum_m w[m]*(n_dk[m][k] + gamma[m]*alpha[m][k])/(len[m] + gamma[m]*alphaSum[m]) / sum_m w[m],
- * w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m].  A view the entity lacks counts as an empty one. */
+ * w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m].  As in the reference, whose topicCounts[m] / docLen[m]
+ * are refreshed only when the entity has view m (PTM:2873-2886), an entity WITHOUT view m is scored with n_dk[m] and
+ * len[m] of the last earlier entity of this handle that had it (zeros before the first). */
 int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_weights /*[M]*/, int64_t d0, int64_t d1, double* out /*[d1-d0][K]*/);
 
 /* ---- the hot path ---- */

@@ -1,6 +1,7 @@
 // FastQMVWVParallelTopicModel.cpp — see the header.  Host logic only; every
 // per-token operation happens in libmvhdp's kernels.
 #include "FastQMVWVParallelTopicModel.h"
+#include "FastQMVWVTopicInferencer.h"
 
 #include <algorithm>
 #include <chrono>
@@ -617,31 +618,19 @@ std::string FastQMVWVParallelTopicModel::printDocumentTopicsToString(double thre
     pushHyper();
     std::vector<double> w((size_t)M);
     for (int m = 0; m < M; m++) w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m];   // PTM:2895
-    if (max < 0 || max > K) max = K;                                                 // PTM:2834-2836
-    std::string out = "#doc name topic proportion ...\n";                            // PTM:2823
-    const int64_t D = (int64_t)data.size();
-    const int64_t batch = std::max<int64_t>(1, (int64_t)(64 << 20) / (K * 8));      // 64 MB of proportions at a time
-    std::vector<double> prop;
-    std::vector<int> order((size_t)K);
-    for (int64_t d0 = 0; d0 < D; d0 += batch) {
-        const int64_t d1 = std::min(D, d0 + batch);
-        prop.assign((size_t)(d1 - d0) * K, 0.0);
-        check(mvhdp_doc_topic_proportions(h_, w.data(), d0, d1, prop.data()), "mvhdp_doc_topic_proportions");
-        for (int64_t doc = d0; doc < d1; doc++) {
-            const double* pr = prop.data() + (size_t)(doc - d0) * K;
-            for (int k = 0; k < K; k++) order[k] = k;
-            // Arrays.sort(IDSorter[]) PTM:2902 with MALLET 2.0.8's IDSorter.compareTo (class file): descending weight,
-            // equal weights by DESCENDING id
-            std::sort(order.begin(), order.end(), [&](int a, int b) { return pr[a] > pr[b] || (pr[a] == pr[b] && a > b); });
-            std::string builder = std::to_string(doc) + "\t" + data[(size_t)doc].EntityId + "\t";     // PTM:2862-2869
-            for (int i = 0; i < max; i++) {
-                if (pr[order[i]] < threshold) break;                                  // PTM:2905
-                builder += std::to_string(order[i]) + "\t" + javaDoubleToString(pr[order[i]]) + "\t";
-                out += builder; out += "\n";                                          // PTM:2909: the whole builder, every time
-            }
-        }
-    }
-    return out;
+    std::vector<std::string> names;
+    names.reserve(data.size());
+    for (auto& e : data) names.push_back(e.EntityId);
+    return formatDocumentTopics(h_, names, K, w, threshold, max);
+}
+
+std::unique_ptr<FastQMVWVTopicInferencer> FastQMVWVParallelTopicModel::getInferencer()
+{
+    if (!h_) throw std::runtime_error("getInferencer() before addInstances()");
+    syncFromDevice(false);                                       // typeTopicCounts / tokensPerTopic as trained so far
+    return std::unique_ptr<FastQMVWVTopicInferencer>(new FastQMVWVTopicInferencer(
+        numTypes, alpha, alphaSum, typeTopicCounts, tokensPerTopic, beta, betaSum, gamma, numTopics, numModalities,
+        p_a, p_b, discrWeightPerModality, pMean));
 }
 
 void FastQMVWVParallelTopicModel::printDocumentTopics(const std::string& filename, double threshold, int max)
@@ -702,7 +691,8 @@ void FastQMVWVParallelTopicModel::estimate()
         }
         pushHyper();
         mvhdp_sweep_stats st;
-        check(mvhdp_sweep(h_, (uint32_t)iteration, seed, 0, nullptr, nullptr, &st), "mvhdp_sweep");  // PTM:1213-1239
+        const uint32_t sweepFlags = liveUpdates_ ? (MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(liveSegments_)) : 0u;
+        check(mvhdp_sweep(h_, (uint32_t)iteration, seed, sweepFlags, nullptr, nullptr, &st), "mvhdp_sweep");  // PTM:1213-1239
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         iterationLog.push_back({iteration, ms, st});
         if (iteration % 10 == 0 && printLogLikelihood) {               // PTM:1296-1304
@@ -738,6 +728,13 @@ static thread_local std::string g_host_err;
 extern "C" {
 
 const char* mvtm_last_error(void) { return g_host_err.c_str(); }
+void mvtm_set_last_error(const char* msg) { g_host_err = msg ? msg : ""; }
+
+int mvtm_model_set_live_updates(void* p, int live, int tree_rebuilds_per_sweep)
+{
+    ((FastQMVWVParallelTopicModel*)p)->setLiveUpdates(live != 0, tree_rebuilds_per_sweep);
+    return 0;
+}
 
 void* mvtm_model_new(int K, int M, double alpha, double beta)
 {

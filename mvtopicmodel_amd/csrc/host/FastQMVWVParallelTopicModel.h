@@ -9,6 +9,7 @@
 // INTEGRATION.md.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -18,6 +19,8 @@
 #include "knowceans_samplers.h"
 
 namespace mvtm {
+
+class FastQMVWVTopicInferencer;
 
 // MALLET Instance restricted to what the path reads: getName() (PTM:437) and the
 // FeatureSequence indices of getData() (PTM:427).
@@ -76,6 +79,9 @@ public:
     void setNumThreads(int threads) { numThreads = threads; }   // a hint only: parallelism is the GPU's
     void setDevice(int device) { device_ = device; }
     void setDocIdBase(int64_t base) { docIdBase_ = base; }      // document shards: global id of entity 0
+    // Update discipline of the sweeps estimate() runs: false = deferred (snapshot sweep, bit-reproducible: the parity
+    // contract), true = MVHDP_SWEEP_LIVE (the updater threads' own discipline, UPD:197-218; profiles/r02_ll_curves.md)
+    void setLiveUpdates(bool live, int treeRebuildsPerSweep = 0) { liveUpdates_ = live; liveSegments_ = treeRebuildsPerSweep; }
 
     // PTM:396.  batchId / vectorSize / previousModel are outside the hot path (previousModel must be null).
     void addInstances(const std::vector<InstanceList>& training, const std::string& batchId = "", int vectorSize = 0);
@@ -146,6 +152,8 @@ public:
     std::vector<double> discrWeightPerModality;                 // PTM:164
     std::string printDocumentTopicsToString(double threshold, int max);
     void printDocumentTopics(const std::string& filename, double threshold, int max);
+    // PTM:3457-3463: a tool for estimating topic distributions of new documents with this model frozen
+    std::unique_ptr<FastQMVWVTopicInferencer> getInferencer();
 
     // getSortedWords PTM:1792-1811 / displayTopWords PTM:1852-1890, what estimate() logs every showTopicsInterval
     // iterations (PTM:1150-1152).  Order: cc.mallet.types.IDSorter.compareTo of MALLET 2.0.8 (count descending, equal
@@ -181,6 +189,8 @@ private:
     mvhdp_handle h_ = nullptr;
     int device_ = 0;
     int64_t docIdBase_ = 0;
+    bool liveUpdates_ = false;
+    int liveSegments_ = 0;
 };
 
 }  // namespace mvtm

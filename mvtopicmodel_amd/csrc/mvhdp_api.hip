@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <functional>
 #include <climits>
+#include <mutex>
+#include <set>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +47,7 @@ struct mvhdp_ctx {
     bool trees_inference = false;            // leaves of the last build: p_wt alone (INF:576)
     bool delta_clean = false;                // the delta buffer is known to be all zero
     bool delta_pending = false;              // a NO_APPLY sweep has left deltas that mvhdp_apply_delta has not consumed yet
+    bool device_released = false;            // release_device_resources has run (mvhdp_destroy, or the exit handler)
 
     unsigned long long* d_stats = nullptr;   // [ST_COUNT]
     long long* d_act_key = nullptr;
@@ -57,12 +60,47 @@ struct mvhdp_ctx {
     hipStream_t side[MVHDP_N_CLASSES]{};     // one stream per wider kernel class (created on first use)
     hipEvent_t ev_fork = nullptr, ev_join[MVHDP_N_CLASSES]{};
     std::vector<int64_t> tokens_desc;        // entity token counts, descending (the order of d_doc_order)
+    int64_t* d_carry[MVHDP_MAXM]{};          // doc_topic_proportions: per view, the entity whose view-m counts score entity d (lazily built)
     unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class, from the last sweep (or the probe)
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
     size_t lds_attr_set = 0;
 };
 
-#define CHECK_H(h) do { if (!(h)) return MVHDP_ERR_INVALID_ARG; } while (0)
+// ---- handle registry and process exit ------------------------------------------------------------------
+// Every live handle is listed here.  The first mvhdp_create registers an atexit handler; it is registered AFTER the
+// HIP runtime initialised (hipGetDeviceCount in mvhdp_create comes first), so at exit it runs BEFORE the runtime's own
+// teardown: it releases the device resources of every handle still open and marks the process as exiting.  A host that
+// closes a handle later than that -- a JVM finalizer or shutdown hook calling NativeSampler.close(), a static destructor
+// of the embedding program -- reaches mvhdp_destroy with g_exiting set: no HIP call is made any more, only host memory is
+// released.  mvhdp_destroy of a pointer that is not (or no longer) a live handle is refused instead of dereferenced.
+static std::mutex g_reg_mutex;
+static std::set<mvhdp_ctx*>* g_live = nullptr;          // heap-allocated and never freed: usable during static destruction
+static bool g_exiting = false, g_atexit_registered = false;
+static void release_device_resources(mvhdp_ctx* h);
+
+static void mvhdp_at_exit()
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    g_exiting = true;
+    if (g_live) for (mvhdp_ctx* h : *g_live) release_device_resources(h);     // the runtime is still alive here
+}
+
+static void register_handle(mvhdp_ctx* h)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    if (!g_live) g_live = new std::set<mvhdp_ctx*>();
+    g_live->insert(h);
+    if (!g_atexit_registered) { atexit(mvhdp_at_exit); g_atexit_registered = true; }
+}
+
+static bool is_live(mvhdp_ctx* h)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    return g_live && g_live->count(h) != 0;
+}
+
+#define CHECK_H(h) do { if (!(h) || !is_live(h)) return MVHDP_ERR_INVALID_ARG; \
+                        if ((h)->device_released) return MVHDP_ERR_STATE; /* the process is exiting */ } while (0)
 #define HIPC(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
 #define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
@@ -98,7 +136,7 @@ static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * 
 
 extern "C" const char* mvhdp_version(void) { return "mvhdp 0.1 (gfx950)"; }
 
-extern "C" const char* mvhdp_last_error(mvhdp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+extern "C" const char* mvhdp_last_error(mvhdp_handle h) { return (h && is_live(h)) ? h->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
 {
@@ -123,6 +161,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
         return MVHDP_ERR_NO_DEVICE;
     }
     mvhdp_ctx* h = new mvhdp_ctx();
+    register_handle(h);
     h->cfg = *cfg;
     h->device = cfg->device;
     h->num_cus = prop.multiProcessorCount;
@@ -176,37 +215,37 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     return MVHDP_OK;
 }
 
+// frees everything the handle holds on the device; idempotent (every pointer is cleared)
+static void release_device_resources(mvhdp_ctx* h)
+{
+    if (h->device_released) return;
+    h->device_released = true;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
+    for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); }
+    fr(h->mm.counts); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
+    fr(h->d_alpha); fr(h->d_inactive); fr(h->d_stats); fr(h->d_act_key); fr(h->d_doc_counter);
+    fr(h->d_doc_order); fr(h->d_overflow); fr(h->d_overflow2); fr(h->d_ovf_meta); fr(h->d_lists);
+    for (auto& e : h->ev) if (e) { hipEventDestroy(e); e = nullptr; }
+    if (h->ev_fork) { hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
+    for (auto& e : h->ev_join) if (e) { hipEventDestroy(e); e = nullptr; }
+    for (auto& st : h->side) if (st) { hipStreamDestroy(st); st = nullptr; }
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = nullptr;
+}
+
 extern "C" int mvhdp_destroy(mvhdp_handle h)
 {
     if (!h) return MVHDP_OK;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    for (int m = 0; m < MVHDP_MAXM; m++) {
-        if (h->d_doc_off[m]) hipFree(h->d_doc_off[m]);
-        if (h->d_tok[m]) hipFree(h->d_tok[m]);
-        if (h->d_z[m]) hipFree(h->d_z[m]);
+    bool exiting;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        if (!g_live || g_live->erase(h) == 0) return MVHDP_ERR_INVALID_ARG;      // not a live handle (closed twice?)
+        exiting = g_exiting;
     }
-    if (h->mm.counts) hipFree(h->mm.counts);
-    if (h->mm.delta) hipFree(h->mm.delta);
-    if (h->mm.trees) hipFree(h->mm.trees);
-    if (h->mm.root) hipFree(h->mm.root);
-    if (h->mm.dtab) hipFree(h->mm.dtab);
-    if (h->mm.p) hipFree(h->mm.p);
-    if (h->d_alpha) hipFree(h->d_alpha);
-    if (h->d_inactive) hipFree(h->d_inactive);
-    if (h->d_stats) hipFree(h->d_stats);
-    if (h->d_act_key) hipFree(h->d_act_key);
-    if (h->d_doc_counter) hipFree(h->d_doc_counter);
-    if (h->d_doc_order) hipFree(h->d_doc_order);
-    if (h->d_overflow) hipFree(h->d_overflow);
-    if (h->d_overflow2) hipFree(h->d_overflow2);
-    if (h->d_ovf_meta) hipFree(h->d_ovf_meta);
-    for (auto& e : h->ev) if (e) hipEventDestroy(e);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    for (auto& e : h->ev_join) if (e) hipEventDestroy(e);
-    for (auto& st : h->side) if (st) hipStreamDestroy(st);
-    if (h->d_lists) hipFree(h->d_lists);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    // after the exit handler has run the HIP runtime may be gone: it released the device side already, touch nothing
+    if (!exiting) release_device_resources(h);
     delete h;
     return MVHDP_OK;
 }
@@ -269,6 +308,7 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     if (h->d_overflow) { hipFree(h->d_overflow); h->d_overflow = nullptr; }
     if (h->d_overflow2) { hipFree(h->d_overflow2); h->d_overflow2 = nullptr; }
     if (h->d_lists) { hipFree(h->d_lists); h->d_lists = nullptr; }
+    for (auto& c : h->d_carry) if (c) { hipFree(c); c = nullptr; }
     h->rmax_hint = 0;
     mm.D = D;
     mm.doc_off[m] = (const int64_t*)h->d_doc_off[m];
@@ -1047,12 +1087,26 @@ extern "C" int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_we
     if (!view_weights || !out || d0 < 0 || d1 > mm.D || d0 > d1) FAIL(h, MVHDP_ERR_INVALID_ARG, "doc_topic_proportions: bad range or null buffer");
     if (d1 == d0) return MVHDP_OK;
     HIPC(h, hipSetDevice(h->device));
+    DocTopicCarry carry{};
+    for (int m = 0; m < mm.M; m++) {
+        if (!h->d_carry[m]) {                              // PTM:2873-2886: a missing view keeps the previous entity's counts
+            std::vector<int64_t> src((size_t)mm.D);
+            int64_t last = -1;
+            for (int64_t d = 0; d < mm.D; d++) {
+                if (h->h_doc_off[m][d + 1] > h->h_doc_off[m][d]) last = d;
+                src[(size_t)d] = last;
+            }
+            HIPC(h, hipMalloc(&h->d_carry[m], (size_t)mm.D * sizeof(int64_t)));
+            HIPC(h, hipMemcpy(h->d_carry[m], src.data(), (size_t)mm.D * sizeof(int64_t), hipMemcpyHostToDevice));
+        }
+        carry.src[m] = h->d_carry[m];
+    }
     double *d_w = nullptr, *d_out = nullptr;
     const size_t n = (size_t)(d1 - d0) * mm.K;
     hipError_t e = hipMalloc(&d_w, (size_t)mm.M * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&d_out, n * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_w, view_weights, (size_t)mm.M * sizeof(double), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = mvhdp_launch_doc_topic_prop(mm, d_w, d0, d1, d_out, h->stream);
+    if (e == hipSuccess) e = mvhdp_launch_doc_topic_prop(mm, carry, d_w, d0, d1, d_out, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (d_w) hipFree(d_w);

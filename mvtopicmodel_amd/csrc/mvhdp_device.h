@@ -94,7 +94,8 @@ hipError_t mvhdp_launch_view_overlap(const MvModel& mm, double* out, hipStream_t
 hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
                                unsigned long long* nonzero, hipStream_t s);
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s);
-hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const double* w_dev, int64_t d0, int64_t d1, double* out_dev, hipStream_t s);
+struct DocTopicCarry { const int64_t* src[MVHDP_MAXM]; };   // per view [D]: the entity whose counts score entity d (PTM:2873-2886)
+hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const DocTopicCarry& carry, const double* w_dev, int64_t d0, int64_t d1, double* out_dev, hipStream_t s);
 // Classes of the sweep kernels by topic-list size: 0..4 = the register-resident variants with 64 << c slots, 5 = the generic LDS kernel
 #define MVHDP_N_CLASSES 6
 struct ClassifyArgs {

@@ -200,8 +200,11 @@ hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double
 //   sum_m w[m] * (n_dk[m][k] + gamma[m]*alpha[m][k]) / (len[m] + gamma[m]*alphaSum[m])  /  sum_m w[m]
 // with w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m], products and quotient in the
 // reference's left-to-right order.  One wave per entity, counts in LDS.
+// The reference reuses topicCounts[m] / docLen[m] across its entity loop and refreshes them only when the entity HAS
+// view m (PTM:2873-2886): an entity without view m is scored with the counts and length of the last earlier entity
+// that had it (zeros before the first).  carry.src[m][d] names that entity (d itself when it has the view, -1 none).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void doc_topic_prop_kernel(MvModel mm, const double* __restrict__ w, int64_t d0, int64_t d1, double* out)
+__global__ __launch_bounds__(64) void doc_topic_prop_kernel(MvModel mm, DocTopicCarry carry, const double* __restrict__ w, int64_t d0, int64_t d1, double* out)
 {
     extern __shared__ int ndk[];                           // [M][K]
     const int lane = threadIdx.x, K = mm.K, M = mm.M;
@@ -209,7 +212,9 @@ __global__ __launch_bounds__(64) void doc_topic_prop_kernel(MvModel mm, const do
         for (int i = lane; i < M * K; i += WAVE) ndk[i] = 0;
         __syncthreads();
         for (int m = 0; m < M; m++) {
-            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
+            const int64_t sd = carry.src[m][d];
+            if (sd < 0) continue;
+            const int64_t b = mm.doc_off[m][sd], e = mm.doc_off[m][sd + 1];
             for (int64_t i = b + lane; i < e; i += WAVE) { const int zz = mm.z[m][i]; if (zz >= 0 && zz < K) atomicAdd(&ndk[m * K + zz], 1); }
         }
         __syncthreads();
@@ -219,7 +224,8 @@ __global__ __launch_bounds__(64) void doc_topic_prop_kernel(MvModel mm, const do
         for (int k = lane; k < K; k += WAVE) {
             double tp = 0;
             for (int m = 0; m < M; m++) {
-                const int len = (int)(mm.doc_off[m][d + 1] - mm.doc_off[m][d]);
+                const int64_t sd = carry.src[m][d];
+                const int len = sd < 0 ? 0 : (int)(mm.doc_off[m][sd + 1] - mm.doc_off[m][sd]);
                 tp += w[m] * ((double)ndk[m * K + k] + mm.gamma[m] * mm.alpha[(int64_t)m * (K + 1) + k]) / (len + mm.gamma[m] * mm.alpha_sum[m]);
             }
             o[k] = tp / norm;
@@ -228,11 +234,11 @@ __global__ __launch_bounds__(64) void doc_topic_prop_kernel(MvModel mm, const do
     }
 }
 
-hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const double* w_dev, int64_t d0, int64_t d1, double* out_dev, hipStream_t s)
+hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const DocTopicCarry& carry, const double* w_dev, int64_t d0, int64_t d1, double* out_dev, hipStream_t s)
 {
     if (d1 <= d0) return hipSuccess;
     int64_t n = d1 - d0;
     int grid = (int)(n < 16384 ? n : 16384);
-    hipLaunchKernelGGL(doc_topic_prop_kernel, dim3(grid), dim3(64), (size_t)mm.M * mm.K * sizeof(int), s, mm, w_dev, d0, d1, out_dev);
+    hipLaunchKernelGGL(doc_topic_prop_kernel, dim3(grid), dim3(64), (size_t)mm.M * mm.K * sizeof(int), s, mm, carry, w_dev, d0, d1, out_dev);
     return hipGetLastError();
 }

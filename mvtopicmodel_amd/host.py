@@ -1,7 +1,9 @@
-"""ctypes view of the C++ host mirror of FastQMVWVParallelTopicModel
-(csrc/host/, hooks declared in include/mvtm_host.h)."""
+"""ctypes view of the C++ host mirror of FastQMVWVParallelTopicModel / FastQMVWVTopicInferencer
+(csrc/host/, hooks declared in include/mvtm_host.h).  The mirror is its own library, lib/libmvtm_host.so: it stands in
+for the Java host classes that cannot be compiled in this image and calls the product (libmvhdp.so) through the C ABI."""
 import atexit
 import ctypes as C
+import os
 import sys
 import weakref
 
@@ -17,7 +19,13 @@ HOST_SYMBOLS = [
     "mvtm_model_print_state", "mvtm_model_display_top_words", "mvtm_number_format5", "mvtm_model_print_document_topics", "mvtm_java_double_to_string", "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
     "mvtm_model_seed_host_samplers", "mvtm_model_optimize_dp", "mvtm_model_optimize_gamma",
     "mvtm_cokus_stream", "mvtm_rand_antoniak_seq", "mvtm_random_samplers_stream", "mvtm_mallet_next_gamma_stream",
+    "mvtm_model_set_live_updates", "mvtm_model_get_inferencer", "mvtm_inferencer_delete", "mvtm_inferencer_configure",
+    "mvtm_inferencer_infer", "mvtm_inferencer_num_entities", "mvtm_inferencer_view_tokens", "mvtm_inferencer_get_view",
+    "mvtm_inferencer_doc_topics", "mvtm_inferencer_print_document_topics", "mvtm_inferencer_get_stats",
 ]
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvtm_host.so")
+_host = None
 
 _ready = False
 _live = weakref.WeakSet()          # open models, closed at exit while the HIP runtime is still alive
@@ -33,8 +41,13 @@ def _close_all():
 
 
 def _lib():
-    global _ready
-    L = load_library()
+    global _ready, _host
+    if _host is None:
+        load_library()                       # the product library first: fails loudly when it has not been built
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} is missing: build it with `make -C mvtopicmodel_amd/csrc`")
+        _host = C.CDLL(HOST_LIB_PATH)
+    L = _host
     if not _ready:
         vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
         L.mvtm_last_error.restype = C.c_char_p
@@ -66,6 +79,17 @@ def _lib():
         L.mvtm_rand_antoniak_seq.argtypes = [i32, vp, vp, vp]
         L.mvtm_random_samplers_stream.argtypes = [i64, i32, dbl, dbl, i32, vp]
         L.mvtm_mallet_next_gamma_stream.argtypes = [i64, dbl, dbl, i32, vp]
+        L.mvtm_model_set_live_updates.argtypes = [vp, i32, i32]
+        L.mvtm_model_get_inferencer.argtypes = [vp, vp, vp]; L.mvtm_model_get_inferencer.restype = vp
+        L.mvtm_inferencer_delete.argtypes = [vp]; L.mvtm_inferencer_delete.restype = None
+        L.mvtm_inferencer_configure.argtypes = [vp, i32, i32, i32]
+        L.mvtm_inferencer_infer.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64]; L.mvtm_inferencer_infer.restype = i64
+        L.mvtm_inferencer_num_entities.argtypes = [vp]; L.mvtm_inferencer_num_entities.restype = i64
+        L.mvtm_inferencer_view_tokens.argtypes = [vp, i32]; L.mvtm_inferencer_view_tokens.restype = i64
+        L.mvtm_inferencer_get_view.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.mvtm_inferencer_doc_topics.argtypes = [vp, vp]
+        L.mvtm_inferencer_print_document_topics.argtypes = [vp, dbl, i32, vp, i64]; L.mvtm_inferencer_print_document_topics.restype = i64
+        L.mvtm_inferencer_get_stats.argtypes = [vp, i32, C.POINTER(SweepStatsC)]
         _ready = True
     return L
 
@@ -166,6 +190,19 @@ class FastQMVWVParallelTopicModel:
     def setRandomSeed(self, s): self._cfg["randomSeed"] = int(s)
     def setNumThreads(self, n): pass
     def setDevice(self, d): self._cfg["device"] = int(d)
+
+    def setLiveUpdates(self, live, tree_rebuilds_per_sweep=0):
+        """False: deferred sweeps (the parity contract); True: MVHDP_SWEEP_LIVE, the reference's update discipline."""
+        self.L.mvtm_model_set_live_updates(self.p, int(bool(live)), int(tree_rebuilds_per_sweep))
+
+    def getInferencer(self, discr_weight=None, p_mean=None):
+        """PTM:3457-3463."""
+        dw = None if discr_weight is None else np.ascontiguousarray(discr_weight, dtype=np.float64)
+        pm = None if p_mean is None else np.ascontiguousarray(p_mean, dtype=np.float64)
+        q = self.L.mvtm_model_get_inferencer(self.p, None if dw is None else dw.ctypes.data, None if pm is None else pm.ctypes.data)
+        if not q:
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return FastQMVWVTopicInferencer(self.L, q, self.K, self.M)
 
     def addInstances(self, training):
         """training: per view (name_ids int64[n], off int64[n+1], tokens int32[N], alphabetSize)."""
@@ -271,5 +308,84 @@ class FastQMVWVParallelTopicModel:
             if self.L.mvtm_model_get_log(self.p, i, C.byref(ms), C.byref(st)):
                 break
             out.append((ms.value, {f: getattr(st, f) for f, _ in SweepStatsC._fields_}))
+            i += 1
+        return out
+
+
+class FastQMVWVTopicInferencer:
+    """org.madgik.MVTopicModel.FastQMVWVTopicInferencer (INF:114-330) through the host mirror; made by
+    FastQMVWVParallelTopicModel.getInferencer()."""
+
+    def __init__(self, L, q, K, M):
+        self.L, self.q, self.K, self.M = L, q, K, M
+        self._cfg = dict(numIterations=10, randomSeed=-1, device=0)       # INF:73
+        _live.add(self)
+
+    def close(self):
+        if getattr(self, "q", None):
+            self.L.mvtm_inferencer_delete(self.q)
+            self.q = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setRandomSeed(self, s): self._cfg["randomSeed"] = int(s)
+    def setNumIterations(self, n): self._cfg["numIterations"] = int(n)
+    def setDevice(self, d): self._cfg["device"] = int(d)
+
+    def inferTopicDistributionsOnNewDocs(self, training):
+        """training: per view (name_ids int64[n], off int64[n+1], tokens int32[N]).  Returns the printDocumentTopics text."""
+        M = self.M
+        assert len(training) == M
+        c = self._cfg
+        self.L.mvtm_inferencer_configure(self.q, c["numIterations"], c["randomSeed"], c["device"])
+        names = [np.ascontiguousarray(t[0], dtype=np.int64) for t in training]
+        offs = [np.ascontiguousarray(t[1], dtype=np.int64) for t in training]
+        toks = [np.ascontiguousarray(t[2], dtype=np.int32) for t in training]
+        n_inst = np.array([len(n) for n in names], dtype=np.int64)
+        arr = lambda xs: C.cast((C.c_void_p * M)(*[x.ctypes.data for x in xs]), C.c_void_p)
+        n = self.L.mvtm_inferencer_infer(self.q, M, n_inst.ctypes.data_as(C.c_void_p), arr(names), arr(offs), arr(toks), None, 0)
+        if n < 0:
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return self.printDocumentTopics(0.03, -1)
+
+    def printDocumentTopics(self, threshold, max_topics):
+        n = self.L.mvtm_inferencer_print_document_topics(self.q, float(threshold), int(max_topics), None, 0)
+        if n < 0:
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        buf = C.create_string_buffer(n + 1)
+        self.L.mvtm_inferencer_print_document_topics(self.q, float(threshold), int(max_topics), buf, n + 1)
+        return buf.raw[:n].decode()
+
+    def num_entities(self):
+        return int(self.L.mvtm_inferencer_num_entities(self.q))
+
+    def get_view(self, m):
+        D = self.num_entities()
+        N = int(self.L.mvtm_inferencer_view_tokens(self.q, m))
+        ids = np.empty(D, dtype=np.int64); off = np.empty(D + 1, dtype=np.int64)
+        tok = np.empty(max(N, 1), dtype=np.int32); top = np.empty(max(N, 1), dtype=np.int32)
+        self.L.mvtm_inferencer_get_view(self.q, m, ids.ctypes.data, off.ctypes.data, tok.ctypes.data, top.ctypes.data)
+        return ids, off, tok[:N], top[:N]
+
+    def doc_topics(self):
+        out = np.zeros((self.num_entities(), self.K), dtype=np.float64)
+        if self.L.mvtm_inferencer_doc_topics(self.q, out.ctypes.data):
+            raise RuntimeError(self.L.mvtm_last_error().decode())
+        return out
+
+    def iteration_stats(self):
+        out = []
+        i = 0
+        while True:
+            st = SweepStatsC()
+            if self.L.mvtm_inferencer_get_stats(self.q, i, C.byref(st)):
+                break
+            out.append({f: getattr(st, f) for f, _ in SweepStatsC._fields_})
             i += 1
         return out

@@ -14,14 +14,20 @@ def doc_topic_proportions(K, doc_off, z, alpha, alpha_sum, gamma, w):
     norm = np.float64(0.0)
     for m in range(M):
         norm = norm + np.float64(w[m])
+    # topicCounts[m] / docLen[m] live outside the entity loop and are refreshed only when the entity has view m
+    # (FastQMVWVParallelTopicModel.java:2873-2886): a missing view is scored with the previous holder's values
+    cnt = [np.zeros(K, dtype=np.float64) for _ in range(M)]
+    doc_len = [0] * M
     for d in range(D):
         tp = np.zeros(K, dtype=np.float64)
         for m in range(M):
             b, e = int(doc_off[m][d]), int(doc_off[m][d + 1])
-            zz = z[m][b:e]
-            cnt = np.bincount(zz[zz >= 0], minlength=K).astype(np.float64)
-            num = cnt + np.float64(gamma[m]) * np.asarray(alpha[m][:K], dtype=np.float64)
-            den = np.float64(e - b) + np.float64(gamma[m]) * np.float64(alpha_sum[m])
+            if e > b:                                   # Assignments[m] != null (an empty span stands for null)
+                zz = z[m][b:e]
+                cnt[m] = np.bincount(zz[zz >= 0], minlength=K).astype(np.float64)
+                doc_len[m] = e - b
+            num = cnt[m] + np.float64(gamma[m]) * np.asarray(alpha[m][:K], dtype=np.float64)
+            den = np.float64(doc_len[m]) + np.float64(gamma[m]) * np.float64(alpha_sum[m])
             tp = tp + (np.float64(w[m]) * num) / den
         out[d] = tp / norm
     return out

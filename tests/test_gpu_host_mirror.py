@@ -295,3 +295,103 @@ def test_number_format_and_display_top_words():
     lines = model.displayTopWords(3, usingNewLines=True).splitlines()
     assert lines[0] == "0\t0.1"
     model.close()
+
+
+def test_inferencer_entry_matches_the_oracle_sequence():
+    """SURVEY 8f #3 as one call: getInferencer() (PTM:3457) then inferTopicDistributionsOnNewDocs (INF:114-330) = align
+    the views by entity name, trees with leaves p_wt (INF:557-586), initial topics drawn from the trees (INF:169-199,
+    out-of-vocabulary tokens stay 0), 10 sweeps with nst = 1 / nut = 0 under p_a = 0.2 (INF:216-219), then the topic
+    proportions and text of printDocumentTopics(out, 0.03, -1) (INF:326-329, incl. the carried-over counts of a missing
+    view, INF:371-386) -- against the same sequence on the oracle."""
+    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, java_double_to_string
+    from mvtopicmodel_amd import synth
+    from mvtopicmodel_amd.native import Hyper
+    from oracle import doc_topics as dto
+    from oracle.binding import Oracle, SWEEP_FROZEN as ORC_FROZEN
+    K, V = 16, [220, 40]
+    c = synth.generate(K, V, 80, [30, 5], seed=311, chunk_docs=4096)
+    training = [(np.arange(c.D, dtype=np.int64) + 1000, c.doc_off[m], c.tokens[m], V[m]) for m in range(2)]
+    model = FastQMVWVParallelTopicModel(K, 2, 0.1, 0.01)
+    model.setNumIterations(6); model.setBurninPeriod(200); model.setOptimizeInterval(50); model.setRandomSeed(5)
+    model.addInstances(training)
+    model.estimate()
+    counts = [model.get_counts(m) for m in range(2)]
+
+    # new documents: view 0 for entities 100..139; view 1 for every third of them plus five names view 0 never saw
+    # (appended as entities without view 0, INF:151-157); some out-of-vocabulary types in view 0
+    new = synth.generate(K, V, 45, [25, 4], seed=312, chunk_docs=4096)
+    tok0 = new.tokens[0][: new.doc_off[0][40]].copy(); tok0[::13] = V[0] + 5
+    off0 = new.doc_off[0][:41].copy()
+    names0 = np.arange(100, 140, dtype=np.int64)
+    pick = [d for d in range(45) if (d % 3 == 0 or d >= 40) and new.doc_off[1][d + 1] > new.doc_off[1][d]]
+    names1 = np.asarray([100 + d if d < 40 else 900 + d for d in pick], dtype=np.int64)
+    lens1 = [int(new.doc_off[1][d + 1] - new.doc_off[1][d]) for d in pick]
+    off1 = np.concatenate([[0], np.cumsum(lens1)]).astype(np.int64)
+    tok1 = np.concatenate([new.tokens[1][new.doc_off[1][d]:new.doc_off[1][d + 1]] for d in pick]).astype(np.int32)
+    pmean = np.array([[1.0, 0.35], [0.35, 1.0]]); discr = np.array([1.0, 0.8])
+    inf = model.getInferencer(discr_weight=discr, p_mean=pmean)
+    inf.setRandomSeed(77)
+    text = inf.inferTopicDistributionsOnNewDocs([(names0, off0, tok0), (names1, off1, tok1)])
+
+    # the same, by hand, on the oracle: entity order = view-0 instances, then the unmatched view-1 names
+    ids = list(names0) + [n for n in names1 if n >= 900]
+    D = len(ids)
+    pos = {n: i for i, n in enumerate(ids)}
+    L1 = np.zeros(D, dtype=np.int64); chunks = [None] * D
+    for j, n in enumerate(names1):
+        L1[pos[n]] = lens1[j]; chunks[pos[n]] = tok1[off1[j]:off1[j + 1]]
+    e_off = [np.concatenate([off0, np.full(D - 40, off0[-1])]).astype(np.int64), np.concatenate([[0], np.cumsum(L1)]).astype(np.int64)]
+    e_tok = [tok0, np.concatenate([ch for ch in chunks if ch is not None]).astype(np.int32)]
+    assert inf.num_entities() == D
+    for m in range(2):
+        gi, go, gt, _ = inf.get_view(m)
+        assert gi.tolist() == [int(x) for x in ids] and np.array_equal(go, e_off[m]) and np.array_equal(gt, e_tok[m])
+    hyi = Hyper.defaults(K, V, p_a=0.2)
+    o = Oracle(K, V)
+    for m in range(2):
+        o.set_corpus(m, e_off[m], e_tok[m]); o.set_counts(m, *counts[m])
+    o.set_hyper(hyi.alpha, hyi.alpha_sum, hyi.beta, hyi.beta_sum, hyi.gamma, hyi.p_a, hyi.p_b, None)
+    o.build_inference_trees()
+    o.init_assignments_from_trees(77)
+    for it in range(1, 11):
+        ro = o.sweep(it, 77, flags=ORC_FROZEN)
+    stats = inf.iteration_stats()
+    assert len(stats) == 10 and stats[-1]["oov_skipped"] == ro["stats"]["oov_skipped"] > 0 and stats[-1]["changed"] == 0
+    z = []
+    for m in range(2):
+        zm = inf.get_view(m)[3]
+        assert np.array_equal(zm, o.get_assignments(m)), f"inferred topics differ in view {m}"
+        z.append(zm)
+    assert (z[0][::13] == 0).all()                                   # OOV tokens keep Java's default 0 and are never sampled
+    for m in range(2):                                                # the trained model is untouched
+        a, b = model.get_counts(m)
+        assert np.array_equal(a, counts[m][0]) and np.array_equal(b, counts[m][1])
+    w = [1.0 * pmean[0, 0], discr[1] * pmean[0, 1]]
+    want = dto.doc_topic_proportions(K, e_off, z, hyi.alpha, hyi.alpha_sum, hyi.gamma, w)
+    assert np.array_equal(inf.doc_topics(), want)
+    assert text == dto.print_document_topics(want, [str(int(n)) for n in ids], 0.03, -1, java_double_to_string)
+    # the carried-over view: entity 1 has no view 1, so it is scored with entity 0's view-1 counts (INF:371-386)
+    assert L1[0] > 0 and L1[1] == 0
+    solo = dto.doc_topic_proportions(K, [e_off[0][1:3] - e_off[0][1], np.zeros(2, dtype=np.int64)], [z[0][e_off[0][1]:e_off[0][2]], z[1][:0]],
+                                     hyi.alpha, hyi.alpha_sum, hyi.gamma, w)
+    assert not np.array_equal(solo[0], want[1])
+    inf.close(); model.close()
+
+
+def test_estimate_with_live_updates_keeps_the_counts_consistent():
+    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from mvtopicmodel_amd import synth
+    K, V = 20, [300, 40, 50]
+    c = synth.generate(K, V, 120, [30, 4, 6], seed=91, chunk_docs=4096)
+    training = [(np.arange(c.D, dtype=np.int64), c.doc_off[m], c.tokens[m], V[m]) for m in range(3)]
+    model = FastQMVWVParallelTopicModel(K, 3, 0.1, 0.01)
+    model.setNumIterations(12); model.setRandomSeed(3); model.setLiveUpdates(True, 3)
+    model.addInstances(training)
+    model.estimate()
+    for m in range(3):
+        _, off, tok, z = model.get_view(m)
+        nwk, nk = model.get_counts(m)
+        ref = np.zeros_like(nwk); np.add.at(ref, (tok, z), 1)
+        assert np.array_equal(ref, nwk) and np.array_equal(ref.sum(axis=0), nk)
+    assert model.perplexities(0)[1] < 0
+    model.close()
