@@ -499,9 +499,10 @@ extern "C" int mvhdp_get_doc_topic_hist(mvhdp_handle h, int32_t m, int32_t* hist
     int rc = require_corpus(h); if (rc) return rc;
     HIPC(h, hipSetDevice(h->device));
     int32_t *d_hist = nullptr, *d_len = nullptr;
-    if (hist) HIPC(h, hipMalloc(&d_hist, (size_t)mm.K * hist_len * sizeof(int32_t)));
-    if (doc_len_counts) HIPC(h, hipMalloc(&d_len, (size_t)len_len * sizeof(int32_t)));
-    hipError_t e = mvhdp_launch_doc_topic_hist(mm, m, d_hist, hist_len, d_len, len_len, h->stream);
+    hipError_t e = hipSuccess;
+    if (hist) e = hipMalloc(&d_hist, (size_t)mm.K * hist_len * sizeof(int32_t));
+    if (e == hipSuccess && doc_len_counts) e = hipMalloc(&d_len, (size_t)len_len * sizeof(int32_t));
+    if (e == hipSuccess) e = mvhdp_launch_doc_topic_hist(mm, m, d_hist, hist_len, d_len, len_len, h->stream);
     if (e == hipSuccess && hist) e = hipMemcpy(hist, d_hist, (size_t)mm.K * hist_len * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess && doc_len_counts) e = hipMemcpy(doc_len_counts, d_len, (size_t)len_len * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (d_hist) hipFree(d_hist);
@@ -533,11 +534,14 @@ static int64_t compute_max_doc_tokens(mvhdp_ctx* h)
         for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
         std::vector<int32_t> order((size_t)mm.D);
         for (int64_t d = 0; d < mm.D; d++) order[(size_t)start[(size_t)(mx - tot[d])]++] = (int32_t)d;
-        if (hipMalloc(&h->d_doc_order, (size_t)mm.D * sizeof(int32_t)) == hipSuccess) {
-            hipMemcpy(h->d_doc_order, order.data(), (size_t)mm.D * sizeof(int32_t), hipMemcpyHostToDevice);
+        // without the order on the device the sweep runs in natural entity order (correct, only less balanced)
+        if (hipMalloc(&h->d_doc_order, (size_t)mm.D * sizeof(int32_t)) != hipSuccess) h->d_doc_order = nullptr;
+        else if (hipMemcpy(h->d_doc_order, order.data(), (size_t)mm.D * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(h->d_doc_order); h->d_doc_order = nullptr;
+        } else {
             h->tokens_desc.resize((size_t)mm.D);
             for (int64_t q = 0; q < mm.D; q++) h->tokens_desc[(size_t)q] = tot[(size_t)order[(size_t)q]];
-        } else h->d_doc_order = nullptr;
+        }
     }
     (void)mn;
     h->max_doc_tokens = mx;
@@ -1127,12 +1131,11 @@ extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
     const int NP = 1024;
     double *d_doc = nullptr, *d_part = nullptr;
     unsigned long long* d_nz = nullptr;
-    HIPC(h, hipMalloc(&d_doc, (size_t)std::max<int64_t>(mm.D, 1) * sizeof(double)));
-    HIPC(h, hipMalloc(&d_part, NP * sizeof(double)));
-    HIPC(h, hipMalloc(&d_nz, sizeof(unsigned long long)));
+    hipError_t e = hipMalloc(&d_doc, (size_t)std::max<int64_t>(mm.D, 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_part, NP * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_nz, sizeof(unsigned long long));
     std::vector<double> hdoc((size_t)std::max<int64_t>(mm.D, 1)), hpart(NP);
     std::vector<int32_t> nk((size_t)K);
-    hipError_t e = hipSuccess;
     for (int m = 0; m < M && e == hipSuccess; m++) {
         unsigned long long nz = 0;
         e = mvhdp_launch_loglik(mm, m, d_doc, d_part, NP, d_nz, h->stream);
@@ -1161,7 +1164,9 @@ extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
         if (std::isinf(ll)) ll = 0;
         out[m] = ll;
     }
-    hipFree(d_doc); hipFree(d_part); hipFree(d_nz);
+    if (d_doc) hipFree(d_doc);
+    if (d_part) hipFree(d_part);
+    if (d_nz) hipFree(d_nz);
     HIPC(h, e);
     return MVHDP_OK;
 }

@@ -737,6 +737,7 @@ __global__ __launch_bounds__(256) void doc_topic_hist_kernel(MvModel mm, int m, 
         for (int k = lane; k < K; k += WAVE) {
             int c = my[k];
             if (c > 0 && c < hist_len && hist) atomicAdd(&hist[(int64_t)k * hist_len + c], 1);
+            if (c > 0 && hist) atomicAdd(&docs_with_view[1 + k], 1);          // entities holding the topic at all (for bucket 0)
         }
         if (lane == 0) {
             atomicAdd(docs_with_view, 1);
@@ -746,35 +747,40 @@ __global__ __launch_bounds__(256) void doc_topic_hist_kernel(MvModel mm, int m, 
     }
 }
 
+// bucket 0 = entities with the view that do not hold the topic (PTM:647-649); entities holding it more than hist_len-1
+// times are in no bucket (the caller asked for a shorter histogram) and must not be taken for non-holders
 __global__ void hist_bucket0_kernel(int32_t* hist, int32_t hist_len, int K, const int32_t* docs_with_view)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    long long s = 0;
-    for (int c = 1; c < hist_len; c++) s += hist[(int64_t)k * hist_len + c];
-    hist[(int64_t)k * hist_len] = (int32_t)(*docs_with_view - s);
+    hist[(int64_t)k * hist_len] = docs_with_view[0] - docs_with_view[1 + k];
 }
 
 hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
                                        int32_t* doc_len_counts, int32_t len_len, hipStream_t s)
 {
-    int32_t* dwv = nullptr;
-    hipError_t e = hipMalloc(&dwv, sizeof(int32_t));
+    int32_t* dwv = nullptr;                                  // [1 + K]: entities with the view, entities holding topic k
+    hipError_t e = hipMalloc(&dwv, (size_t)(1 + mm.K) * sizeof(int32_t));
     if (e != hipSuccess) return e;
-    hipMemsetAsync(dwv, 0, sizeof(int32_t), s);
-    if (hist) hipMemsetAsync(hist, 0, (size_t)mm.K * hist_len * sizeof(int32_t), s);
-    if (doc_len_counts) hipMemsetAsync(doc_len_counts, 0, (size_t)len_len * sizeof(int32_t), s);
-    int wpb = 4;
-    while (wpb > 1 && (size_t)wpb * mm.K * sizeof(int) > 60000) wpb >>= 1;
-    int64_t blocks = (mm.D + wpb - 1) / wpb;
-    int grid = (int)(blocks < 4096 ? (blocks < 1 ? 1 : blocks) : 4096);
-    hipLaunchKernelGGL(doc_topic_hist_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * mm.K * sizeof(int), s,
-                       mm, m, hist, hist_len, doc_len_counts, len_len, dwv);
-    if (hist) hipLaunchKernelGGL(hist_bucket0_kernel, dim3((mm.K + 63) / 64), dim3(64), 0, s, hist, hist_len, mm.K, dwv);
-    e = hipGetLastError();
-    hipStreamSynchronize(s);
+    e = hipMemsetAsync(dwv, 0, (size_t)(1 + mm.K) * sizeof(int32_t), s);
+    if (e == hipSuccess && hist) e = hipMemsetAsync(hist, 0, (size_t)mm.K * hist_len * sizeof(int32_t), s);
+    if (e == hipSuccess && doc_len_counts) e = hipMemsetAsync(doc_len_counts, 0, (size_t)len_len * sizeof(int32_t), s);
+    if (e == hipSuccess) {
+        int wpb = 4;
+        while (wpb > 1 && (size_t)wpb * mm.K * sizeof(int) > 60000) wpb >>= 1;
+        int64_t blocks = (mm.D + wpb - 1) / wpb;
+        int grid = (int)(blocks < 4096 ? (blocks < 1 ? 1 : blocks) : 4096);
+        hipLaunchKernelGGL(doc_topic_hist_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * mm.K * sizeof(int), s,
+                           mm, m, hist, hist_len, doc_len_counts, len_len, dwv);
+        e = hipGetLastError();
+        if (e == hipSuccess && hist) {
+            hipLaunchKernelGGL(hist_bucket0_kernel, dim3((mm.K + 63) / 64), dim3(64), 0, s, hist, hist_len, mm.K, dwv);
+            e = hipGetLastError();
+        }
+    }
+    const hipError_t es = hipStreamSynchronize(s);           // a kernel fault surfaces here, not on a later call
     hipFree(dwv);
-    return e;
+    return e != hipSuccess ? e : es;
 }
 
 

@@ -1,11 +1,18 @@
 // mvhdp_jni.cpp — JNI shim between org.madgik.MVTopicModel.NativeSampler and the C ABI
-// of libmvhdp.so (include/mvhdp.h).  NOT compiled in the build image (no jni.h there):
-//   g++ -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
-//       mvtopicmodel_amd/java/mvhdp_jni.cpp -Lmvtopicmodel_amd/lib -lmvhdp -o libmvhdp_jni.so
-// Arrays cross with Get/ReleasePrimitiveArrayCritical around the library's own copies;
-// a negative status becomes a RuntimeException carrying mvhdp_last_error().
+// of libmvhdp.so (include/mvhdp.h).  NOT compiled in the build image (no JDK there):
+//   g++ -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude
+//       mvtopicmodel_amd/java/mvhdp_jni.cpp -Lmvtopicmodel_amd/lib -lmvhdp -o libmvhdp_jni.so      (one command line)
+// (tests/test_jni_shim.py type-checks it against a declaration-only jni.h stub.)
+//
+// Arrays cross with Get<Type>ArrayElements / Release<Type>ArrayElements, never with GetPrimitiveArrayCritical: every
+// mvhdp_* call may block (hipMalloc, synchronous copies, a whole sweep), and JNI forbids blocking -- or any other JNI
+// call -- inside a critical region (it stalls the collector for every Java thread and can deadlock it).  The elements
+// calls may copy; the library copies once more into HBM, and the Java arrays are free to move meanwhile.  Every array
+// length is checked against the shape the handle was created with before the library sees a pointer.
+// A negative status becomes a RuntimeException carrying mvhdp_last_error().
 #include <jni.h>
 
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -13,20 +20,59 @@
 
 namespace {
 
-void throw_rt(JNIEnv* env, mvhdp_handle h, int rc, const char* what)
-{
-    char msg[512];
-    snprintf(msg, sizeof msg, "%s failed (%d): %s", what, rc, mvhdp_last_error(h));
-    env->ThrowNew(env->FindClass("java/lang/RuntimeException"), msg);
-}
-
-struct Crit {   // RAII for GetPrimitiveArrayCritical
-    JNIEnv* env; jarray arr; void* p; jint mode;
-    Crit(JNIEnv* e, jarray a, jint m = 0) : env(e), arr(a), p(a ? e->GetPrimitiveArrayCritical(a, nullptr) : nullptr), mode(m) {}
-    ~Crit() { if (arr) env->ReleasePrimitiveArrayCritical(arr, p, mode); }
+struct Shard {                       // what the jlong handle points to: the library handle plus the shape for the checks
+    mvhdp_handle h = nullptr;
+    int K = 0, M = 0;
+    int V[MVHDP_MAX_MODALITIES] = {};
+    jlong D = -1;
+    jlong N[MVHDP_MAX_MODALITIES] = {};
 };
 
-inline mvhdp_handle H(jlong h) { return reinterpret_cast<mvhdp_handle>(h); }
+inline Shard* S(jlong p) { return reinterpret_cast<Shard*>(p); }
+
+void throw_msg(JNIEnv* env, const char* cls, const char* msg)
+{
+    jclass c = env->FindClass(cls);
+    if (c) env->ThrowNew(c, msg);
+}
+
+void throw_rt(JNIEnv* env, mvhdp_handle h, int rc, const char* what)
+{
+    char msg[640];
+    snprintf(msg, sizeof msg, "%s failed (%d): %s", what, rc, mvhdp_last_error(h));
+    throw_msg(env, "java/lang/RuntimeException", msg);
+}
+
+bool bad_len(JNIEnv* env, jarray a, jlong want, const char* what)
+{
+    if (a && env->GetArrayLength(a) == want) return false;
+    char msg[256];
+    snprintf(msg, sizeof msg, "%s: array of length %lld expected, got %lld", what, (long long)want, a ? (long long)env->GetArrayLength(a) : -1LL);
+    throw_msg(env, "java/lang/IllegalArgumentException", msg);
+    return true;
+}
+
+// RAII over Get/Release<Type>ArrayElements (mode 0: copy back and free; JNI_ABORT: input only)
+struct Ints {
+    JNIEnv* env; jintArray a; jint* p; jint mode;
+    Ints(JNIEnv* e, jintArray arr, jint m) : env(e), a(arr), p(arr ? e->GetIntArrayElements(arr, nullptr) : nullptr), mode(m) {}
+    ~Ints() { if (a && p) env->ReleaseIntArrayElements(a, p, mode); }
+    bool failed() const { return a && !p; }
+};
+struct Longs {
+    JNIEnv* env; jlongArray a; jlong* p; jint mode;
+    Longs(JNIEnv* e, jlongArray arr, jint m) : env(e), a(arr), p(arr ? e->GetLongArrayElements(arr, nullptr) : nullptr), mode(m) {}
+    ~Longs() { if (a && p) env->ReleaseLongArrayElements(a, p, mode); }
+    bool failed() const { return a && !p; }
+};
+struct Doubles {
+    JNIEnv* env; jdoubleArray a; jdouble* p; jint mode;
+    Doubles(JNIEnv* e, jdoubleArray arr, jint m) : env(e), a(arr), p(arr ? e->GetDoubleArrayElements(arr, nullptr) : nullptr), mode(m) {}
+    ~Doubles() { if (a && p) env->ReleaseDoubleArrayElements(a, p, mode); }
+    bool failed() const { return a && !p; }
+};
+
+static_assert(sizeof(jint) == sizeof(int32_t) && sizeof(jlong) == sizeof(int64_t) && sizeof(jdouble) == sizeof(double), "JNI primitive sizes");
 
 }  // namespace
 
@@ -34,60 +80,96 @@ extern "C" {
 
 JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nCreate(JNIEnv* env, jclass, jint K, jintArray numTypes, jint device, jlong docIdBase)
 {
+    const jsize M = numTypes ? env->GetArrayLength(numTypes) : 0;
+    if (M < 1 || M > MVHDP_MAX_MODALITIES) { throw_msg(env, "java/lang/IllegalArgumentException", "numTypes: 1..8 modalities"); return 0; }
     mvhdp_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.num_topics = K;
-    cfg.num_modalities = env->GetArrayLength(numTypes);
-    env->GetIntArrayRegion(numTypes, 0, cfg.num_modalities, cfg.num_types);
+    cfg.num_modalities = M;
+    env->GetIntArrayRegion(numTypes, 0, M, cfg.num_types);
     cfg.device = device;
     cfg.doc_id_base = docIdBase;
-    mvhdp_handle h = nullptr;
-    int rc = mvhdp_create(&cfg, &h);
-    if (rc != MVHDP_OK) { throw_rt(env, nullptr, rc, "mvhdp_create"); return 0; }
-    return reinterpret_cast<jlong>(h);
+    Shard* s = new Shard();
+    int rc = mvhdp_create(&cfg, &s->h);
+    if (rc != MVHDP_OK) { delete s; throw_rt(env, nullptr, rc, "mvhdp_create"); return 0; }
+    s->K = K; s->M = M;
+    for (int m = 0; m < M; m++) s->V[m] = cfg.num_types[m];
+    return reinterpret_cast<jlong>(s);
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nDestroy(JNIEnv*, jclass, jlong h) { mvhdp_destroy(H(h)); }
-
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetCorpus(JNIEnv* env, jclass, jlong h, jint m, jlongArray docOff, jintArray tokens)
+// Safe at any time, including from a finalizer or shutdown hook after the HIP runtime is gone (mvhdp_destroy then
+// releases host memory only) and when called twice (the second call is refused by the library, nothing is dereferenced).
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nDestroy(JNIEnv*, jclass, jlong p)
 {
-    jsize D = env->GetArrayLength(docOff) - 1;
-    int rc;
-    { Crit o(env, docOff, JNI_ABORT), t(env, tokens, JNI_ABORT);
-      rc = mvhdp_set_corpus(H(h), m, D, static_cast<const int64_t*>(o.p), static_cast<const int32_t*>(t.p)); }
-    if (rc) throw_rt(env, H(h), rc, "mvhdp_set_corpus");
+    Shard* s = S(p);
+    if (!s) return;
+    mvhdp_destroy(s->h);
+    delete s;
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetAssignments(JNIEnv* env, jclass, jlong h, jint m, jintArray z)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetCorpus(JNIEnv* env, jclass, jlong p, jint m, jlongArray docOff, jintArray tokens)
 {
+    Shard* s = S(p);
+    if (m < 0 || m >= s->M || !docOff || env->GetArrayLength(docOff) < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "setCorpus: bad view or docOff"); return; }
+    const jsize D = env->GetArrayLength(docOff) - 1;
     int rc;
-    { Crit a(env, z, JNI_ABORT); rc = mvhdp_set_assignments(H(h), m, static_cast<const int32_t*>(a.p)); }
-    if (rc) throw_rt(env, H(h), rc, "mvhdp_set_assignments");
+    jlong N = 0;
+    {
+        Longs o(env, docOff, JNI_ABORT);
+        if (o.failed()) return;                                   // OutOfMemoryError pending
+        N = o.p[D];
+        if (N < 0 || (N > 0 && bad_len(env, tokens, N, "setCorpus tokens"))) return;
+        Ints t(env, N > 0 ? tokens : nullptr, JNI_ABORT);
+        if (t.failed()) return;
+        rc = mvhdp_set_corpus(s->h, m, D, reinterpret_cast<const int64_t*>(o.p), reinterpret_cast<const int32_t*>(t.p));
+    }
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_set_corpus"); return; }
+    s->D = D; s->N[m] = N;
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAssignments(JNIEnv* env, jclass, jlong h, jint m, jintArray z)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetAssignments(JNIEnv* env, jclass, jlong p, jint m, jintArray z)
 {
+    Shard* s = S(p);
+    if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "setAssignments: bad view"); return; }
+    if (s->N[m] > 0 && bad_len(env, z, s->N[m], "setAssignments")) return;
     int rc;
-    { Crit a(env, z); rc = mvhdp_get_assignments(H(h), m, static_cast<int32_t*>(a.p)); }
-    if (rc) throw_rt(env, H(h), rc, "mvhdp_get_assignments");
+    { Ints a(env, s->N[m] > 0 ? z : nullptr, JNI_ABORT); if (a.failed()) return;
+      rc = mvhdp_set_assignments(s->h, m, reinterpret_cast<const int32_t*>(a.p)); }
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_set_assignments");
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetHyper(JNIEnv* env, jclass, jlong h, jobjectArray alpha, jdoubleArray alphaSum,
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAssignments(JNIEnv* env, jclass, jlong p, jint m, jintArray z)
+{
+    Shard* s = S(p);
+    if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "getAssignments: bad view"); return; }
+    if (s->N[m] == 0) return;
+    if (bad_len(env, z, s->N[m], "getAssignments")) return;
+    int rc;
+    { Ints a(env, z, 0); if (a.failed()) return; rc = mvhdp_get_assignments(s->h, m, reinterpret_cast<int32_t*>(a.p)); }
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_get_assignments");
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetHyper(JNIEnv* env, jclass, jlong p, jobjectArray alpha, jdoubleArray alphaSum,
         jdoubleArray beta, jdoubleArray betaSum, jdoubleArray gamma, jobjectArray p_a, jobjectArray p_b, jbooleanArray inactive)
 {
-    const jsize M = env->GetArrayLength(alpha);
-    jdoubleArray row0 = static_cast<jdoubleArray>(env->GetObjectArrayElement(alpha, 0));
-    const jsize K1 = env->GetArrayLength(row0);           // K+1
+    Shard* s = S(p);
+    const jsize M = s->M, K1 = s->K + 1;
+    if (bad_len(env, alpha, M, "setHyper alpha") || bad_len(env, p_a, M, "setHyper p_a") || bad_len(env, p_b, M, "setHyper p_b") ||
+        bad_len(env, alphaSum, M, "setHyper alphaSum") || bad_len(env, beta, M, "setHyper beta") ||
+        bad_len(env, betaSum, M, "setHyper betaSum") || bad_len(env, gamma, M, "setHyper gamma")) return;
+    if (inactive && bad_len(env, inactive, s->K, "setHyper inactive")) return;
     std::vector<double> a(static_cast<size_t>(M) * K1);
     mvhdp_hyper hy;
     std::memset(&hy, 0, sizeof hy);
     for (jsize m = 0; m < M; m++) {
         jdoubleArray r = static_cast<jdoubleArray>(env->GetObjectArrayElement(alpha, m));
-        env->GetDoubleArrayRegion(r, 0, K1, a.data() + static_cast<size_t>(m) * K1);
         jdoubleArray pa = static_cast<jdoubleArray>(env->GetObjectArrayElement(p_a, m));
         jdoubleArray pb = static_cast<jdoubleArray>(env->GetObjectArrayElement(p_b, m));
+        if (bad_len(env, r, K1, "setHyper alpha[m] (K+1 entries, PTM:196)") || bad_len(env, pa, M, "setHyper p_a[m]") || bad_len(env, pb, M, "setHyper p_b[m]")) return;
+        env->GetDoubleArrayRegion(r, 0, K1, a.data() + static_cast<size_t>(m) * K1);
         env->GetDoubleArrayRegion(pa, 0, M, hy.p_a[m]);
         env->GetDoubleArrayRegion(pb, 0, M, hy.p_b[m]);
+        env->DeleteLocalRef(r); env->DeleteLocalRef(pa); env->DeleteLocalRef(pb);
     }
     env->GetDoubleArrayRegion(alphaSum, 0, M, hy.alpha_sum);
     env->GetDoubleArrayRegion(beta, 0, M, hy.beta);
@@ -95,51 +177,69 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetHyper(JNIE
     env->GetDoubleArrayRegion(gamma, 0, M, hy.gamma);
     std::vector<uint8_t> ina;
     if (inactive) {
-        ina.resize(K1 - 1);
-        env->GetBooleanArrayRegion(inactive, 0, K1 - 1, reinterpret_cast<jboolean*>(ina.data()));
+        ina.resize(static_cast<size_t>(s->K));
+        env->GetBooleanArrayRegion(inactive, 0, s->K, reinterpret_cast<jboolean*>(ina.data()));
         hy.inactive = ina.data();
     }
     hy.alpha = a.data();
-    int rc = mvhdp_set_hyper(H(h), &hy);
-    if (rc) throw_rt(env, H(h), rc, "mvhdp_set_hyper");
+    int rc = mvhdp_set_hyper(s->h, &hy);
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_set_hyper");
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildCounts(JNIEnv* env, jclass, jlong h)
-{ int rc = mvhdp_build_counts(H(h)); if (rc) throw_rt(env, H(h), rc, "mvhdp_build_counts"); }
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildCounts(JNIEnv* env, jclass, jlong p)
+{ int rc = mvhdp_build_counts(S(p)->h); if (rc) throw_rt(env, S(p)->h, rc, "mvhdp_build_counts"); }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildTrees(JNIEnv* env, jclass, jlong h)
-{ int rc = mvhdp_build_trees(H(h)); if (rc) throw_rt(env, H(h), rc, "mvhdp_build_trees"); }
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildTrees(JNIEnv* env, jclass, jlong p)
+{ int rc = mvhdp_build_trees(S(p)->h); if (rc) throw_rt(env, S(p)->h, rc, "mvhdp_build_trees"); }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetCounts(JNIEnv* env, jclass, jlong h, jint m, jintArray nwk, jintArray nk)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetCounts(JNIEnv* env, jclass, jlong p, jint m, jintArray nwk, jintArray nk)
 {
+    Shard* s = S(p);
+    if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "getCounts: bad view"); return; }
+    if ((nwk && bad_len(env, nwk, (jlong)s->V[m] * s->K, "getCounts typeTopicCounts")) || (nk && bad_len(env, nk, s->K, "getCounts tokensPerTopic"))) return;
     int rc;
-    { Crit a(env, nwk), b(env, nk); rc = mvhdp_get_counts(H(h), m, static_cast<int32_t*>(a.p), static_cast<int32_t*>(b.p)); }
-    if (rc) throw_rt(env, H(h), rc, "mvhdp_get_counts");
+    { Ints a(env, nwk, 0), b(env, nk, 0); if (a.failed() || b.failed()) return;
+      rc = mvhdp_get_counts(s->h, m, reinterpret_cast<int32_t*>(a.p), reinterpret_cast<int32_t*>(b.p)); }
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_get_counts");
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetDocTopicHist(JNIEnv* env, jclass, jlong h, jint m, jintArray hist, jint histLen, jintArray lens)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetDocTopicHist(JNIEnv* env, jclass, jlong p, jint m, jintArray hist, jint histLen, jintArray lens)
 {
+    Shard* s = S(p);
+    if (m < 0 || m >= s->M || histLen < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "getDocTopicHist: bad view or length"); return; }
+    if (hist && bad_len(env, hist, (jlong)s->K * histLen, "getDocTopicHist hist")) return;
     int rc;
-    { Crit a(env, hist), b(env, lens);
-      rc = mvhdp_get_doc_topic_hist(H(h), m, static_cast<int32_t*>(a.p), histLen, static_cast<int32_t*>(b.p), lens ? env->GetArrayLength(lens) : 0); }
-    if (rc) throw_rt(env, H(h), rc, "mvhdp_get_doc_topic_hist");
+    { Ints a(env, hist, 0), b(env, lens, 0); if (a.failed() || b.failed()) return;
+      rc = mvhdp_get_doc_topic_hist(s->h, m, reinterpret_cast<int32_t*>(a.p), histLen, reinterpret_cast<int32_t*>(b.p), lens ? env->GetArrayLength(lens) : 0); }
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_get_doc_topic_hist");
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAlpha(JNIEnv* env, jclass, jlong h, jdoubleArray alphaFlat, jbooleanArray inactive)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAlpha(JNIEnv* env, jclass, jlong p, jdoubleArray alphaFlat, jbooleanArray inactive)
 {
-    int rc;
-    { Crit a(env, alphaFlat), b(env, inactive); rc = mvhdp_get_alpha(H(h), static_cast<double*>(a.p), static_cast<uint8_t*>(b.p)); }
-    if (rc) throw_rt(env, H(h), rc, "mvhdp_get_alpha");
+    Shard* s = S(p);
+    if (bad_len(env, alphaFlat, (jlong)s->M * (s->K + 1), "getAlpha alpha") || bad_len(env, inactive, s->K, "getAlpha inactive")) return;
+    std::vector<double> a(static_cast<size_t>(s->M) * (s->K + 1));
+    std::vector<uint8_t> ina(static_cast<size_t>(s->K));
+    int rc = mvhdp_get_alpha(s->h, a.data(), ina.data());
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_get_alpha"); return; }
+    env->SetDoubleArrayRegion(alphaFlat, 0, (jsize)a.size(), a.data());
+    env->SetBooleanArrayRegion(inactive, 0, s->K, reinterpret_cast<const jboolean*>(ina.data()));
 }
 
-JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv* env, jclass, jlong h, jint sweepIdx, jlong seed, jint flags, jdoubleArray pOverride, jobject out)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv* env, jclass, jlong p, jint sweepIdx, jlong seed, jint flags, jdoubleArray pOverride, jobject out)
 {
+    Shard* s = S(p);
+    if (pOverride && bad_len(env, pOverride, s->D * s->M * s->M, "sweep pOverride [D][M][M]")) return;
     mvhdp_sweep_stats st;
     int rc;
-    { Crit p(env, pOverride, JNI_ABORT);
-      rc = mvhdp_sweep(H(h), static_cast<uint32_t>(sweepIdx), static_cast<uint64_t>(seed), static_cast<uint32_t>(flags),
-                       static_cast<const double*>(p.p), nullptr, &st); }
-    if (rc) { throw_rt(env, H(h), rc, "mvhdp_sweep"); return; }
+    {
+        // the view weights are copied out first; the sweep itself runs with no Java array held
+        std::vector<double> pcopy;
+        if (pOverride) { pcopy.resize(static_cast<size_t>(env->GetArrayLength(pOverride))); env->GetDoubleArrayRegion(pOverride, 0, (jsize)pcopy.size(), pcopy.data()); }
+        rc = mvhdp_sweep(s->h, static_cast<uint32_t>(sweepIdx), static_cast<uint64_t>(seed), static_cast<uint32_t>(flags),
+                         pOverride ? pcopy.data() : nullptr, nullptr, &st);
+    }
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_sweep"); return; }
     jclass c = env->GetObjectClass(out);
     auto setL = [&](const char* f, jlong v) { env->SetLongField(out, env->GetFieldID(c, f, "J"), v); };
     auto setI = [&](const char* f, jint v) { env->SetIntField(out, env->GetFieldID(c, f, "I"), v); };
@@ -149,6 +249,19 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv*
     setL("oovSkipped", st.oov_skipped); setL("abortedDocs", st.aborted_docs); setL("exactFallbacks", st.exact_fallbacks);
     setI("activatedTopic", st.activated_topic); setI("activatedModality", st.activated_modality);
     setL("activationKey", st.activation_key); setD("sweepKernelMs", st.sweep_kernel_ms); setD("totalMs", st.total_ms);
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nApplyDelta(JNIEnv* env, jclass, jlong p, jint topic, jint modality)
+{ int rc = mvhdp_apply_delta(S(p)->h, topic, modality); if (rc) throw_rt(env, S(p)->h, rc, "mvhdp_apply_delta"); }
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nModelLogLikelihood(JNIEnv* env, jclass, jlong p, jdoubleArray out)
+{
+    Shard* s = S(p);
+    if (bad_len(env, out, s->M, "modelLogLikelihood")) return;
+    double ll[MVHDP_MAX_MODALITIES];
+    int rc = mvhdp_model_log_likelihood(s->h, ll);
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_model_log_likelihood"); return; }
+    env->SetDoubleArrayRegion(out, 0, s->M, ll);
 }
 
 }  // extern "C"

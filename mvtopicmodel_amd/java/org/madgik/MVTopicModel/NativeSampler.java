@@ -19,6 +19,9 @@ public final class NativeSampler implements AutoCloseable {
     public static final int SWEEP_REUSE_TREES = 0x1;
     public static final int SWEEP_NO_APPLY = 0x2;
     public static final int SWEEP_EXACT_CHAIN = 0x4;
+    public static final int SWEEP_FROZEN = 0x10;       // the inferencer's call (nst = 1, nut = 0)
+    public static final int SWEEP_LIVE = 0x20;         // the updater threads' own discipline: atomics on the shared counts
+    public static int sweepLiveSegments(int n) { return (n & 0xff) << 16; }
 
     /** What one sweep reports: the three branch counters of the worker plus bookkeeping. */
     public static final class SweepStats {
@@ -57,6 +60,11 @@ public final class NativeSampler implements AutoCloseable {
         return st;
     }
 
+    /** Multi-GPU: after the all-reduce of the delta buffer; (topic, modality) = winner of the MIN-reduced activation key. */
+    public void applyDelta(int activatedTopic, int activatedModality) { nApplyDelta(handle, activatedTopic, activatedModality); }
+    public double[] modelLogLikelihood(int numModalities) { double[] ll = new double[numModalities]; nModelLogLikelihood(handle, ll); return ll; }
+
+    /** Safe from a finalizer or a shutdown hook: after the HIP runtime has gone the library frees host memory only. */
     @Override
     public void close() {
         if (handle != 0) { nDestroy(handle); handle = 0; }
@@ -75,4 +83,6 @@ public final class NativeSampler implements AutoCloseable {
     private static native void nGetDocTopicHist(long h, int m, int[] histFlat, int histLen, int[] docLengthCounts);
     private static native void nGetAlpha(long h, double[] alphaFlat, boolean[] inactive);
     private static native void nSweep(long h, int sweepIdx, long seed, int flags, double[] pOverride, SweepStats out);
+    private static native void nApplyDelta(long h, int topic, int modality);
+    private static native void nModelLogLikelihood(long h, double[] out);
 }

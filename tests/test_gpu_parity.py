@@ -214,6 +214,12 @@ def test_doc_topic_hist_matches():
         ho, lo = o.get_doc_topic_hist(m, 128, 128)
         hs, ls = s.get_doc_topic_hist(m, 128, 128)
         assert np.array_equal(ho, hs) and np.array_equal(lo, ls)
+        # a histogram shorter than the largest per-entity count: an entity holding a topic more often than the last
+        # bucket is in no bucket -- in particular not in bucket 0 (non-holders, PTM:647-649)
+        ho, lo = o.get_doc_topic_hist(m, 3, 5)
+        hs, ls = s.get_doc_topic_hist(m, 3, 5)
+        assert np.array_equal(ho, hs) and np.array_equal(lo, ls)
+    assert o.get_doc_topic_hist(0, 128, 0)[0][:, 3:].sum() > 0      # the short histogram really cut something off
     s.close()
 
 
