@@ -197,6 +197,19 @@ int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flag
  * recorded by the sweep when (topic,modality) >= 0 (multi-GPU: the host passes
  * the winner of the min-reduction over activation_key). */
 int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_t activated_modality);
+/* The same update as a stream-ordered pipeline, for document shards on several GPUs: the all-reduce of the delta buffer
+ * can be issued in row-range chunks and each chunk's rows applied AND their F+trees rebuilt (buildFTrees PTM:2660-2696
+ * from the updated counts) while the next chunk is still on the wire.  n_wk rows are numbered over all views (view m
+ * starts at num_types[0] + .. + num_types[m-1]); the tokensPerTopic part sits behind the last row in both buffers.
+ *   mvhdp_apply_delta_begin    applies the tokensPerTopic part (all-reduce it first: every tree needs all of it)
+ *   mvhdp_apply_delta_rows     rows [row_begin, row_end): counts += delta, delta = 0, trees of those rows rebuilt; no wait
+ *   mvhdp_apply_delta_end      every row must have been applied exactly once; topic activation as mvhdp_apply_delta;
+ *                              one synchronisation; negative counts reported here
+ * Afterwards mvhdp_trees_current() is 1 (unless a topic was activated) and the next sweep may pass REUSE_TREES. */
+int mvhdp_apply_delta_begin(mvhdp_handle h);
+int mvhdp_apply_delta_rows(mvhdp_handle h, int64_t row_begin, int64_t row_end);
+int mvhdp_apply_delta_end(mvhdp_handle h, int32_t activated_topic, int32_t activated_modality);
+int mvhdp_trees_current(mvhdp_handle h);    /* 1: the F+trees match the counts and hyper-parameters, 0: not, < 0: error */
 /* the per-document view weights used by the last sweep */
 int mvhdp_get_view_weights(mvhdp_handle h, double* p /*[D][M][M]*/);
 

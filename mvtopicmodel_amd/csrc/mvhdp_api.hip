@@ -47,6 +47,8 @@ struct mvhdp_ctx {
     bool trees_inference = false;            // leaves of the last build: p_wt alone (INF:576)
     bool delta_clean = false;                // the delta buffer is known to be all zero
     bool delta_pending = false;              // a NO_APPLY sweep has left deltas that mvhdp_apply_delta has not consumed yet
+    bool last_need_full = true;              // the last sweep's kernels could reach the generic kernel (needs FTree.tree itself)
+    int64_t rows_applied = -1;               // mvhdp_apply_delta_rows progress of the current begin/end bracket (-1: no bracket open)
     bool device_released = false;            // release_device_resources has run (mvhdp_destroy, or the exit handler)
 
     unsigned long long* d_stats = nullptr;   // [ST_COUNT]
@@ -584,6 +586,59 @@ extern "C" int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_
     return MVHDP_OK;
 }
 
+// ---- the multi-GPU pipeline: apply + tree rebuild by row ranges, stream-ordered (see include/mvhdp.h) ----
+extern "C" int mvhdp_apply_delta_begin(mvhdp_handle h)
+{
+    CHECK_H(h);
+    if (!h->have_hyper || !h->have_counts) FAIL(h, MVHDP_ERR_STATE, "apply_delta_begin before set_hyper / counts");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipMemsetAsync(h->d_stats + ST_NEGATIVE, 0, sizeof(unsigned long long), h->stream));
+    HIPC(h, mvhdp_launch_apply_nk(h->mm, h->d_stats + ST_NEGATIVE, h->stream));
+    h->rows_applied = 0;
+    h->have_trees = false;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_apply_delta_rows(mvhdp_handle h, int64_t row_begin, int64_t row_end)
+{
+    CHECK_H(h);
+    const int64_t nrows = h->mm.rowbase[h->mm.M];
+    if (h->rows_applied < 0) FAIL(h, MVHDP_ERR_STATE, "apply_delta_rows outside an apply_delta_begin / apply_delta_end bracket");
+    if (row_begin < 0 || row_end > nrows || row_begin > row_end) FAIL(h, MVHDP_ERR_INVALID_ARG, "apply_delta_rows: bad row range");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, mvhdp_launch_build_trees_rows(h->mm, false, h->last_need_full, row_begin, row_end, true, h->d_stats + ST_NEGATIVE, h->stream));
+    h->rows_applied += row_end - row_begin;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_apply_delta_end(mvhdp_handle h, int32_t activated_topic, int32_t activated_modality)
+{
+    CHECK_H(h);
+    const int64_t nrows = h->mm.rowbase[h->mm.M];
+    if (h->rows_applied != nrows) { h->rows_applied = -1; FAIL(h, MVHDP_ERR_STATE, "apply_delta_end: the row ranges applied do not cover every row exactly once"); }
+    h->rows_applied = -1;
+    HIPC(h, hipSetDevice(h->device));
+    unsigned long long neg = 0;
+    HIPC(h, hipMemcpyAsync(&neg, h->d_stats + ST_NEGATIVE, sizeof neg, hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->delta_clean = true; h->delta_pending = false;
+    // the trees were rebuilt from the updated counts row by row: current, unless an activation now changes alpha
+    h->have_trees = true; h->full_trees = h->last_need_full; h->trees_inference = false;
+    if (activated_topic >= 0) {
+        h->have_trees = false;
+        int rc = apply_activation(h, activated_topic, activated_modality);
+        if (rc) return rc;
+    }
+    if (neg) FAIL(h, MVHDP_ERR_NEGATIVE_COUNT, "a topic count went below zero (UPD:202-215)");
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_trees_current(mvhdp_handle h)
+{
+    CHECK_H(h);
+    return h->have_trees ? 1 : 0;
+}
+
 extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
                            const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats)
 {
@@ -786,6 +841,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     } else if (fast) {
         need_full = need_full || n_chain == 0 || S_cap > 64 * chain[n_chain - 1];
     }
+    h->last_need_full = need_full;
     auto rebuild_trees = [&]() {
         step(mvhdp_launch_build_trees(mm, false, need_full, s));
         h->have_trees = true; h->full_trees = need_full; h->trees_inference = false;

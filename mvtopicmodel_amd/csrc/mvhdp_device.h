@@ -80,6 +80,10 @@ size_t mvhdp_sweep_wave_bytes(int M, int S_cap);
 hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens_per_view, hipStream_t s);
 // write_full = false: only the descent table (what the register-resident kernels read), not the FTree.tree arrays
 hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s);
+// the same for the rows [row_begin, row_end) only; apply_first: counts += delta, delta = 0 for those rows before the build
+hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
+                                         bool apply_first, unsigned long long* negatives, hipStream_t s);
+hipError_t mvhdp_launch_apply_nk(const MvModel& mm, unsigned long long* negatives, hipStream_t s);
 hipError_t mvhdp_launch_init_from_trees(const MvModel& mm, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s);

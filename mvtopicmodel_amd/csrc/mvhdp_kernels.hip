@@ -66,27 +66,38 @@ hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens,
 // by level (children always have larger indices, so descending depth is safe)
 // and written out whole, coalesced.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves, bool write_full)
+// apply_first: the multi-GPU pipeline's form (mvhdp_apply_delta_rows): the row's all-reduced deltas are added to the
+// counts (UPD:197-207) on the way in -- counts += delta, delta = 0 -- and the tree is built from the updated row; the
+// tokensPerTopic part has been applied before (mvhdp_apply_delta_begin), every tree needs all of it.
+__global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
+                                                         bool apply_first, unsigned long long* negatives)
 {
     extern __shared__ double t[];                  // 2K doubles
     const int K = mm.K, lane = threadIdx.x;
     const int64_t nrows = mm.rowbase[mm.M];
     const int32_t* nk_all = mm.counts + nrows * K;
-    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+    int neg = 0;
+    for (int64_t row = row_begin + blockIdx.x; row < row_end; row += gridDim.x) {
         int m = 0;
         while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
-        const int32_t* cnt = mm.counts + row * K;
+        int32_t* cnt = mm.counts + row * K;
+        int32_t* dl = mm.delta + row * K;
         const int32_t* nk = nk_all + (int64_t)m * K;
         const double* al = mm.alpha + (int64_t)m * (K + 1);
         const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
         for (int k = lane; k < K; k += WAVE) {
+            int c = cnt[k];
+            if (apply_first) {
+                const int d = dl[k];
+                if (d) { c += d; cnt[k] = c; dl[k] = 0; neg += c < 0; }    // UPD:202-215 logs a negative count; here it is reported
+            }
             double leaf;
             if (inference_leaves) {                                // INF:576: p_wt alone
-                leaf = ((double)cnt[k] + beta) / ((double)nk[k] + beta_sum);
+                leaf = ((double)c + beta) / ((double)nk[k] + beta_sum);
             } else if (mm.inactive[k]) {                           // PTM:2670-2671
                 leaf = 0.0;
             } else {
-                double p_wt = ((double)cnt[k] + beta) / ((double)nk[k] + beta_sum);   // PTM:2676
+                double p_wt = ((double)c + beta) / ((double)nk[k] + beta_sum);   // PTM:2676
                 leaf = gamma * al[k] * p_wt;                        // PTM:2678
             }
             t[K + k] = leaf;
@@ -125,14 +136,43 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         }
         __syncthreads();
     }
+    if (apply_first && negatives) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) neg += __shfl_xor(neg, sft, WAVE);
+        if (lane == 0 && neg) atomicAdd(negatives, (unsigned long long)neg);
+    }
 }
 
 hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s)
 {
-    int64_t nrows = mm.rowbase[mm.M];
+    return mvhdp_launch_build_trees_rows(mm, inference_leaves, write_full, 0, mm.rowbase[mm.M], false, nullptr, s);
+}
+
+hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
+                                         bool apply_first, unsigned long long* negatives, hipStream_t s)
+{
+    int64_t nrows = row_end - row_begin;
+    if (nrows <= 0) return hipSuccess;
     int grid = (int)(nrows < 65536 ? nrows : 65536);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full);
+    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
+                       row_begin, row_end, apply_first, negatives);
+    return hipGetLastError();
+}
+
+// tokensPerTopic part of apply_delta alone (M*K words): UPD:209-218
+__global__ __launch_bounds__(256) void apply_nk_kernel(int32_t* counts_nk, int32_t* delta_nk, int n, unsigned long long* negatives)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = delta_nk[i];
+    if (d) { const int c = counts_nk[i] + d; counts_nk[i] = c; delta_nk[i] = 0; if (c < 0 && negatives) atomicAdd(negatives, 1ull); }
+}
+
+hipError_t mvhdp_launch_apply_nk(const MvModel& mm, unsigned long long* negatives, hipStream_t s)
+{
+    const int n = mm.M * mm.K;
+    const int64_t off = mm.rowbase[mm.M] * mm.K;
+    hipLaunchKernelGGL(apply_nk_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mm.counts + off, mm.delta + off, n, negatives);
     return hipGetLastError();
 }
 

@@ -105,6 +105,20 @@ class GpuShard:
     def apply(self, topic, modality):
         self.s.apply_delta(topic, modality)
 
+    # ---- pipelined exchange: chunked all-reduce overlapped with apply + F+tree rebuild of the chunk's rows ----
+    def can_pipeline(self):
+        return self.stream is not None and not self.host_staged
+
+    def row_chunks(self, n_chunks):
+        """[(row_begin, row_end)] covering the n_wk rows of every view, and the element offset of the n_k part."""
+        rows = sum(self.s.V)
+        n_chunks = max(1, min(int(n_chunks), rows))
+        cuts = [rows * i // n_chunks for i in range(n_chunks + 1)]
+        return [(cuts[i], cuts[i + 1]) for i in range(n_chunks) if cuts[i + 1] > cuts[i]], rows * self.s.K
+
+    def trees_current(self):
+        return self.s.trees_current()
+
     def sync(self):
         if self.host_staged:                 # push all-reduced host copies back to the library's buffers
             if self._counts_host is not None:
@@ -144,7 +158,10 @@ def build_counts_all_reduce(shard, group=None):
         shard.counts_written()
 
 
-def sweep_all_reduce(shard, sweep_idx, seed, group=None, flags=0, timings=None):
+PIPELINE_CHUNKS = 4      # all-reduce chunks per sweep: the apply + tree rebuild of chunk i runs while chunk i+1 is on the wire
+
+
+def sweep_all_reduce(shard, sweep_idx, seed, group=None, flags=0, timings=None, pipeline=True, force_exchange=False):
     """One global Gibbs sweep: every shard samples its entities against the same snapshot of
     n_wk / n_k, the deltas are summed across shards, every replica applies the same sum
     (AD-LDA style).  Bit-identical to the single-shard sweep: entities are independent under
@@ -160,7 +177,9 @@ def sweep_all_reduce(shard, sweep_idx, seed, group=None, flags=0, timings=None):
     "allreduce" (host wall time until the collective is enqueued and, with a shared stream, device
     time by events), "apply" (host wall time of mvhdp_apply_delta, which waits for the collective)."""
     t0 = time.perf_counter()
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange)
+    if multi and pipeline and getattr(shard, "can_pipeline", lambda: False)():
+        return _sweep_pipelined(shard, sweep_idx, seed, group, flags, timings, t0)
     if not multi and hasattr(shard, "sweep_and_apply"):
         st = shard.sweep_and_apply(sweep_idx, seed, flags)
         if timings is not None:
@@ -201,5 +220,56 @@ def sweep_all_reduce(shard, sweep_idx, seed, group=None, flags=0, timings=None):
         timings["apply"] = timings.get("apply", 0.0) + (t3 - t2) * 1e3
         if ev is not None:
             timings["allreduce_device"] = timings.get("allreduce_device", 0.0) + ev[0].elapsed_time(ev[1])
+        timings["n"] = timings.get("n", 0) + 1
+    return st
+
+
+def _sweep_pipelined(shard, sweep_idx, seed, group, flags, timings, t0):
+    """The exchange step as a pipeline on the shard's stream (GPU shards only): the tokensPerTopic part and then
+    PIPELINE_CHUNKS row ranges of the delta buffer are all-reduced one after the other on RCCL's stream; as each chunk
+    arrives its rows are applied and their F+trees rebuilt (mvhdp_apply_delta_rows) while the next chunk is still on the
+    wire.  The next sweep then reuses the trees (MVHDP_SWEEP_REUSE_TREES) instead of rebuilding them.  Same integers as
+    the plain sequence: the trees are built from the same counts by the same kernel."""
+    from .native import SWEEP_REUSE_TREES
+    reuse = SWEEP_REUSE_TREES if shard.trees_current() else 0
+    st = shard.sweep_local(sweep_idx, seed, flags | reuse)
+    t1 = time.perf_counter()
+    need_key = shard.has_inactive()
+    chunks, nk_off = shard.row_chunks(PIPELINE_CHUNKS)
+    K = shard.s.K
+    ev = None
+    with shard.on_stream():
+        if timings is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        t = shard.delta
+        works = [dist.all_reduce(t[nk_off:], op=dist.ReduceOp.SUM, group=group, async_op=True)]
+        for r0, r1 in chunks:
+            works.append(dist.all_reduce(t[r0 * K:r1 * K], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        key = None
+        if need_key:
+            key = torch.tensor([st.activation_key], dtype=torch.int64, device=t.device)
+            works.append(dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group, async_op=True))
+        works[0].wait()                                   # the stream waits, the host does not
+        shard.s.apply_delta_begin()
+        for (r0, r1), w in zip(chunks, works[1:]):
+            w.wait()
+            shard.s.apply_delta_rows(r0, r1)
+        topic, modality = st.activated_topic, st.activated_modality
+        if need_key:
+            works[-1].wait()
+            topic, modality = decode_activation(int(key.item()))
+        if ev is not None:
+            ev[1].record()
+    t2 = time.perf_counter()
+    shard.s.apply_delta_end(topic, modality)
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings["sweep_call"] = timings.get("sweep_call", 0.0) + (t1 - t0) * 1e3
+        timings["sweep_kernel"] = timings.get("sweep_kernel", 0.0) + st.sweep_kernel_ms
+        timings["sweep_device_total"] = timings.get("sweep_device_total", 0.0) + st.total_ms
+        timings["exchange_enqueue_host"] = timings.get("exchange_enqueue_host", 0.0) + (t2 - t1) * 1e3
+        timings["exchange_wait_host"] = timings.get("exchange_wait_host", 0.0) + (t3 - t2) * 1e3
+        timings["exchange_device"] = timings.get("exchange_device", 0.0) + ev[0].elapsed_time(ev[1])
         timings["n"] = timings.get("n", 0) + 1
     return st

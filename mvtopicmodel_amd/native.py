@@ -282,6 +282,21 @@ class NativeSampler:
     def apply_delta(self, activated_topic=-1, activated_modality=-1):
         self._ck(self.L.mvhdp_apply_delta(self.h, int(activated_topic), int(activated_modality)))
 
+    def apply_delta_begin(self):
+        self._ck(self.L.mvhdp_apply_delta_begin(self.h))
+
+    def apply_delta_rows(self, row_begin, row_end):
+        self._ck(self.L.mvhdp_apply_delta_rows(self.h, int(row_begin), int(row_end)))
+
+    def apply_delta_end(self, activated_topic=-1, activated_modality=-1):
+        self._ck(self.L.mvhdp_apply_delta_end(self.h, int(activated_topic), int(activated_modality)))
+
+    def trees_current(self):
+        rc = self.L.mvhdp_trees_current(self.h)
+        if rc < 0:
+            self._ck(rc)
+        return bool(rc)
+
     def get_view_weights(self):
         p = np.empty((self.D, self.M, self.M), dtype=np.float64)
         self._ck(self.L.mvhdp_get_view_weights(self.h, _ptr(p)))

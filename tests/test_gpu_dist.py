@@ -39,8 +39,71 @@ def test_device_buffers_alias_and_single_rank_rccl_all_reduce():
             o.sweep(it, 5)
             sweep_all_reduce(shard, it, 5)
             assert_same_state(o, s, 2)
+        # the exchange step itself, forced although the group has one rank: plain sequence, then the chunked pipeline
+        # (all-reduce by row ranges, apply + tree rebuild per range, trees reused by the next sweep)
+        o.sweep(2, 5); sweep_all_reduce(shard, 2, 5, pipeline=False, force_exchange=True); assert_same_state(o, s, 2)
+        ph = {}
+        for it in range(3, 7):
+            o.sweep(it, 5)
+            sweep_all_reduce(shard, it, 5, force_exchange=True, timings=ph)
+            assert_same_state(o, s, 2)
+            assert s.trees_current()
+            for m, w in [(0, 3), (1, 79)]:
+                o.build_trees()
+                assert np.array_equal(o.get_tree(m, w), s.get_tree(m, w))
+        assert ph["n"] == 4 and "exchange_device" in ph
     finally:
         dist.destroy_process_group()
+    shard.close()
+    s.close()
+
+
+def test_pipelined_exchange_with_inactive_topics_and_row_range_errors():
+    import torch
+    import torch.distributed as dist
+    from mvtopicmodel_amd._lib import MvhdpError
+    from mvtopicmodel_amd.dist import GpuShard, sweep_all_reduce
+    K, V = 30, [400, 50, 60]
+    c = small_corpus(K, V, 90, [25, 4, 6], 93)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[25, 28]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive)
+    hy.alpha[:, K] = 30.0
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(3)]
+    for m in range(3):
+        z[m][np.isin(z[m], [25, 28])] = 2
+        o.set_assignments(m, z[m])
+    o.build_counts()
+    s = make_native(c, hy, z)
+    shard = GpuShard(s, "cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29612")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        acts = 0
+        for it in range(4):
+            ro = o.sweep(it, 8)
+            st = sweep_all_reduce(shard, it, 8, force_exchange=True)
+            assert st.activated_topic == ro["stats"]["activated_topic"]
+            acts += st.activated_topic >= 0
+            assert s.trees_current() == (st.activated_topic < 0)          # an activation changes alpha: trees rebuilt next sweep
+            assert_same_state(o, s, 3)
+            assert np.array_equal(s.get_alpha()[0], o.get_alpha()) and np.array_equal(s.get_alpha()[1], o.get_inactive())
+        assert acts >= 1
+        # bracket discipline
+        st = shard.sweep_local(9, 8)
+        with pytest.raises(MvhdpError):
+            s.apply_delta_rows(0, 10)                      # no begin
+        s.apply_delta_begin()
+        s.apply_delta_rows(0, 100)
+        with pytest.raises(MvhdpError):
+            s.apply_delta_end(-1, -1)                      # rows missing
+        s.apply_delta_begin()                              # (the n_k part is zero by now: applying it again adds nothing)
+        s.apply_delta_rows(100, sum(V)); s.apply_delta_rows(0, 100)
+        s.apply_delta_end(-1, -1)
+    finally:
+        dist.destroy_process_group()
+    shard.close()
     s.close()
 
 

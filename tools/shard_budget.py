@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""What one rank of an N-GPU run spends per sweep, measured on ONE GPU: rank 0's document shard of the workload
+(same cut as bench.py), the same call sequence as mvtopicmodel_amd.dist.sweep_all_reduce (sweep with NO_APPLY ->
+[all-reduce, not run here] -> apply_delta), host wall time and device time of every phase.  The collective itself cannot
+be timed on one GPU; everything else of the per-rank budget can (is >= 6x at 8 GPUs reachable?).
+
+  python tools/shard_budget.py --workload C4 --of 8 --steps 20 --warmup 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C4")
+    ap.add_argument("--of", type=int, default=8, help="number of ranks the corpus is cut for; rank 0's shard is run")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--live", action="store_true")
+    ap.add_argument("--plain", action="store_true", help="the unpipelined sequence: sweep (rebuilds the trees) -> apply_delta")
+    args = ap.parse_args()
+    import torch
+    from mvtopicmodel_amd import NativeSampler, synth
+    from mvtopicmodel_amd.dist import GpuShard
+    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE
+
+    cfg = synth.CONFIGS[args.workload]
+    K, V = cfg["K"], cfg["V"]
+    M = len(V)
+    doc_tokens = synth.config_doc_token_counts(args.workload)
+    lo, hi = synth.shard_bounds(doc_tokens, args.of)[0]
+    c = synth.make_config(args.workload, doc_lo=lo, doc_hi=hi)
+    inactive, K_init = synth.config_inactive(args.workload)
+    z0 = init_assignments(K_init, c.doc_off, seed=1)
+    s = NativeSampler(K, V, doc_id_base=lo)
+    for m in range(M):
+        s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z0[m])
+    s.set_hyper(Hyper.defaults(K, V, inactive=inactive))
+    s.build_counts()
+    # global-sized counts (the replica every rank holds): scale the shard's counts so that n_k has the magnitude of the full corpus
+    shard = GpuShard(s, "cuda:0")
+    with shard.on_stream():
+        shard.counts.mul_(args.of)
+    torch.cuda.synchronize()
+    s.counts_written()
+    flags = SWEEP_LIVE if args.live else 0
+    ph = {"sweep_call_host": 0.0, "sweep_kernel_dev": 0.0, "sweep_total_dev": 0.0, "apply_host": 0.0}
+    from mvtopicmodel_amd.dist import PIPELINE_CHUNKS
+    from mvtopicmodel_amd.native import SWEEP_REUSE_TREES
+    chunks, _ = shard.row_chunks(PIPELINE_CHUNKS)
+    for it in range(args.warmup + args.steps):
+        t0 = time.perf_counter()
+        if args.plain:
+            st = shard.sweep_local(it, 1, flags)
+            t1 = time.perf_counter()
+            # (the all-reduce of shard.delta would run here, on the same stream)
+            shard.apply(-1, -1)
+        else:
+            st = shard.sweep_local(it, 1, flags | (SWEEP_REUSE_TREES if shard.trees_current() else 0))
+            t1 = time.perf_counter()
+            # (the chunked all-reduce would be in flight here; each chunk's rows are applied and their trees rebuilt as it lands)
+            s.apply_delta_begin()
+            for r0, r1 in chunks:
+                s.apply_delta_rows(r0, r1)
+            s.apply_delta_end(-1, -1)
+        t2 = time.perf_counter()
+        if it >= args.warmup:
+            ph["sweep_call_host"] += (t1 - t0) * 1e3; ph["apply_host"] += (t2 - t1) * 1e3
+            ph["sweep_kernel_dev"] += st.sweep_kernel_ms; ph["sweep_total_dev"] += st.total_ms
+    out = {k: v / args.steps for k, v in ph.items()}
+    out.update(workload=args.workload, ranks=args.of, shard_entities=c.D, shard_tokens=c.total_tokens,
+               per_rank_ms_without_collective=out["sweep_call_host"] + out["apply_host"],
+               delta_bytes=int(shard.delta.numel() * 4), mode="live" if args.live else "deferred",
+               sequence="plain" if args.plain else "pipelined (apply + tree rebuild by row ranges, hidden behind the collective on a real run)")
+    print(json.dumps(out))
+    shard.close(); s.close()
+
+
+if __name__ == "__main__":
+    main()
