@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--docs", type=int, default=None, help="override the entity count (smoke runs)")
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-docs", type=int, default=60000)
+    ap.add_argument("--cpu-sample-docs", type=int, default=120000)
     ap.add_argument("--live", action="store_true",
                     help="MVHDP_SWEEP_LIVE: atomics straight on the shared counts (the reference's update discipline); "
                          "not bit-reproducible, so not the default")
@@ -250,7 +250,7 @@ def main():
     shard.close()
     s.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample_docs, D_total), 2, args.seed)
+        out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample_docs, D_total), 3, args.seed)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

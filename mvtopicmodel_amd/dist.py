@@ -230,8 +230,9 @@ def _sweep_pipelined(shard, sweep_idx, seed, group, flags, timings, t0):
     arrives its rows are applied and their F+trees rebuilt (mvhdp_apply_delta_rows) while the next chunk is still on the
     wire.  The next sweep then reuses the trees (MVHDP_SWEEP_REUSE_TREES) instead of rebuilding them.  Same integers as
     the plain sequence: the trees are built from the same counts by the same kernel."""
-    from .native import SWEEP_REUSE_TREES
-    reuse = SWEEP_REUSE_TREES if shard.trees_current() else 0
+    from .native import SWEEP_LIVE, SWEEP_REUSE_TREES
+    # (a live sweep rebuilds its trees per segment by itself; REUSE_TREES would mean "never" there)
+    reuse = SWEEP_REUSE_TREES if (shard.trees_current() and not (flags & SWEEP_LIVE)) else 0
     st = shard.sweep_local(sweep_idx, seed, flags | reuse)
     t1 = time.perf_counter()
     need_key = shard.has_inactive()

@@ -85,6 +85,16 @@ def test_config_at_full_size(name):
         else:
             assert st.new_mass_cnt == 0 and st.activated_topic == -1
         acts.append((st.activated_topic, st.activated_modality, st.activation_key))
+        if M > 1 and it == 0:
+            # WRK:327-337 for EVERY entity: the device's log / pow / cos feed Math.round(1000 x) -- one flipped rounding in a
+            # million entities would go unseen by the prefix check below
+            from oracle.binding import Oracle
+            ow = Oracle(K, V)
+            for m in range(M):
+                ow.set_corpus(m, np.zeros(c.D + 1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+            ow.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, None)
+            assert np.array_equal(ow.draw_p_philox(1, it), one.get_view_weights())
+            ow.close()
         # the oracle follows the first PREFIX entities against the same snapshot
         o = _oracle_prefix(c, (alpha_before, inactive_before if inactive is not None else None, hy), z_prev, counts_before)
         o.sweep(it, 1, flags=ORC_NO_APPLY, doc_id_base=0)

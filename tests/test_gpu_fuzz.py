@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from tests.helpers import assert_same_state, make_native, make_oracle
-from mvtopicmodel_amd.native import Hyper, SWEEP_EXACT_CHAIN, SWEEP_GENERIC_KERNEL
+from mvtopicmodel_amd.native import Hyper, SWEEP_EXACT_CHAIN, SWEEP_GENERIC_KERNEL, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS
 from mvtopicmodel_amd.synth import Corpus
 
 pytestmark = pytest.mark.gpu
@@ -41,6 +41,8 @@ def _case(seed):
     hy.gamma[:] = rng.uniform(0.3, 2.0, M)
     hy.beta[:] = rng.choice([0.01, 0.05, 0.2], M); hy.beta_sum[:] = hy.beta * np.array(V)
     flags = int(rng.choice([0, 0, 0, SWEEP_EXACT_CHAIN, SWEEP_GENERIC_KERNEL]))
+    # the segmented launch path (interleaved queue segments) under the deferred contract: same integers for any count
+    flags |= SWEEP_LIVE_SEGMENTS(int(rng.choice([0, 0, 1, 2, 3, 7, 40])))
     env = {"MVHDP_FORCE_MODE": str(rng.choice(["", "optimistic", "classified"])),
            "MVHDP_FORCE_RMAX": str(rng.choice(["", "", "1", "2", "4", "8", "16"]))}
     return c, hy, inactive, flags, env, rng
@@ -135,4 +137,34 @@ def test_random_shapes_statistics_and_shards(seed):
             assert np.array_equal(np.concatenate([sh.get_assignments(m) for sh in shards]), s.get_assignments(m))
         for sh in shards:
             sh.close()
+    s.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MVHDP_FUZZ_CASES", "40")) // 2))
+def test_random_shapes_live(seed, monkeypatch):
+    """MVHDP_SWEEP_LIVE on the same random shapes (variants, dispatch modes, unassigned and out-of-vocabulary tokens,
+    inactive topics): whatever the interleaving, the counts are the counts of z and the statistics add up."""
+    c, hy, inactive, flags, env, rng = _case(9000 + seed)
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    for m in range(c.M):
+        if inactive is not None:
+            z0[m][np.isin(z0[m], np.flatnonzero(inactive))] = int(np.flatnonzero(inactive == 0)[0])
+        if len(z0[m]) and rng.rand() < 0.3:
+            z0[m][rng.rand(len(z0[m])) < 0.1] = -1
+    s = make_native(c, hy, z0)
+    tokens_in_vocab = sum(int(((c.tokens[m] >= 0) & (c.tokens[m] < c.V[m])).sum()) for m in range(c.M))
+    for it in range(3):
+        st = s.sweep(it, 5 + seed, flags=(flags & ~0xFF0000) | SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(int(rng.choice([0, 1, 2, 5]))))
+        assert st.tokens == tokens_in_vocab and st.aborted_docs == 0
+        assert st.new_mass_cnt + st.topic_doc_mass_cnt + st.word_ftree_mass_cnt == st.tokens
+        for m in range(c.M):
+            z = s.get_assignments(m)
+            nwk, nk = s.get_counts(m)
+            ok = (z >= 0) & (c.tokens[m] >= 0) & (c.tokens[m] < c.V[m])
+            ref = np.zeros_like(nwk); np.add.at(ref, (c.tokens[m][ok], z[ok]), 1)
+            assert nwk.min() >= 0 and np.array_equal(ref, nwk) and np.array_equal(ref.sum(axis=0), nk)
     s.close()
