@@ -52,6 +52,17 @@ def test_device_buffers_alias_and_single_rank_rccl_all_reduce():
                 o.build_trees()
                 assert np.array_equal(o.get_tree(m, w), s.get_tree(m, w))
         assert ph["n"] == 4 and "exchange_device" in ph
+        # live sweeps through the same exchange (each replica live for its own entities, AD-LDA across replicas): the
+        # shard's delta is counts_after - counts_before, the snapshot is restored, the pipeline applies the sum
+        from mvtopicmodel_amd.native import SWEEP_LIVE, SWEEP_LIVE_SEGMENTS
+        for it in range(7, 10):
+            st = sweep_all_reduce(shard, it, 5, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(3), force_exchange=True, pipeline=(it != 8))
+            assert st.tokens == c.total_tokens
+            for m in range(2):
+                z = s.get_assignments(m)
+                nwk, nk = s.get_counts(m)
+                ref = np.zeros_like(nwk); np.add.at(ref, (c.tokens[m], z), 1)
+                assert nwk.min() >= 0 and np.array_equal(ref, nwk) and np.array_equal(ref.sum(axis=0), nk)
     finally:
         dist.destroy_process_group()
     shard.close()

@@ -263,3 +263,92 @@ def test_kat7_every_history():
                 got, want, _ = _kat7_run_oracle(seed, with_inactive, m_t, pos_t)
                 worst = max(worst, float(np.abs(got - want).max()))
     assert worst < 1e-12
+
+
+class _PyJavaRandom:
+    """java.util.Random, documented contract, in plain Python (independent of the C oracle)."""
+
+    def __init__(self, seed):
+        self.s = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+        self.have = False
+        self.nxt = 0.0
+
+    def next(self, bits):
+        self.s = (self.s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        v = self.s >> (48 - bits)
+        return v - (1 << bits) if v >= (1 << (bits - 1)) and bits == 32 else v
+
+    def uniform(self):                       # MALLET Randoms.nextUniform == nextDouble
+        return ((self.next(26) << 27) + self.next(27)) / float(1 << 53)
+
+    def gaussian(self):                      # MALLET Randoms.nextGaussian: Box-Muller, caches the sine twin
+        import math
+        if not self.have:
+            v1, v2 = self.uniform(), self.uniform()
+            x1 = math.sqrt(-2 * math.log(v1)) * math.cos(2 * math.pi * v2)
+            self.nxt = math.sqrt(-2 * math.log(v1)) * math.sin(2 * math.pi * v2)
+            self.have = True
+            return x1
+        self.have = False
+        return self.nxt
+
+    def beta(self, a, b):                    # MALLET Randoms.nextBeta as read from the 2.0.8 class file (SURVEY 8c)
+        import math
+        if a == 1 and b == 1:
+            return self.uniform()
+        if a >= 1 and b >= 1:
+            A, B = a - 1, b - 1
+            C_ = A + B
+            L = C_ * math.log(C_)
+            mu, sigma = A / C_, 0.5 / math.sqrt(C_)
+            y = self.gaussian(); x = sigma * y + mu
+            while x < 0 or x > 1:
+                y = self.gaussian(); x = sigma * y + mu
+            u = self.uniform()
+            while True:
+                with np.errstate(all="ignore"):
+                    t2 = np.float64(B) * np.log(np.float64(1 - x) / np.float64(B))     # b == 1: 0 * log(./0) = NaN -> comparison false
+                    rhs = A * math.log(x / A) + t2 + L + 0.5 * y * y
+                if not (math.log(u) >= rhs):
+                    return x
+                y = self.gaussian(); x = sigma * y + mu
+                while x < 0 or x > 1:
+                    y = self.gaussian(); x = sigma * y + mu
+                u = self.uniform()
+        v1, v2 = math.pow(self.uniform(), 1 / a), math.pow(self.uniform(), 1 / b)
+        while v1 + v2 > 1:
+            v1, v2 = math.pow(self.uniform(), 1 / a), math.pow(self.uniform(), 1 / b)
+        return v1 / (v1 + v2)
+
+
+def test_kat8_view_weights_from_the_mallet_stream_independent_restatement():
+    """WRK:327-337 drawn with the worker's MALLET Randoms (java.util.Random LCG -> nextUniform -> nextBeta ->
+    Math.round(1000 x)/1000), restated in plain Python from the documented JDK contract and the class-file reading of
+    nextBeta -- no call into the C oracle for the expected value -- for the Joehnk branch (a < 1), the Gaussian-proposal
+    branch with its b == 1 NaN quirk (a > 1) and the beta == 0.0001 clamp of Q4."""
+    import math
+    from tests.helpers import small_corpus, make_oracle
+    from mvtopicmodel_amd.native import Hyper
+    K, V = 6, [40, 9, 9]
+    c = small_corpus(K, V, 25, [8, 3, 3], seed=4)
+    for pa, clamp in ((0.31, False), (1.1, False), (0.74, True)):
+        hy = Hyper.defaults(K, V, p_a=pa)
+        if clamp:
+            hy.beta[2] = 0.0001; hy.beta_sum[2] = 0.0001 * V[2]
+        o = make_oracle(c, hy)
+        got = o.draw_p_mallet(12345)
+        r = _PyJavaRandom(12345)
+        want = np.zeros((c.D, 3, 3))
+        for d in range(c.D):
+            for m in range(3):
+                for j in range(m, 3):
+                    if m == j:
+                        pr = 1.0
+                    else:
+                        x = 1000 * r.beta(pa, 1.0)
+                        pr = float(math.floor(x + 0.5)) / 1000.0            # Math.round for non-negative finite x
+                    want[d, m, j] = 0.0 if (j != 0 and hy.beta[j] == 0.0001) else pr
+                    want[d, j, m] = 0.0 if (m != 0 and hy.beta[m] == 0.0001) else pr
+        assert np.array_equal(got, want), (pa, clamp)
+        if clamp:
+            assert np.all(got[:, 2, 2] == 0) and np.all(got[:, 0, 2] == 0) and np.any(got[:, 2, 0] > 0)
