@@ -444,8 +444,7 @@ extern "C" int mvhdp_init_assignments_from_trees(mvhdp_handle h, uint64_t seed)
     int rc = require_corpus(h); if (rc) return rc;
     if (!h->have_trees) FAIL(h, MVHDP_ERR_STATE, "init_assignments_from_trees before build_trees/build_inference_trees");
     HIPC(h, hipSetDevice(h->device));
-    { int rc2 = ensure_full_trees(h); if (rc2) return rc2; }
-    HIPC(h, mvhdp_launch_init_from_trees(h->mm, (uint32_t)seed, (uint32_t)(seed >> 32), h->stream));
+    HIPC(h, mvhdp_launch_init_from_trees(h->mm, (uint32_t)seed, (uint32_t)(seed >> 32), h->stream));     // reads the descent table only
     HIPC(h, hipStreamSynchronize(h->stream));
     h->rmax_hint = 0;
     return MVHDP_OK;

@@ -941,26 +941,57 @@ hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipS
 // init_from_trees: INF:169-199.  One wave per (view, entity): each token's topic is drawn from its
 // type's tree (FTree.sample FT:111-136); out-of-vocabulary tokens get 0 (Java's new int[]).
 // ---------------------------------------------------------------------------
+// FTree.sample (FT:111-136) through the descent table (MvModel::dtab), one lane per token: the same reads, comparisons and
+// subtractions as the literal descent over FTree.tree, three levels per 64-byte block (see the chunk head of the
+// register-resident sweep kernel, which walks the same table the same way).
+__device__ __forceinline__ int dtab_sample(const MvModel& mm, int64_t row, double u01)
+{
+    const int K = mm.K;
+    const double* __restrict__ dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
+    double u = 0.0;
+    int i = 1;
+    for (int bd = 0; bd < mm.dt_nbd; bd++) {
+        if (bd == 0 || i < K) {
+            const double2* __restrict__ blk = (const double2*)(dt + (int64_t)(mm.dt_base[bd] + (i - (1 << mm.dt_depth[bd]))) * 8);
+            const double2 q0 = blk[0], q1 = blk[1], q2 = blk[2], q3 = blk[3];
+            const int levels = (bd == 0) ? mm.dt_f : 3;
+            if (bd == 0) u = u01 * q3.y;                                              // FT:120  u *= tree[1]
+            int path = 0;
+            if (i < K && levels > 0) {                                                // FT:122-130
+                const double l = q0.x;
+                if (u < l) { i = 2 * i; } else { u = u - l; i = 2 * i + 1; path = 1; }
+            }
+            if (i < K && levels > 1) {
+                const double l = path ? q1.x : q0.y;
+                if (u < l) { i = 2 * i; path = 2 * path; } else { u = u - l; i = 2 * i + 1; path = 2 * path + 1; }
+                if (i < K && levels > 2) {
+                    const double l3 = (path == 0) ? q1.y : (path == 1) ? q2.x : (path == 2) ? q2.y : q3.x;
+                    if (u < l3) { i = 2 * i; } else { u = u - l3; i = 2 * i + 1; }
+                }
+            }
+        }
+    }
+    return i - K;                                                                     // FT:132
+}
+
 __global__ __launch_bounds__(256) void init_from_trees_kernel(MvModel mm, uint32_t seed_lo, uint32_t seed_hi)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K = mm.K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wstride = (int64_t)gridDim.x * 4;
     for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < mm.D; d += wstride) {
         const int64_t dg = mm.doc_id_base + d;
         for (int m = 0; m < mm.M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
-            for (int64_t i = b; i < e; i++) {                      // tokens one at a time: the descent is wave-wide
+            for (int64_t i = b + lane; i < e; i += WAVE) {             // one lane per token: 64 descents side by side
                 const int type = mm.tok[m][i];
-                int topic = 0;
+                int topic = 0;                                         // out-of-vocabulary: Java's new int[] (INF:193-199)
                 if (type >= 0 && type < mm.V[m]) {
                     uint32_t x[4];
                     philox4x32_10((uint32_t)(i - b), (uint32_t)m, (uint32_t)dg, 0xFFFFFFFFu,
                                   seed_lo, seed_hi ^ (uint32_t)((unsigned long long)dg >> 32), x);
-                    const double u = bits_to_unit(x[0], x[1]);
-                    const int64_t row = mm.rowbase[m] + type;
-                    topic = tree_sample(mm.trees + row * 2 * K, K, u, mm.root[row], lane);
+                    topic = dtab_sample(mm, mm.rowbase[m] + type, bits_to_unit(x[0], x[1]));
                 }
-                if (lane == 0) mm.z[m][i] = topic;
+                mm.z[m][i] = topic;
             }
         }
     }
