@@ -760,14 +760,22 @@ hipError_t mvhdp_launch_live_helper(const MvModel& mm, int which, unsigned long 
 // (PTM:620-651) recomputed from z.  One wave per entity.  Bucket 0 is filled
 // afterwards from the totals (docs with the view minus docs holding the topic).
 // ---------------------------------------------------------------------------
+// The low buckets take nearly every increment (a topic an entity holds, it mostly holds once or a few times), so each
+// workgroup keeps its own copy of buckets [0, CL) and of the holder counts in LDS and adds them to the global arrays once at
+// the end: the global atomics no longer queue on K hot words per bucket (25.7 -> a few ms per view at C4).
 __global__ __launch_bounds__(256) void doc_topic_hist_kernel(MvModel mm, int m, int32_t* hist, int32_t hist_len,
-                                                             int32_t* doc_len_counts, int32_t len_len, int32_t* docs_with_view)
+                                                             int32_t* doc_len_counts, int32_t len_len, int32_t* docs_with_view, int CL)
 {
-    extern __shared__ int ldk[];                           // [waves][K]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K = mm.K;
+    extern __shared__ int ldk[];                           // [waves][K] per-entity counts, [K][CL] low buckets, [K] holders, [1] entities
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K = mm.K, nwaves = blockDim.x >> 6;
     int* my = ldk + wave * K;
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t d = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; d < mm.D; d += wstride) {
+    int* low = ldk + nwaves * K;
+    int* holders = low + K * CL;
+    int* nview = holders + K;
+    for (int i = threadIdx.x; i < K * CL + K + 1; i += blockDim.x) low[i] = 0;
+    __syncthreads();
+    const int64_t wstride = (int64_t)gridDim.x * nwaves;
+    for (int64_t d = (int64_t)blockIdx.x * nwaves + wave; d < mm.D; d += wstride) {
         const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
         if (e == b) continue;
         for (int k = lane; k < K; k += WAVE) my[k] = 0;
@@ -776,15 +784,27 @@ __global__ __launch_bounds__(256) void doc_topic_hist_kernel(MvModel mm, int m, 
         LDS_FENCE();
         for (int k = lane; k < K; k += WAVE) {
             int c = my[k];
-            if (c > 0 && c < hist_len && hist) atomicAdd(&hist[(int64_t)k * hist_len + c], 1);
-            if (c > 0 && hist) atomicAdd(&docs_with_view[1 + k], 1);          // entities holding the topic at all (for bucket 0)
+            if (c > 0 && hist) {
+                if (c < CL) atomicAdd(&low[k * CL + c], 1);
+                else if (c < hist_len) atomicAdd(&hist[(int64_t)k * hist_len + c], 1);
+                atomicAdd(&holders[k], 1);                 // entities holding the topic at all (for bucket 0)
+            }
         }
         if (lane == 0) {
-            atomicAdd(docs_with_view, 1);
+            atomicAdd(nview, 1);
             if (doc_len_counts && e - b < len_len) atomicAdd(&doc_len_counts[e - b], 1);
         }
         LDS_FENCE();
     }
+    __syncthreads();
+    if (hist) {
+        for (int i = threadIdx.x; i < K * CL; i += blockDim.x) {
+            const int v = low[i], k = i / CL, c = i - k * CL;
+            if (v && c < hist_len) atomicAdd(&hist[(int64_t)k * hist_len + c], v);
+        }
+        for (int k = threadIdx.x; k < K; k += blockDim.x) if (holders[k]) atomicAdd(&docs_with_view[1 + k], holders[k]);
+    }
+    if (threadIdx.x == 0 && *nview) atomicAdd(docs_with_view, *nview);
 }
 
 // bucket 0 = entities with the view that do not hold the topic (PTM:647-649); entities holding it more than hist_len-1
@@ -808,11 +828,19 @@ hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, 
     if (e == hipSuccess) {
         int wpb = 4;
         while (wpb > 1 && (size_t)wpb * mm.K * sizeof(int) > 60000) wpb >>= 1;
+        int CL = 16384 / mm.K;                               // low buckets kept per workgroup: at most 64 KiB of LDS
+        if (CL > 32) CL = 32;
+        if (CL < 2) CL = 2;
+        if (CL > hist_len) CL = hist_len;
+        const size_t lds = ((size_t)wpb * mm.K + (size_t)mm.K * CL + mm.K + 1) * sizeof(int);
+        if (lds > 65536) {
+            e = hipFuncSetAttribute((const void*)doc_topic_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         int64_t blocks = (mm.D + wpb - 1) / wpb;
-        int grid = (int)(blocks < 4096 ? (blocks < 1 ? 1 : blocks) : 4096);
-        hipLaunchKernelGGL(doc_topic_hist_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * mm.K * sizeof(int), s,
-                           mm, m, hist, hist_len, doc_len_counts, len_len, dwv);
-        e = hipGetLastError();
+        int grid = (int)(blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024);
+        if (e == hipSuccess) hipLaunchKernelGGL(doc_topic_hist_kernel, dim3(grid), dim3(64 * wpb), lds, s,
+                                                mm, m, hist, hist_len, doc_len_counts, len_len, dwv, CL);
+        if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess && hist) {
             hipLaunchKernelGGL(hist_bucket0_kernel, dim3((mm.K + 63) / 64), dim3(64), 0, s, hist, hist_len, mm.K, dwv);
             e = hipGetLastError();
