@@ -176,6 +176,12 @@ int mvhdp_get_count_histogram(mvhdp_handle h, int32_t m, int32_t* hist, int32_t 
 int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums /*[M][M]*/);
 /* modelLogLikelihood PTM:3322-3452, one value per view. */
 int mvhdp_model_log_likelihood(mvhdp_handle h, double* log_likelihood /*[M]*/);
+/* optimizeGamma PTM:2415-2433, the document level (Teh et al. 2006): over the entities that have view m, of length j,
+ * qs = sum Bernoulli(j/(j+gamma_m)) and qw = sum log Beta(gamma_m+1, j).  The reference draws them sequentially from a
+ * stream that cannot be seeded (RandomSamplers over ThreadLocalRandom, PTM:236), ten rounds per view; here every entity
+ * draws from its own counter-based stream (seed, global entity id, view, round): the same random variables in distribution,
+ * reproducible, shard-independent.  A host keeps its closed-form updates and calls this for the two sums. */
+int mvhdp_gamma_doc_statistics(mvhdp_handle h, int32_t m, double gamma_m, uint64_t seed, uint32_t round, double* qs, double* qw);
 /* printDocumentTopics PTM:2871-2899 (and the inferencer's INF:383-411): topic proportions of entities [d0, d1),
  * out[(d-d0)*K + k] = sum_m w[m]*(n_dk[m][k] + gamma[m]*alpha[m][k])/(len[m] + gamma[m]*alphaSum[m]) / sum_m w[m],
  * w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m].  As in the reference, whose topicCounts[m] / docLen[m]

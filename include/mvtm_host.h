@@ -65,6 +65,8 @@ int   mvtm_java_double_to_string(double v, char* out, int cap);
 void* mvtm_model_native_handle(void* model);
 /* update discipline of estimate()'s sweeps: 0 = deferred (parity contract), 1 = MVHDP_SWEEP_LIVE (UPD:197-218) */
 int   mvtm_model_set_live_updates(void* model, int live, int tree_rebuilds_per_sweep);
+/* optimizeGamma's per-entity Bernoulli / Beta sums (PTM:2415-2433): 0 = sequential host loop (the reference's), 1 = device kernel */
+int   mvtm_model_set_device_gamma_statistics(void* model, int on);
 /* FastQMVWVTopicInferencer (INF:114-330) as one call chain: getInferencer() PTM:3457, then
  * inferTopicDistributionsOnNewDocs = align views by name, trees without gamma*alpha, tree-sampled initial topics,
  * numIterations (10) frozen sweeps, printDocumentTopics(out, 0.03, -1) text.  Returns the text length (-1 on error). */

@@ -15,6 +15,7 @@ ABI_SYMBOLS = [
     "mvhdp_build_inference_trees", "mvhdp_init_assignments_from_trees",
     "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
     "mvhdp_get_count_histogram", "mvhdp_view_overlap_sums", "mvhdp_model_log_likelihood", "mvhdp_doc_topic_proportions",
+    "mvhdp_gamma_doc_statistics",
     "mvhdp_sweep", "mvhdp_apply_delta", "mvhdp_apply_delta_begin", "mvhdp_apply_delta_rows", "mvhdp_apply_delta_end",
     "mvhdp_trees_current", "mvhdp_get_view_weights",
     "mvhdp_device_buffer", "mvhdp_counts_written", "mvhdp_set_stream", "mvhdp_synchronize",
@@ -90,6 +91,7 @@ def load_library():
     L.mvhdp_view_overlap_sums.argtypes = [vp, vp]
     L.mvhdp_model_log_likelihood.argtypes = [vp, vp]
     L.mvhdp_doc_topic_proportions.argtypes = [vp, vp, i64, i64, vp]
+    L.mvhdp_gamma_doc_statistics.argtypes = [vp, i32, C.c_double, u64, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mvhdp_sweep.argtypes = [vp, u32, u64, u32, vp, C.POINTER(DebugC), C.POINTER(SweepStatsC)]
     L.mvhdp_apply_delta.argtypes = [vp, i32, i32]
     L.mvhdp_apply_delta_begin.argtypes = [vp]

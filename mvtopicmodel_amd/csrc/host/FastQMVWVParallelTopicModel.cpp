@@ -441,6 +441,7 @@ void FastQMVWVParallelTopicModel::optimizeGamma()
 {
     const int M = numModalities, K = numTopics;
     ensureHostSamplers();
+    gammaCalls_++;
     RandomSamplers<JavaRandom> samp(&sampRand_);
     const double aalpha = 5, balpha = 0.1, agamma = 5, bgamma = 0.1;                 // PTM:2373-2379
     const int R = 10;
@@ -460,6 +461,12 @@ void FastQMVWVParallelTopicModel::optimizeGamma()
             int u = samp.randBernoulli(pie);
             gammaView[m] = samp.randGamma(agamma + K - 1 + u, 1. / bloge);
             double qs = 0, qw = 0;                                                   // document level (Teh+06)
+            if (deviceGammaStatistics_) {
+                // the same two sums, every entity drawing from its own counter-based stream on the device (the
+                // reference's stream for them, `samp` over ThreadLocalRandom, cannot be seeded or replayed anyway)
+                const uint64_t seed = (randomSeed == -1) ? 0x9E3779B97F4A7C15ull : (uint64_t)(int64_t)randomSeed;
+                check(mvhdp_gamma_doc_statistics(h_, m, gamma[m], seed, (uint32_t)(gammaCalls_ * 16 + r), &qs, &qw), "mvhdp_gamma_doc_statistics");
+            } else
             for (size_t j = 0; j < docLengthCounts[m].size(); j++)
                 for (int i = 0; i < docLengthCounts[m][j]; i++) {
                     qs += samp.randBernoulli((double)j / ((double)j + gamma[m]));
@@ -729,6 +736,12 @@ extern "C" {
 
 const char* mvtm_last_error(void) { return g_host_err.c_str(); }
 void mvtm_set_last_error(const char* msg) { g_host_err = msg ? msg : ""; }
+
+int mvtm_model_set_device_gamma_statistics(void* p, int on)
+{
+    ((FastQMVWVParallelTopicModel*)p)->setDeviceGammaStatistics(on != 0);
+    return 0;
+}
 
 int mvtm_model_set_live_updates(void* p, int live, int tree_rebuilds_per_sweep)
 {

@@ -82,6 +82,10 @@ public:
     // Update discipline of the sweeps estimate() runs: false = deferred (snapshot sweep, bit-reproducible: the parity
     // contract), true = MVHDP_SWEEP_LIVE (the updater threads' own discipline, UPD:197-218; profiles/r02_ll_curves.md)
     void setLiveUpdates(bool live, int treeRebuildsPerSweep = 0) { liveUpdates_ = live; liveSegments_ = treeRebuildsPerSweep; }
+    // optimizeGamma's document-level sums (PTM:2415-2433): false = the reference's sequential host loop over every entity,
+    // ten rounds per view (reproducible against the Python oracle under an injected stream; 1.9 s per call at C4),
+    // true = mvhdp_gamma_doc_statistics on the device (the same random variables in distribution; milliseconds)
+    void setDeviceGammaStatistics(bool on) { deviceGammaStatistics_ = on; }
 
     // PTM:396.  batchId / vectorSize / previousModel are outside the hot path (previousModel must be null).
     void addInstances(const std::vector<InstanceList>& training, const std::string& batchId = "", int vectorSize = 0);
@@ -191,6 +195,8 @@ private:
     int64_t docIdBase_ = 0;
     bool liveUpdates_ = false;
     int liveSegments_ = 0;
+    bool deviceGammaStatistics_ = false;
+    uint32_t gammaCalls_ = 0;
 };
 
 }  // namespace mvtm

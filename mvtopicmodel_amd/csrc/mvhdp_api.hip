@@ -1174,6 +1174,30 @@ extern "C" int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_we
     return MVHDP_OK;
 }
 
+extern "C" int mvhdp_gamma_doc_statistics(mvhdp_handle h, int32_t m, double gamma_m, uint64_t seed, uint32_t round, double* qs, double* qw)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M || !qs || !qw || !(gamma_m > 0.0)) FAIL(h, MVHDP_ERR_INVALID_ARG, "gamma_doc_statistics: bad argument");
+    int rc = require_corpus(h); if (rc) return rc;
+    *qs = 0; *qw = 0;
+    if (mm.D == 0) return MVHDP_OK;
+    HIPC(h, hipSetDevice(h->device));
+    const int NB = 1024;                                   // fixed: the summation order is part of the result
+    double* d_part = nullptr;
+    std::vector<double> part(2 * NB);
+    hipError_t e = hipMalloc(&d_part, 2 * NB * sizeof(double));
+    if (e == hipSuccess) e = mvhdp_launch_gamma_doc_stats(mm, m, gamma_m, (uint32_t)seed, (uint32_t)(seed >> 32), round, d_part, NB, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, 2 * NB * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (d_part) hipFree(d_part);
+    HIPC(h, e);
+    double a = 0, b = 0;
+    for (int i = 0; i < NB; i++) { a += part[2 * i]; b += part[2 * i + 1]; }
+    *qs = a; *qw = b;
+    return MVHDP_OK;
+}
+
 extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
 {
     CHECK_H(h);

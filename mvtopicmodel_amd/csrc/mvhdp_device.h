@@ -97,6 +97,8 @@ hipError_t mvhdp_launch_count_hist(const MvModel& mm, int m, int32_t* hist, int3
 hipError_t mvhdp_launch_view_overlap(const MvModel& mm, double* out, hipStream_t s);
 hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
                                unsigned long long* nonzero, hipStream_t s);
+hipError_t mvhdp_launch_gamma_doc_stats(const MvModel& mm, int m, double gamma_m, uint32_t seed_lo, uint32_t seed_hi, uint32_t round,
+                                        double* partial, int n_blocks, hipStream_t s);
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s);
 struct DocTopicCarry { const int64_t* src[MVHDP_MAXM]; };   // per view [D]: the entity whose counts score entity d (PTM:2873-2886)
 hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const DocTopicCarry& carry, const double* w_dev, int64_t d0, int64_t d1, double* out_dev, hipStream_t s);

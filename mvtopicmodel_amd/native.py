@@ -236,6 +236,12 @@ class NativeSampler:
         self._ck(self.L.mvhdp_model_log_likelihood(self.h, _ptr(ll)))
         return ll
 
+    def gamma_doc_statistics(self, m, gamma_m, seed, round_idx):
+        """PTM:2415-2433: (qs, qw) = (sum Bernoulli(j/(j+gamma)), sum log Beta(gamma+1, j)) over the entities with view m."""
+        qs, qw = C.c_double(), C.c_double()
+        self._ck(self.L.mvhdp_gamma_doc_statistics(self.h, int(m), float(gamma_m), int(seed), int(round_idx), C.byref(qs), C.byref(qw)))
+        return qs.value, qw.value
+
     def doc_topic_proportions(self, view_weights, d0=0, d1=None):
         """PTM:2871-2899: [d1-d0][K] topic proportions, view_weights[m] = (m==0 ? 1 : discrWeight[m]) * pMean[0][m]."""
         d1 = self.D if d1 is None else int(d1)

@@ -194,3 +194,39 @@ def test_doc_topic_proportions_and_print_document_topics(tmp_path):
     assert lines[0] == "#doc name topic proportion ..." and lines[1].startswith("0\t1000\t")
     assert lines[2].startswith(lines[1])                                # the builder keeps growing within an entity
     model.close()
+
+
+@pytest.mark.gpu
+def test_gamma_doc_statistics_distribution_and_determinism():
+    """optimizeGamma's document-level sums (PTM:2415-2433) from the device: qs = sum Bernoulli(j/(j+gamma)),
+    qw = sum log Beta(gamma+1, j) over the entities with the view.  The reference's stream for them cannot be seeded, so the
+    bar is the distribution: E qs = sum j/(j+gamma), Var qs = sum p(1-p); E qw = sum psi(gamma+1) - psi(gamma+1+j),
+    Var qw = sum psi'(gamma+1) - psi'(gamma+1+j); plus determinism for a seed and independence of document shards."""
+    from scipy.special import digamma, polygamma
+    from mvtopicmodel_amd import NativeSampler, synth
+    K, V = 10, [300, 40]
+    c = synth.generate(K, V, 40000, [30, 4], seed=41, chunk_docs=8192)
+    s = NativeSampler(K, V)
+    for m in range(2):
+        s.set_corpus(m, c.doc_off[m], c.tokens[m])
+    for m, g in ((0, 1.0), (1, 0.37), (0, 6.5)):
+        j = np.diff(c.doc_off[m]).astype(np.float64); j = j[j > 0]
+        p = j / (j + g)
+        e_qs, v_qs = p.sum(), (p * (1 - p)).sum()
+        e_qw = (digamma(g + 1) - digamma(g + 1 + j)).sum()
+        v_qw = (polygamma(1, g + 1) - polygamma(1, g + 1 + j)).sum()
+        draws = np.array([s.gamma_doc_statistics(m, g, 777, r) for r in range(24)])
+        assert abs(draws[:, 0].mean() - e_qs) < 4 * np.sqrt(v_qs / 24) and abs(draws[:, 1].mean() - e_qw) < 4 * np.sqrt(v_qw / 24)
+        assert 0.4 * v_qs < draws[:, 0].var(ddof=1) < 2.2 * v_qs and 0.4 * v_qw < draws[:, 1].var(ddof=1) < 2.2 * v_qw
+        assert s.gamma_doc_statistics(m, g, 777, 3) == tuple(draws[3])                       # deterministic for (seed, round)
+        assert s.gamma_doc_statistics(m, g, 778, 3) != tuple(draws[3])
+    # two shards with global entity ids: the per-entity draws are the same, so the sums agree up to the summation order
+    lo = 17000
+    a = NativeSampler(K, V); b = NativeSampler(K, V, doc_id_base=lo)
+    sa, sb = c.slice_docs(0, lo), c.slice_docs(lo, c.D)
+    for m in range(2):
+        a.set_corpus(m, sa.doc_off[m], sa.tokens[m]); b.set_corpus(m, sb.doc_off[m], sb.tokens[m])
+    whole = s.gamma_doc_statistics(0, 1.0, 777, 5)
+    pa, pb = a.gamma_doc_statistics(0, 1.0, 777, 5), b.gamma_doc_statistics(0, 1.0, 777, 5)
+    assert pa[0] + pb[0] == whole[0] and abs(pa[1] + pb[1] - whole[1]) < 1e-9 * abs(whole[1])
+    a.close(); b.close(); s.close()
