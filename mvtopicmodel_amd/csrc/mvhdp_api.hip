@@ -398,6 +398,12 @@ extern "C" int mvhdp_build_counts(mvhdp_handle h)
     int rc = require_corpus(h); if (rc) return rc;
     HIPC(h, hipSetDevice(h->device));
     HIPC(h, mvhdp_launch_build_counts(h->mm, h->N, h->stream));
+    if (h->delta_pending) {
+        // a NO_APPLY sweep's deltas were never applied: z already holds its assignments, so the recount above includes
+        // them -- drop the deltas instead of leaving them to be added on top
+        HIPC(h, hipMemsetAsync(h->mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), h->stream));
+        h->delta_pending = false; h->delta_clean = true;
+    }
     HIPC(h, hipStreamSynchronize(h->stream));
     h->have_counts = true; h->have_trees = false;
     return MVHDP_OK;
@@ -652,6 +658,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
                   MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff))) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
     const bool live = (flags & MVHDP_SWEEP_LIVE) != 0;
     if (live && (flags & MVHDP_SWEEP_FROZEN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: LIVE and FROZEN exclude each other");
+    if (h->rows_applied >= 0) FAIL(h, MVHDP_ERR_STATE, "sweep: an mvhdp_apply_delta_begin bracket is open (call mvhdp_apply_delta_end)");
     if (h->delta_pending && !(flags & MVHDP_SWEEP_FROZEN))
         FAIL(h, MVHDP_ERR_STATE, "sweep: the previous NO_APPLY sweep's deltas have not been applied (mvhdp_apply_delta)");
     // live sweep: the entities are cut into nseg interleaved segments of the longest-first order, the trees are rebuilt
