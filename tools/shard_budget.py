@@ -18,6 +18,72 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def exact(args):
+    import torch
+    from mvtopicmodel_amd import NativeSampler, synth
+    from mvtopicmodel_amd.dist import PIPELINE_CHUNKS, GpuShard
+    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.native import Hyper, SWEEP_REUSE_TREES
+    cfg = synth.CONFIGS[args.workload]
+    K, V = cfg["K"], cfg["V"]
+    M = len(V)
+    c = synth.make_config(args.workload)
+    inactive, K_init = synth.config_inactive(args.workload)
+    z0 = init_assignments(K_init, c.doc_off, seed=1)
+    tot = sum(np.diff(c.doc_off[m]) for m in range(M))
+    bounds = synth.shard_bounds(tot, args.of)
+    shards = []
+    for lo, hi in bounds:
+        sub = c.slice_docs(lo, hi)
+        s = NativeSampler(K, V, doc_id_base=lo)
+        for m in range(M):
+            s.set_corpus(m, sub.doc_off[m], sub.tokens[m]); s.set_assignments(m, z0[m][c.doc_off[m][lo]:c.doc_off[m][hi]])
+        s.set_hyper(Hyper.defaults(K, V, inactive=inactive)); s.build_counts()
+        shards.append(GpuShard(s, "cuda:0"))
+    torch.cuda.synchronize()
+    total = shards[0].counts.clone()
+    for g in shards[1:]:
+        total += g.counts
+    for g in shards:
+        g.counts.copy_(total)
+    torch.cuda.synchronize()
+    for g in shards:
+        g.counts_written()
+    chunks, _ = shards[0].row_chunks(PIPELINE_CHUNKS)
+    ph = {"sweep_call_host": 0.0, "sweep_kernel_dev": 0.0, "apply_and_trees_host": 0.0}
+    for it in range(args.warmup + args.steps):
+        sts = []
+        for r, g in enumerate(shards):
+            t0 = time.perf_counter()
+            st = g.sweep_local(it, 1, SWEEP_REUSE_TREES if g.trees_current() else 0)
+            t1 = time.perf_counter()
+            sts.append(st)
+            if r == 0 and it >= args.warmup:
+                ph["sweep_call_host"] += (t1 - t0) * 1e3; ph["sweep_kernel_dev"] += st.sweep_kernel_ms
+        torch.cuda.synchronize()
+        total = shards[0].delta.clone()
+        for g in shards[1:]:
+            total += g.delta
+        for g in shards:
+            g.delta.copy_(total)
+        torch.cuda.synchronize()
+        for r, g in enumerate(shards):
+            t0 = time.perf_counter()
+            g.s.apply_delta_begin()
+            for r0, r1 in chunks:
+                g.s.apply_delta_rows(r0, r1)
+            g.s.apply_delta_end(-1, -1)
+            if r == 0 and it >= args.warmup:
+                ph["apply_and_trees_host"] += (time.perf_counter() - t0) * 1e3
+    out = {k: v / args.steps for k, v in ph.items()}
+    nk_fp = [int(np.asarray(shards[0].s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]
+    out.update(workload=args.workload, ranks=args.of, shard0_tokens=int(tot[bounds[0][0]:bounds[0][1]].sum()), final_nk_fingerprint=nk_fp,
+               note="all shards on one GPU, true global counts; rank 0's calls timed; the collective itself is not (device-side sum instead)")
+    print(json.dumps(out))
+    for g in shards:
+        g.close(); g.s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="C4")
@@ -26,6 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--live", action="store_true")
     ap.add_argument("--plain", action="store_true", help="the unpipelined sequence: sweep (rebuilds the trees) -> apply_delta")
+    ap.add_argument("--exact", action="store_true",
+                    help="hold ALL N shards on this one GPU and run the real N-shard computation (deltas summed on the device as the "
+                         "all-reduce would): rank 0's calls are timed against true global counts, not against scaled local ones")
     args = ap.parse_args()
     import torch
     from mvtopicmodel_amd import NativeSampler, synth
@@ -33,6 +102,8 @@ def main():
     from mvtopicmodel_amd.host import init_assignments
     from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE
 
+    if args.exact:
+        return exact(args)
     cfg = synth.CONFIGS[args.workload]
     K, V = cfg["K"], cfg["V"]
     M = len(V)
