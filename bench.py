@@ -73,7 +73,8 @@ def main():
                     help="MVHDP_SWEEP_LIVE: atomics straight on the shared counts (the reference's update discipline); "
                          "not bit-reproducible, so not the default")
     ap.add_argument("--live-segments", type=int, default=0, help="F+tree rebuilds per live sweep (0 = library default)")
-    ap.add_argument("--live-steps", type=int, default=5, help="live sweeps timed after the K steps for the 'live' object (0 = none)")
+    ap.add_argument("--live-steps", type=int, default=None,
+                    help="live sweeps timed after the K steps for the 'live' object (default: 5 on one GPU, 0 on several; 0 = none)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks all on cuda:0 with the gloo backend (host-staged all-reduce): exercises the "
                          "sharding logic on a 1-GPU box; not a performance number")
@@ -227,26 +228,33 @@ def main():
     # order-independent fingerprint of the final global counts: must not depend on the number of shards
     nk_fp = [int(np.asarray(s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]
     out["final_nk_fingerprint"] = nk_fp
+    if args.live_steps is None:
+        args.live_steps = 5 if world == 1 else 0
     if not args.live and args.live_steps > 0:
         # The other update mode, timed after (and outside) the K steps above: MVHDP_SWEEP_LIVE, the reference's own
         # discipline.  profiles/r02_ll_curves.md: a live sweep is worth one sweep of the CPU reference (0.93-1.0 sweeps
         # needed per reference sweep on C3), a deferred sweep 0.4-0.7 of one -- quote tokens/s with that in mind.
         lf = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(args.live_segments)
-        sweep_all_reduce(shard, args.warmup + args.steps, args.seed, flags=lf)
-        barrier()
-        t1 = time.perf_counter()
-        for k in range(args.live_steps):
-            sweep_all_reduce(shard, args.warmup + args.steps + 1 + k, args.seed, flags=lf)
-        barrier()
-        dl = time.perf_counter() - t1
-        if world > 1:
-            tl = torch.tensor([dl], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
-            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-            dl = float(tl.item())
-        out["live"] = {"value": total_tokens * args.live_steps / dl, "unit": "tokens/s", "steps": args.live_steps,
-                       "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
-                       "note": "MVHDP_SWEEP_LIVE (atomics on the shared n_wk, UPD:197-207), timed after the K deferred steps; "
-                               "sweep-for-sweep equal to the CPU reference (profiles/r02_ll_curves.md), not bit-reproducible"}
+        try:
+            sweep_all_reduce(shard, args.warmup + args.steps, args.seed, flags=lf)
+            barrier()
+            t1 = time.perf_counter()
+            for k in range(args.live_steps):
+                sweep_all_reduce(shard, args.warmup + args.steps + 1 + k, args.seed, flags=lf)
+            barrier()
+            dl = time.perf_counter() - t1
+            if world > 1:
+                tl = torch.tensor([dl], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+                dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+                dl = float(tl.item())
+        except Exception as e:                      # the secondary measurement must never cost the primary one
+            out["live"] = {"error": repr(e)}
+            dl = None
+        if dl is not None:
+            out["live"] = {"value": total_tokens * args.live_steps / dl, "unit": "tokens/s", "steps": args.live_steps,
+                           "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
+                           "note": "MVHDP_SWEEP_LIVE (atomics on the shared n_wk, UPD:197-207), timed after the K deferred steps; "
+                                   "sweep-for-sweep equal to the CPU reference (profiles/r02_ll_curves.md), not bit-reproducible"}
     shard.close()
     s.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
