@@ -107,7 +107,7 @@ class GpuShard:
 
     # ---- pipelined exchange: chunked all-reduce overlapped with apply + F+tree rebuild of the chunk's rows ----
     def can_pipeline(self):
-        return self.stream is not None and not self.host_staged
+        return self.stream is not None or self.host_staged
 
     def row_chunks(self, n_chunks):
         """[(row_begin, row_end)] covering the n_wk rows of every view, and the element offset of the n_k part."""
@@ -239,6 +239,32 @@ def _sweep_pipelined(shard, sweep_idx, seed, group, flags, timings, t0):
     chunks, nk_off = shard.row_chunks(PIPELINE_CHUNKS)
     K = shard.s.K
     ev = None
+    if shard.host_staged:
+        # gloo rehearsal on one GPU: the same sequence of collectives and row-range updates, each chunk staged through
+        # the host (no overlap to measure; what it exercises is that every rank issues the same chunks in the same order)
+        torch.cuda.synchronize(shard.device)
+        t = shard._delta_dev
+        pieces = [(nk_off, t.numel())] + [(r0 * K, r1 * K) for r0, r1 in chunks]
+        for i, (a, b) in enumerate(pieces):
+            h = t[a:b].cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t[a:b].copy_(h)
+            torch.cuda.synchronize(shard.device)
+            if i == 0:
+                shard.s.apply_delta_begin()
+            else:
+                shard.s.apply_delta_rows(*chunks[i - 1])
+        topic, modality = st.activated_topic, st.activated_modality
+        if need_key:
+            key = torch.tensor([st.activation_key], dtype=torch.int64)
+            dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
+            topic, modality = decode_activation(int(key.item()))
+        shard.s.apply_delta_end(topic, modality)
+        if timings is not None:
+            timings["sweep_call"] = timings.get("sweep_call", 0.0) + (t1 - t0) * 1e3
+            timings["sweep_kernel"] = timings.get("sweep_kernel", 0.0) + st.sweep_kernel_ms
+            timings["n"] = timings.get("n", 0) + 1
+        return st
     with shard.on_stream():
         if timings is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
