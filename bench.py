@@ -255,6 +255,27 @@ def main():
                            "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
                            "note": "MVHDP_SWEEP_LIVE (atomics on the shared n_wk, UPD:197-207), timed after the K deferred steps; "
                                    "sweep-for-sweep equal to the CPU reference (profiles/r02_ll_curves.md), not bit-reproducible"}
+    if world == 1 and not args.live and args.live_steps > 0:
+        # the deterministic middle ground, single GPU only: a deferred sweep in 8 interleaved segments with the deltas
+        # applied in between (MVHDP_SWEEP_SEGMENT_APPLY): bit-exact against the oracle like the plain deferred sweep and
+        # 0.94-1.07 sweeps per sweep of the CPU reference (profiles/r02_ll_curves.md)
+        try:
+            from mvtopicmodel_amd.native import SWEEP_SEGMENT_APPLY
+            sf = SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(8)
+            base = args.warmup + args.steps + args.live_steps + 1
+            s.sweep(base, args.seed, flags=sf)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(args.live_steps):
+                s.sweep(base + 1 + k, args.seed, flags=sf)
+            torch.cuda.synchronize()
+            dsg = time.perf_counter() - t1
+            out["segmented"] = {"value": total_tokens * args.live_steps / dsg, "unit": "tokens/s", "steps": args.live_steps,
+                                "ms_per_step": dsg / args.live_steps * 1e3, "segments": 8,
+                                "note": "MVHDP_SWEEP_SEGMENT_APPLY: deferred sweep in 8 segments, deltas applied and trees rebuilt in "
+                                        "between; deterministic (oracle-checked), about one reference sweep per sweep"}
+        except Exception as e:
+            out["segmented"] = {"error": repr(e)}
     shard.close()
     s.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -132,6 +132,15 @@ typedef struct {
 #define MVHDP_SWEEP_LIVE        0x20u
 #define MVHDP_SWEEP_LIVE_SEGMENTS(n) (((uint32_t)(n) & 0xffu) << 16)
 
+/* A deferred sweep cut into MVHDP_SWEEP_LIVE_SEGMENTS(n) segments WITH the updater catching up in between: every
+ * segment is a snapshot sweep over its entities (trees rebuilt from the current counts, deltas collected), then its deltas
+ * are applied before the next segment starts.  Bit-reproducible like the plain deferred sweep (the oracle follows it
+ * segment by segment), and statistically between the deferred and the live sweep: a token sees counts that are at most
+ * one segment old.  Single handle only (not combinable with NO_APPLY, LIVE or FROZEN); a topic activation takes effect
+ * at the end of the sweep.  The segments are the interleaved ones of the live sweep: positions s, s+n, s+2n, ... of the
+ * entities ordered by decreasing token count (ties by entity index). */
+#define MVHDP_SWEEP_SEGMENT_APPLY 0x40u
+
 /* device buffers a host may hand to a collective (RCCL through torch.distributed or directly) */
 typedef enum {
     MVHDP_BUF_COUNTS = 0,  /* int32 [sumV*K + M*K]: n_wk rows of every view, then n_k */

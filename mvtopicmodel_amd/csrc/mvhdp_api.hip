@@ -655,8 +655,11 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     if (flags & MVHDP_SWEEP_FROZEN) flags |= MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY;   // nut == 0: the model is read-only
     if ((flags & MVHDP_SWEEP_REUSE_TREES) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES / FROZEN without trees");
     if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL | MVHDP_SWEEP_FROZEN |
-                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff))) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff) | MVHDP_SWEEP_SEGMENT_APPLY)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
     const bool live = (flags & MVHDP_SWEEP_LIVE) != 0;
+    const bool seg_apply = (flags & MVHDP_SWEEP_SEGMENT_APPLY) != 0;
+    if (seg_apply && (flags & (MVHDP_SWEEP_LIVE | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_REUSE_TREES)))
+        FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: SEGMENT_APPLY excludes LIVE, NO_APPLY, FROZEN and REUSE_TREES");
     if (live && (flags & MVHDP_SWEEP_FROZEN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: LIVE and FROZEN exclude each other");
     if (h->rows_applied >= 0) FAIL(h, MVHDP_ERR_STATE, "sweep: an mvhdp_apply_delta_begin bracket is open (call mvhdp_apply_delta_end)");
     if (h->delta_pending && !(flags & MVHDP_SWEEP_FROZEN))
@@ -665,7 +668,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     // from the live counts before each
     // (a deferred sweep accepts a segment count too: same integers as one segment, the trees being those of the snapshot)
     int nseg = (int)((flags >> 16) & 0xffu);
-    if (nseg == 0) nseg = live ? 4 : 1;
+    if (nseg == 0) nseg = (live || seg_apply) ? 4 : 1;
     if ((int64_t)nseg > mm.D) nseg = (int)std::max<int64_t>(1, mm.D);
     const int K = mm.K, M = mm.M;
     HIPC(h, hipSetDevice(h->device));
@@ -887,7 +890,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         auto share = [&](int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
         const int64_t n_seg = share(mm.D);
         if (seg > 0) {
-            if (live && !(flags & MVHDP_SWEEP_REUSE_TREES)) rebuild_trees();             // from the live counts
+            if ((live && !(flags & MVHDP_SWEEP_REUSE_TREES)) || seg_apply) rebuild_trees();   // from the live / just-updated counts
             step(hipMemsetAsync(h->d_ovf_meta, 0, 2 * sizeof(unsigned int), s));         // overflow counts of passes 1, 2
             step(hipMemsetAsync(h->d_ovf_meta + ovf_word[2], 0, sizeof(unsigned int), s));
             step(hipMemsetAsync(class_counts, 0, MVHDP_N_CLASSES * sizeof(unsigned int), s));
@@ -988,6 +991,8 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             sg.wave_bytes = gen.wave_bytes; sg.waves_per_block = gen.wpb;
             step(mvhdp_launch_sweep(mk, sg, blocks_for(n_seg, gen), debug, s));
         }
+        // segmented deferred sweep: the updater catches up before the next segment (counts += delta, delta = 0)
+        if (seg_apply) step(mvhdp_launch_apply_delta(mm, h->d_stats, s));
     }
     if (live) {
         if (flags & MVHDP_SWEEP_NO_APPLY) step(mvhdp_launch_live_helper(mm, 1, h->d_stats, s));   // delta = after - before, counts = snapshot
@@ -1036,9 +1041,10 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         // nothing was queued (WRK:587): the delta buffer is untouched
     } else if (flags & MVHDP_SWEEP_NO_APPLY) {
         h->delta_pending = true;
-    } else if (live) {
+    } else if (live || seg_apply) {
         // the counts are already updated; what is left of the updater's work is the topic activation
         h->have_trees = false;
+        if (seg_apply) h->delta_clean = true;                        // apply_delta_kernel zeroed what it added
         ret = apply_activation(h, st.activated_topic, st.activated_modality);
         if (ret == MVHDP_OK && hs[ST_NEGATIVE]) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
     } else {

@@ -19,6 +19,7 @@ SWEEP_EXACT_CHAIN = 0x4
 SWEEP_GENERIC_KERNEL = 0x8
 SWEEP_FROZEN = 0x10
 SWEEP_LIVE = 0x20
+SWEEP_SEGMENT_APPLY = 0x40
 
 
 def SWEEP_LIVE_SEGMENTS(n):

@@ -89,6 +89,8 @@ def lib():
     L.orc_draw_p_philox.argtypes = [vp, u64, u32, i64, vp]
     L.orc_sweep.argtypes = [vp, u32, u64, i64, vp, u32, P(Stats), vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.orc_sweep.restype = C.c_int
+    L.orc_sweep_list.argtypes = [vp, u32, u64, i64, vp, u32, P(Stats), vp, vp, vp, i64]
+    L.orc_sweep_list.restype = C.c_int
     L.orc_apply_delta.argtypes = [vp, vp, vp, i32, i32]
     L.orc_log_gamma_stirling.argtypes = [dbl]; L.orc_log_gamma_stirling.restype = dbl
     L.orc_mallet_digamma.argtypes = [dbl]; L.orc_mallet_digamma.restype = dbl
@@ -256,6 +258,20 @@ class Oracle:
             raise RuntimeError(f"orc_sweep rc={rc}")
         return dict(stats=st.as_dict(), delta_nwk=dn, delta_nk=dk,
                     dbg=[d[: self.N[m]] for m, d in enumerate(dbg)] if dbg else None, trace=tout)
+
+    def sweep_list(self, sweep_idx, seed, docs, p=None, flags=0, doc_id_base=0, want_delta=False):
+        """Deferred sweep over the listed entities only (local indices, list order)."""
+        st = Stats()
+        docs = np.ascontiguousarray(docs, dtype=np.int64)
+        dn = np.zeros((sum(self.V), self.K), dtype=np.int32) if want_delta else None
+        dk = np.zeros((self.M, self.K), dtype=np.int32) if want_delta else None
+        if p is not None:
+            p = np.ascontiguousarray(p, dtype=np.float64)
+        rc = self.L.orc_sweep_list(self.h, int(sweep_idx), int(seed), int(doc_id_base), _ptr(p), int(flags), C.byref(st),
+                                   _ptr(dn), _ptr(dk), _ptr(docs), len(docs))
+        if rc:
+            raise RuntimeError(f"orc_sweep_list rc={rc}")
+        return dict(stats=st.as_dict(), delta_nwk=dn, delta_nk=dk)
 
     def apply_delta(self, dn, dk, act_topic=-1, act_modality=-1):
         dn = np.ascontiguousarray(dn, dtype=np.int32)

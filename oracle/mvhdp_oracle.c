@@ -756,12 +756,43 @@ static void apply_deltas(orc_model* o, const delta_vec* dv, orc_stats* st, int32
     (void)M;
 }
 
+static int sweep_impl(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base,
+                      const double* p_in, uint32_t flags, orc_stats* st,
+                      int32_t* delta_nwk, int32_t* delta_nk,
+                      double* const* tok_dbg,
+                      int n_trace, const int64_t* trace_doc, const int32_t* trace_view,
+                      const int32_t* trace_pos, double* trace_out,
+                      const int64_t* doc_list, int64_t n_list);
+
 int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base,
               const double* p_in, uint32_t flags, orc_stats* st,
               int32_t* delta_nwk, int32_t* delta_nk,
               double* const* tok_dbg,
               int n_trace, const int64_t* trace_doc, const int32_t* trace_view,
               const int32_t* trace_pos, double* trace_out)
+{
+    return sweep_impl(o, sweep_idx, seed, doc_id_base, p_in, flags, st, delta_nwk, delta_nk, tok_dbg,
+                      n_trace, trace_doc, trace_view, trace_pos, trace_out, NULL, 0);
+}
+
+/* The same deferred sweep over a LIST of entities only (local indices, visited in list order): one segment of a
+ * segmented sweep (MVHDP_SWEEP_SEGMENT_APPLY: the worker threads' slices PTM:1051-1098 taken one after the other, the
+ * updater catching up in between).  Entities outside the list are left untouched. */
+int orc_sweep_list(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base,
+                   const double* p_in, uint32_t flags, orc_stats* st, int32_t* delta_nwk, int32_t* delta_nk,
+                   const int64_t* doc_list, int64_t n_list)
+{
+    return sweep_impl(o, sweep_idx, seed, doc_id_base, p_in, flags, st, delta_nwk, delta_nk, NULL,
+                      0, NULL, NULL, NULL, NULL, doc_list ? doc_list : (const int64_t*)"", n_list);
+}
+
+static int sweep_impl(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base,
+                      const double* p_in, uint32_t flags, orc_stats* st,
+                      int32_t* delta_nwk, int32_t* delta_nk,
+                      double* const* tok_dbg,
+                      int n_trace, const int64_t* trace_doc, const int32_t* trace_view,
+                      const int32_t* trace_pos, double* trace_out,
+                      const int64_t* doc_list, int64_t n_list)
 {
     const int K = o->K, M = o->M;
     orc_stats local; memset(&local, 0, sizeof local);
@@ -788,7 +819,10 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
     double* totalMassOtherModalities = (double*)malloc((size_t)K * sizeof(double));
     delta_vec dv = { NULL, 0, 0 };
 
-    for (int64_t d = 0; d < o->D; d++) {
+    const int64_t n_visit = doc_list ? n_list : o->D;
+    for (int64_t q = 0; q < n_visit; q++) {
+        const int64_t d = doc_list ? doc_list[q] : q;
+        if (d < 0 || d >= o->D) continue;
         memset(localTopicIndex, 0, (size_t)(K + 1) * sizeof(int32_t));
         topicDocWordMasses[0] = 0;
         int rc = sample_one_doc(o, d, doc_id_base + d, sweep_idx, seed, p + (size_t)d * M * M,

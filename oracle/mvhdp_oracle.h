@@ -136,6 +136,11 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
               int n_trace, const int64_t* trace_doc, const int32_t* trace_view,
               const int32_t* trace_pos, double* trace_out);
 
+/* The same deferred sweep over a list of entities only (local indices, list order): one segment of a segmented sweep. */
+int orc_sweep_list(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base,
+                   const double* p, uint32_t flags, orc_stats* st, int32_t* delta_nwk, int32_t* delta_nk,
+                   const int64_t* doc_list, int64_t n_list);
+
 /* Apply externally reduced deltas (multi-rank tests): n_wk += d, n_k += d, then the topic
  * activation (UPD:263-270) decided by the caller (act_topic < 0: none). */
 void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk,

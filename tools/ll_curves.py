@@ -73,7 +73,7 @@ def run_cpu(args):
 def run_gpu(args):
     from mvtopicmodel_amd import NativeSampler
     from mvtopicmodel_amd.host import init_assignments
-    from mvtopicmodel_amd.native import SWEEP_LIVE, SWEEP_LIVE_SEGMENTS
+    from mvtopicmodel_amd.native import SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
     c, hy, K_init = load(args.workload, args.docs)
     z0 = init_assignments(K_init, c.doc_off, seed=1)
     ntok = np.array([int(c.doc_off[m][-1]) for m in range(c.M)], dtype=np.float64)
@@ -81,6 +81,10 @@ def run_gpu(args):
     modes = [("gpu deferred (snapshot sweep)", 0)]
     for n in args.live_segments:
         modes.append((f"gpu live, {n} tree rebuild(s) per sweep", SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(n)))
+    for n in args.segmented:
+        modes.append((f"gpu deferred in {n} segments, applied in between", SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(n)))
+    if args.only:
+        modes = [mo for mo in modes if any(o in mo[0] for o in args.only)]
     for name, flags in modes:
         s = NativeSampler(c.K, c.V)
         for m in range(c.M):
@@ -166,6 +170,8 @@ def main():
             p.add_argument("--threads", type=int, default=8)
         else:
             p.add_argument("--live-segments", type=int, nargs="*", default=[1, 4, 16])
+            p.add_argument("--segmented", type=int, nargs="*", default=[], help="also run SEGMENT_APPLY sweeps with these segment counts")
+            p.add_argument("--only", nargs="*", default=[], help="keep only the modes whose name contains one of these strings")
     p = sub.add_parser("table")
     p.add_argument("files", nargs="+")
     args = ap.parse_args()
