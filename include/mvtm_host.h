@@ -63,7 +63,8 @@ int   mvtm_model_print_document_topics(void* model, const char* filename, double
                                        const double* discr_weight, const double* p_mean);
 int   mvtm_java_double_to_string(double v, char* out, int cap);
 void* mvtm_model_native_handle(void* model);
-/* update discipline of estimate()'s sweeps: 0 = deferred (parity contract), 1 = MVHDP_SWEEP_LIVE (UPD:197-218) */
+/* update discipline of estimate()'s sweeps: 0 = deferred (parity contract), 1 = MVHDP_SWEEP_LIVE (UPD:197-218),
+ * 2 = MVHDP_SWEEP_SEGMENT_APPLY (deterministic, segments applied in between); second argument = segments (0 = default) */
 int   mvtm_model_set_live_updates(void* model, int live, int tree_rebuilds_per_sweep);
 /* optimizeGamma's per-entity Bernoulli / Beta sums (PTM:2415-2433): 0 = sequential host loop (the reference's), 1 = device kernel */
 int   mvtm_model_set_device_gamma_statistics(void* model, int on);

@@ -698,7 +698,8 @@ void FastQMVWVParallelTopicModel::estimate()
         }
         pushHyper();
         mvhdp_sweep_stats st;
-        const uint32_t sweepFlags = liveUpdates_ ? (MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(liveSegments_)) : 0u;
+        const uint32_t sweepFlags = liveUpdates_ ? (MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(liveSegments_))
+                                  : segmentedUpdates_ ? (MVHDP_SWEEP_SEGMENT_APPLY | MVHDP_SWEEP_LIVE_SEGMENTS(liveSegments_)) : 0u;
         check(mvhdp_sweep(h_, (uint32_t)iteration, seed, sweepFlags, nullptr, nullptr, &st), "mvhdp_sweep");  // PTM:1213-1239
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         iterationLog.push_back({iteration, ms, st});
@@ -745,7 +746,9 @@ int mvtm_model_set_device_gamma_statistics(void* p, int on)
 
 int mvtm_model_set_live_updates(void* p, int live, int tree_rebuilds_per_sweep)
 {
-    ((FastQMVWVParallelTopicModel*)p)->setLiveUpdates(live != 0, tree_rebuilds_per_sweep);
+    auto* m = (FastQMVWVParallelTopicModel*)p;
+    if (live == 2) m->setSegmentedUpdates(true, tree_rebuilds_per_sweep);        // 2 = MVHDP_SWEEP_SEGMENT_APPLY
+    else { m->setSegmentedUpdates(false); m->setLiveUpdates(live != 0, tree_rebuilds_per_sweep); }
     return 0;
 }
 

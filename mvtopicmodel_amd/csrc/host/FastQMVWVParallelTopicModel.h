@@ -81,7 +81,9 @@ public:
     void setDocIdBase(int64_t base) { docIdBase_ = base; }      // document shards: global id of entity 0
     // Update discipline of the sweeps estimate() runs: false = deferred (snapshot sweep, bit-reproducible: the parity
     // contract), true = MVHDP_SWEEP_LIVE (the updater threads' own discipline, UPD:197-218; profiles/r02_ll_curves.md)
-    void setLiveUpdates(bool live, int treeRebuildsPerSweep = 0) { liveUpdates_ = live; liveSegments_ = treeRebuildsPerSweep; }
+    void setLiveUpdates(bool live, int treeRebuildsPerSweep = 0) { liveUpdates_ = live; liveSegments_ = treeRebuildsPerSweep; if (live) segmentedUpdates_ = false; }
+    // the deterministic middle ground: MVHDP_SWEEP_SEGMENT_APPLY with this many segments (0 = library default)
+    void setSegmentedUpdates(bool on, int segments = 0) { segmentedUpdates_ = on; liveSegments_ = segments; if (on) liveUpdates_ = false; }
     // optimizeGamma's document-level sums (PTM:2415-2433): false = the reference's sequential host loop over every entity,
     // ten rounds per view (reproducible against the Python oracle under an injected stream; 1.9 s per call at C4),
     // true = mvhdp_gamma_doc_statistics on the device (the same random variables in distribution; milliseconds)
@@ -193,7 +195,7 @@ private:
     mvhdp_handle h_ = nullptr;
     int device_ = 0;
     int64_t docIdBase_ = 0;
-    bool liveUpdates_ = false;
+    bool liveUpdates_ = false, segmentedUpdates_ = false;
     int liveSegments_ = 0;
     bool deviceGammaStatistics_ = false;
     uint32_t gammaCalls_ = 0;

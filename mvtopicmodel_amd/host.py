@@ -196,6 +196,10 @@ class FastQMVWVParallelTopicModel:
         """False: deferred sweeps (the parity contract); True: MVHDP_SWEEP_LIVE, the reference's update discipline."""
         self.L.mvtm_model_set_live_updates(self.p, int(bool(live)), int(tree_rebuilds_per_sweep))
 
+    def setSegmentedUpdates(self, segments=0):
+        """MVHDP_SWEEP_SEGMENT_APPLY: deterministic sweeps in `segments` segments with the deltas applied in between."""
+        self.L.mvtm_model_set_live_updates(self.p, 2, int(segments))
+
     def setDeviceGammaStatistics(self, on):
         """optimizeGamma's per-entity sums on the device instead of the reference's sequential host loop."""
         self.L.mvtm_model_set_device_gamma_statistics(self.p, int(bool(on)))

@@ -745,13 +745,16 @@ static void apply_deltas(orc_model* o, const delta_vec* dv, orc_stats* st, int32
         if (apply) { o->nwk[row + dl->newT]++; o->nk[(size_t)dl->mod * K + dl->newT]++; }       /* UPD:207,218 */
         if (delta_nwk) delta_nwk[row + dl->newT]++;
         if (delta_nk) delta_nk[(size_t)dl->mod * K + dl->newT]++;
-        if (o->inactive[dl->newT]) {                                                              /* UPD:263-270 */
-            if (st->activated_topic < 0) { st->activated_topic = dl->newT; st->activated_modality = dl->mod; st->activation_key = dl->key; }
-            if (apply) {
-                o->inactive[dl->newT] = 0;
-                o->alpha[(size_t)dl->mod * (K + 1) + dl->newT] = o->alpha[(size_t)dl->mod * (K + 1) + K];
-            }
+        /* UPD:263-270: the delta that activates a topic is the FIRST one in (global entity, view, position) order, i.e.
+         * the one with the smallest key.  A whole sweep visits the entities in that order, so "first queued" and
+         * "smallest key" coincide; a list sweep (orc_sweep_list) visits them in list order, and the key decides. */
+        if (o->inactive[dl->newT] && dl->key < st->activation_key) {
+            st->activated_topic = dl->newT; st->activated_modality = dl->mod; st->activation_key = dl->key;
         }
+    }
+    if (apply && st->activated_topic >= 0) {
+        o->inactive[st->activated_topic] = 0;
+        o->alpha[(size_t)st->activated_modality * (K + 1) + st->activated_topic] = o->alpha[(size_t)st->activated_modality * (K + 1) + K];
     }
     (void)M;
 }

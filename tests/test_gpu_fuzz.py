@@ -168,3 +168,34 @@ def test_random_shapes_live(seed, monkeypatch):
             ref = np.zeros_like(nwk); np.add.at(ref, (c.tokens[m][ok], z[ok]), 1)
             assert nwk.min() >= 0 and np.array_equal(ref, nwk) and np.array_equal(ref.sum(axis=0), nk)
     s.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MVHDP_FUZZ_CASES", "40")) // 2))
+def test_random_shapes_segmented(seed, monkeypatch):
+    """MVHDP_SWEEP_SEGMENT_APPLY on random shapes: deterministic, so every integer must equal the oracle's, which follows
+    the sweep segment by segment (tests/test_gpu_segmented.py)."""
+    from mvtopicmodel_amd.native import SWEEP_SEGMENT_APPLY
+    from tests.test_gpu_segmented import oracle_segmented_sweep
+    c, hy, inactive, flags, env, rng = _case(13000 + seed)
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    for m in range(c.M):
+        if inactive is not None:
+            z0[m][np.isin(z0[m], np.flatnonzero(inactive))] = int(np.flatnonzero(inactive == 0)[0])
+        if len(z0[m]) and rng.rand() < 0.3:
+            z0[m][rng.rand(len(z0[m])) < 0.1] = -1
+        o.set_assignments(m, z0[m])
+    o.build_counts()
+    s = make_native(c, hy, z0)
+    nseg = int(rng.choice([2, 3, 4, 9]))
+    for it in range(3):
+        so, best = oracle_segmented_sweep(o, c, it, 31 + seed, nseg)
+        st = s.sweep(it, 31 + seed, flags=(flags & 0xFFFF) | SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(nseg))
+        assert (st.tokens, st.changed, st.new_mass_cnt, st.topic_doc_mass_cnt, st.word_ftree_mass_cnt) == \
+               (so["tokens"], so["changed"], so["new_mass_cnt"], so["topic_doc_mass_cnt"], so["word_ftree_mass_cnt"])
+        assert (st.activated_topic, st.activated_modality) == (best[1], best[2])
+        assert_same_state(o, s, c.M)
+    s.close()
