@@ -15,7 +15,6 @@ sweep's own statistics read-back is the only synchronisation per sweep).
 """
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

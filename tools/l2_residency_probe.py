@@ -1,4 +1,4 @@
-import sys, json, time
+import sys
 sys.path.insert(0, '.')
 import numpy as np
 from mvtopicmodel_amd import NativeSampler, synth

@@ -20,7 +20,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 import numpy as np
 
