@@ -21,6 +21,7 @@ public final class NativeSampler implements AutoCloseable {
     public static final int SWEEP_EXACT_CHAIN = 0x4;
     public static final int SWEEP_FROZEN = 0x10;       // the inferencer's call (nst = 1, nut = 0)
     public static final int SWEEP_LIVE = 0x20;         // the updater threads' own discipline: atomics on the shared counts
+    public static final int SWEEP_SEGMENT_APPLY = 0x40; // deterministic: segments sampled one after the other, deltas applied in between
     public static int sweepLiveSegments(int n) { return (n & 0xff) << 16; }
 
     /** What one sweep reports: the three branch counters of the worker plus bookkeeping. */
