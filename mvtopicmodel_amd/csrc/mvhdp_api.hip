@@ -65,6 +65,13 @@ struct mvhdp_ctx {
     int64_t* d_carry[MVHDP_MAXM]{};          // doc_topic_proportions: per view, the entity whose view-m counts score entity d (lazily built)
     unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class, from the last sweep (or the probe)
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
+    // 1-round or 2-round primary variant?  Measured, not tabulated: when the histogram first allows the 1-round variant with an
+    // optimistic overflow pass, it runs for ONE sweep; if its kernel time per token is not better than the 2-round variant's of
+    // the sweep before, the choice goes back to 2 rounds and is not tried again for 20 sweeps.
+    int last_primary = 0;                    // primary variant of the last plain sweep (0: none)
+    double last_ns_per_token = 0;            //   and its sweep-kernel time per token
+    double two_round_ns_per_token = 0;       // the 2-round variant's time per token just before a 1-round trial
+    long long sweeps_done = 0, one_round_banned_until = 0;
     size_t lds_attr_set = 0;
 };
 
@@ -116,7 +123,10 @@ static bool is_live(mvhdp_ctx* h)
 static int rmax_from_hist(const unsigned long long* hist)
 {
     static const int variants[5] = {1, 2, 4, 8, 16};
-    static const double cost[5] = {0.85, 1.0, 1.45, 2.6, 4.5};
+    // The 1-round variant against the 2-round one is config-dependent (12 % faster on C3, K = 200; 0.6 % SLOWER on C4,
+    // K = 400, where its seventh wave per SIMD buys nothing): the table only proposes it, the sweep measures it
+    // (try_one_round below).
+    static const double cost[5] = {0.95, 1.0, 1.45, 2.6, 4.5};
     const double cost_generic = 6.0;
     double tot = 0;
     for (int i = 0; i < MVHDP_HIST_BINS; i++) tot += (double)hist[i];
@@ -1010,6 +1020,13 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         // between sweeps); entities counted twice (overflow re-run) only make the choice more conservative
         std::copy(ovf + 1, ovf + 1 + MVHDP_HIST_BINS, h->last_hist);
         h->rmax_hint = rmax_from_hist(ovf + 1);
+        if (h->rmax_hint == 1) {
+            // proposed by the table: taken only if almost nothing would overflow it (no classify pass for a 1-round primary)
+            // and if it is not banned by an earlier measurement
+            double tot = 0, beyond = 0;
+            for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)ovf[1 + b]; if (b >= 1) beyond += (double)ovf[1 + b]; }
+            if (beyond > 0.005 * tot || h->sweeps_done < h->one_round_banned_until) h->rmax_hint = 2;
+        }
     }
     if (e != hipSuccess) { cleanup(); HIPC(h, e); }
     if (getenv("MVHDP_DEBUG") && hs[ST_T_TOTAL])
@@ -1056,6 +1073,20 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     hipEventElapsedTime(&ms_k, h->ev[1], h->ev[2]);
     hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
     st.sweep_kernel_ms = ms_k; st.total_ms = ms_t;
+    // the 1-round trial (see mvhdp_ctx::last_primary): plain full sweeps only, so that the two times are comparable
+    h->sweeps_done++;
+    const bool plain = fast && !classified && nseg == 1 && !debug && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) &&
+                       !getenv("MVHDP_FORCE_RMAX") && st.tokens > 0;
+    if (plain) {
+        const double ns = (double)ms_k * 1e6 / (double)st.tokens;
+        if (rmax == 1 && h->last_primary == 2 && h->last_ns_per_token > 0) h->two_round_ns_per_token = h->last_ns_per_token;
+        if (rmax == 1 && h->two_round_ns_per_token > 0 && ns > 0.995 * h->two_round_ns_per_token) {
+            if (h->rmax_hint == 1) h->rmax_hint = 2;
+            h->one_round_banned_until = h->sweeps_done + 20;
+            h->two_round_ns_per_token = 0;
+        } else if (rmax == 1) h->two_round_ns_per_token = 0;         // the trial is over: the 1-round variant stays
+        h->last_primary = rmax; h->last_ns_per_token = ns;
+    } else h->last_primary = 0;
     if (stats) *stats = st;
     return ret;
 }
