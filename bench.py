@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--live-segments", type=int, default=0, help="F+tree rebuilds per live sweep (0 = library default)")
     ap.add_argument("--live-steps", type=int, default=None,
                     help="live sweeps timed after the K steps for the 'live' object (default: 5 on one GPU, 0 on several; 0 = none)")
+    ap.add_argument("--plain-exchange", action="store_true", help="N>1: one all-reduce then apply, instead of the chunked pipeline")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks all on cuda:0 with the gloo backend (host-staged all-reduce): exercises the "
                          "sharding logic on a 1-GPU box; not a performance number")
@@ -161,15 +162,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the exchange step: pipelined (chunked all-reduce overlapped with apply + tree rebuild) unless it fails in the warm-up,
+    # in which case every rank falls back to the plain sequence (sweep -> one all-reduce -> apply) and the line says so
+    exchange = {"pipeline": not args.plain_exchange}
     for w in range(args.warmup):
-        sweep_all_reduce(shard, w, args.seed, flags=sweep_flags)
+        try:
+            sweep_all_reduce(shard, w, args.seed, flags=sweep_flags, pipeline=exchange["pipeline"])
+        except Exception as e:
+            if not exchange["pipeline"] or world == 1:
+                raise
+            exchange = {"pipeline": False, "fallback_reason": repr(e)}
+            s.synchronize()
+            sweep_all_reduce(shard, w, args.seed, flags=sweep_flags, pipeline=False)
     barrier()
     kernel_ms = []
     phases = {}
     t0 = time.perf_counter()
     last = None
     for k in range(args.steps):
-        last = sweep_all_reduce(shard, args.warmup + k, args.seed, flags=sweep_flags, timings=phases)
+        last = sweep_all_reduce(shard, args.warmup + k, args.seed, flags=sweep_flags, timings=phases, pipeline=exchange["pipeline"])
         kernel_ms.append(last.sweep_kernel_ms)
     barrier()
     dt = time.perf_counter() - t0
@@ -223,6 +234,9 @@ def main():
         # sweep call (view weights, F+tree rebuild, kernels, statistics read-back), of which device time in the sweep
         # kernels; the collective (device time by events on the shared stream); apply (waits for the collective)
         "phase_ms": {k: v / max(1, phases.get("n", 1)) for k, v in phases.items() if k != "n"},
+        "exchange": ("none (one shard)" if world == 1 else
+                     ("pipelined: %d row-range all-reduces overlapped with apply + tree rebuild" % 4 if exchange["pipeline"] else
+                      "plain: one all-reduce, then apply" + (" (pipeline failed in warm-up: %s)" % exchange["fallback_reason"] if "fallback_reason" in exchange else ""))),
         "update_mode": ("live, %d tree rebuilds per sweep" % (args.live_segments or 4)) if args.live else "deferred (snapshot sweep, bit-reproducible)",
     }
     # order-independent fingerprint of the final global counts: must not depend on the number of shards
