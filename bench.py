@@ -172,7 +172,11 @@ def main():
             if not exchange["pipeline"] or world == 1:
                 raise
             exchange = {"pipeline": False, "fallback_reason": repr(e)}
-            s.synchronize()
+            for cleanup in (lambda: s.apply_delta_end(-1, -1), lambda: s.apply_delta(-1, -1), s.synchronize):
+                try:                                 # close a half-open apply bracket, drop pending deltas
+                    cleanup()
+                except Exception:
+                    pass
             sweep_all_reduce(shard, w, args.seed, flags=sweep_flags, pipeline=False)
     barrier()
     kernel_ms = []
