@@ -199,19 +199,20 @@ def main():
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     bpt = algorithmic_bytes_per_token(K)
     achieved = local_tokens * bpt / avg_kernel_s / 1e9
-    # HBM-side traffic of the same kernel from the committed PMC passes (profiles/profile_c4.sh:
-    # separate FETCH_SIZE / WRITE_SIZE runs); bytes per token there x tokens per launch here.
+    # HBM-side traffic of the same kernels from the committed PMC passes (profiles/pmc_r02b.sh: separate FETCH_SIZE /
+    # TCC_EA0_RDREQ / WRITE_SIZE runs of this very command); bytes per token there x tokens per launch here.
     traffic = None
     traffic_note = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_pmc_summary.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02b_c4_pmc_summary.json")))
         if args.workload == "C4":
             bpt_meas = pm["fetch_bytes_per_token"] + pm["write_bytes_per_token"]
             traffic = local_tokens * bpt_meas / avg_kernel_s / 1e9
             traffic_note = (f"{bpt_meas:.0f} B/token = TCC_EA0_RDREQ x 128 B (= 2 x FETCH_SIZE: the gfx950 correction, calibrated "
                             "on this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits "
-                            "included; PMC passes of profiles/calib.sh on this workload, a rocprofv3 run of its own: the "
-                            "per-token figure is a constant of the kernel build, the rate is this run's")
+                            "included; PMC passes of profiles/pmc_r02b.sh over the 20 timed sweeps of `--steps 20 --warmup 5` "
+                            "(a rocprofv3 run of its own; the walk threshold of the chunk head moves during those sweeps, so the "
+                            "per-token figure belongs to that window), the rate is this run's")
     except Exception:
         pass
     out = {

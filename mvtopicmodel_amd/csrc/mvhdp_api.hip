@@ -72,6 +72,20 @@ struct mvhdp_ctx {
     double last_ns_per_token = 0;            //   and its sweep-kernel time per token
     double two_round_ns_per_token = 0;       // the 2-round variant's time per token just before a 1-round trial
     long long sweeps_done = 0, one_round_banned_until = 0;
+    // Walk threshold of the chunk head (SweepLaunch::walk_theta, in steps of 1/MVHDP_WALK_BINS): which tokens have their word tree
+    // walked up front.  It changes when the walk is done, never what is sampled, so it is steered by the clock: sweeps at the current
+    // threshold (A) alternate with sweeps a step away (B); B replaces A when its kernel time per token beats the mean of the A sweeps
+    // on either side (the chain's own drift cancels).  An upward step is as long as the last sweep's histogram of the tree-branch
+    // tokens' u1 says is nearly free (<= 0.4 % of the tokens more to walk on demand), a downward step is one bin.  A step that does
+    // not pay turns the search around; two in a row let it rest for a growing number of sweeps, and the first B sweep after a rest
+    // tries half the threshold (a slope too shallow for single steps to see, e.g. where the kernel is not bandwidth-bound and
+    // the best threshold is 0).  Views where most tokens take the tree branch anyway (walk_f >= 0.35) are always walked.
+    int walk_i = 0, walk_probe_i = 0, walk_b_i = 0, walk_phase = 0, walk_dir = 1, walk_fails = 0, walk_wait = 4, walk_cfg = -1, walk_maxj = 6;
+    bool walk_far = false;                   // the next B sweep after a rest tries half the threshold (slopes too shallow for single steps)
+    double walk_ns_a1 = 0.0, walk_ns_b = 0.0;
+    long long walk_idle_until = 0, walk_refresh_at = 0;
+    double walk_f[MVHDP_MAXM] = {-1, -1, -1, -1, -1, -1, -1, -1};   // tree-branch share per view in the last sweep (< 0: not known yet)
+    double walk_hist[MVHDP_WALK_BINS] = {0};  // tree-branch tokens of those views by u1 bin, as a share of all tokens (last sweep)
     size_t lds_attr_set = 0;
 };
 
@@ -698,8 +712,47 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     // memory side (measured on C3: 28 ms per sweep instead of 5.7), so tokensPerTopic becomes current at each
     // segment end -- together with the trees -- while n_wk is updated in place (UPD:197-207).
     sl.nk_global = ((size_t)M * K * sizeof(int) > 24 * 1024) ? 1 : 0;
-    sl.block_shared_bytes = (uint32_t)((((size_t)(sl.nk_global ? 0 : M * K) + MVHDP_HIST_BINS) * sizeof(int) + 15) & ~(size_t)15);
+    sl.block_shared_bytes = (uint32_t)((((size_t)(sl.nk_global ? 0 : M * K) + MVHDP_HIST_BINS + MVHDP_MAXM * MVHDP_VIEW_STATS) * sizeof(int) + 15) & ~(size_t)15);
     const bool debug = dbg != nullptr;
+    // walk thresholds of this sweep (see mvhdp_ctx::walk_i) and the kernel flavour that goes with them
+    const char* theta_env = getenv("MVHDP_WALK_THETA");         // diagnostics: "t0,t1,..." fixes the thresholds
+    auto walk_controlled = [&](int m) { return h->walk_f[m] >= 0.0 && h->walk_f[m] < 0.35; };
+    bool walk_any = false, walk_unknown = false;                 // (walk_f < 0: not measured yet)
+    for (int m = 0; m < M; m++) { walk_any = walk_any || walk_controlled(m); walk_unknown = walk_unknown || h->walk_f[m] < 0.0; }
+    if (theta_env) {
+        int m = 0;
+        for (const char* q = theta_env; *q && m < MVHDP_MAXM; m++) {
+            sl.walk_theta[m] = atof(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        for (; m < MVHDP_MAXM; m++) sl.walk_theta[m] = 0.0;
+        sl.walk = 1;
+    } else {
+        const int top = MVHDP_WALK_BINS * 17 / 20;               // thresholds up to 0.85
+        h->walk_probe_i = h->walk_i;
+        if (h->walk_phase == 1 && walk_any) {
+            if (h->walk_far && h->walk_i < 4) h->walk_far = false;
+            if (h->walk_far) h->walk_dir = -1;
+            if (h->walk_dir > 0 && h->walk_i >= top) h->walk_dir = -1;
+            if (h->walk_dir < 0 && h->walk_i <= 0) h->walk_dir = 1;
+            if (h->walk_dir > 0) {
+                int j = 1;
+                double extra = h->walk_hist[h->walk_i];
+                while (h->walk_i + j < top && j < h->walk_maxj && extra + h->walk_hist[h->walk_i + j] <= 0.004) { extra += h->walk_hist[h->walk_i + j]; j++; }
+                h->walk_probe_i = h->walk_i + j;
+            } else h->walk_probe_i = h->walk_far ? h->walk_i / 2 : h->walk_i - 1;
+        }
+        sl.walk = 0;
+        for (int m = 0; m < MVHDP_MAXM; m++) {
+            sl.walk_theta[m] = (m < M && walk_controlled(m)) ? (double)h->walk_probe_i / MVHDP_WALK_BINS : 0.0;
+            if (sl.walk_theta[m] > 0.0) sl.walk = 1;
+        }
+        // no view qualifies: look again every 16th sweep (the statistics come from the walk flavour only)
+        if (!walk_any && h->sweeps_done >= h->walk_refresh_at) { sl.walk = 1; h->walk_refresh_at = h->sweeps_done + 16; }
+        if (walk_unknown) sl.walk = 1;                           // the first sweep measures (threshold 0)
+    }
+    if (debug) sl.walk = 1;
     // Primary kernel variant: the register-resident kernel with 64*rmax topic slots per entity that is
     // cheapest for the topic-list histogram of the previous sweep (first time: of a probe pass over z).
     bool fast = !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
@@ -760,7 +813,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         while (g.wpb > 1 && sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes > h->max_lds) g.wpb >>= 1;
         g.lds = sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes;
         if (g.lds > h->max_lds) return MVHDP_ERR_UNSUPPORTED;
-        int bpc = is_fast ? mvhdp_sweep_fast_occupancy(r, debug, 64 * g.wpb, g.lds) : mvhdp_sweep_generic_occupancy(debug, 64 * g.wpb, g.lds);
+        int bpc = is_fast ? mvhdp_sweep_fast_occupancy(r, debug, sl.walk != 0, 64 * g.wpb, g.lds) : mvhdp_sweep_generic_occupancy(debug, 64 * g.wpb, g.lds);
         if (bpc < 1) bpc = 1;
         int64_t need = (mm.D + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
         g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * bpc));
@@ -807,7 +860,6 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     sl.q_order = h->d_doc_order; sl.q_order_start = 0; sl.q_order_count = mm.D;      // default: every entity, longest first
     sl.overflow_list = nullptr; sl.overflow_count = nullptr;
     sl.slot_hist = (unsigned long long*)(h->d_ovf_meta + 2);
-
     // debug buffers
     std::vector<void*> to_free;
     auto cleanup = [&]() { for (void* p : to_free) hipFree(p); };
@@ -1015,6 +1067,21 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     step(hipMemcpyAsync(&act, h->d_act_key, sizeof act, hipMemcpyDeviceToHost, s));
     step(hipMemcpyAsync(ovf, h->d_ovf_meta, sizeof ovf, hipMemcpyDeviceToHost, s));
     step(hipStreamSynchronize(s));
+    if (e == hipSuccess && sl.walk) {
+        double all = 0.0;
+        for (int m = 0; m < M; m++) {
+            const double n = (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS];
+            all += n;
+            if (n >= 64) h->walk_f[m] = (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS + 1] / n;
+            else if (nseg == 1) h->walk_f[m] = 1.0;                  // a view with next to no tokens is never steered
+        }
+        for (int b = 0; b < MVHDP_WALK_BINS; b++) {
+            double c = 0.0;
+            for (int m = 0; m < M; m++)
+                if (h->walk_f[m] >= 0.0 && h->walk_f[m] < 0.35) c += (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS + 2 + b];
+            h->walk_hist[b] = all > 0 ? c / all : 0.0;
+        }
+    }
     if (e == hipSuccess && mm.D > 0) {
         // next sweep: the variant that is cheapest for this sweep's topic-list histogram (topic lists change slowly
         // between sweeps); entities counted twice (overflow re-run) only make the choice more conservative
@@ -1029,6 +1096,16 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         }
     }
     if (e != hipSuccess) { cleanup(); HIPC(h, e); }
+    if (getenv("MVHDP_DEBUG")) {
+        fprintf(stderr, "[mvhdp] walk threshold %.2f (base %.2f, phase %d, dir %+d); tree branch %.4f of tokens, walked on demand %.4f; per view (threshold, tree share):",
+                (double)h->walk_probe_i / MVHDP_WALK_BINS, (double)h->walk_i / MVHDP_WALK_BINS, h->walk_phase, h->walk_dir,
+                (double)hs[ST_TREE] / std::max<double>(1.0, (double)hs[ST_TOKENS]), (double)hs[ST_ONDEMAND] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
+        for (int m = 0; m < M; m++) {
+            const double n = std::max<double>(1.0, (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS]);
+            fprintf(stderr, " (%.2f %.3f)", sl.walk_theta[m], hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS + 1] / n);
+        }
+        fprintf(stderr, "\n");
+    }
     if (getenv("MVHDP_DEBUG") && hs[ST_T_TOTAL])
         fprintf(stderr, "[mvhdp] wave cycles: queue %.1f%% prologue %.1f%% view setup %.1f%% chunk head %.1f%% tokens %.1f%% chunk end %.1f%% | %.0f cycles per token per wave\n",
                 100.0 * hs[ST_T_QUEUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_PROLOGUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_VIEW] / hs[ST_T_TOTAL],
@@ -1087,6 +1164,58 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         } else if (rmax == 1) h->two_round_ns_per_token = 0;         // the trial is over: the 1-round variant stays
         h->last_primary = rmax; h->last_ns_per_token = ns;
     } else h->last_primary = 0;
+    // the walk-threshold search (see mvhdp_ctx::walk_t): full sweeps of one kernel configuration only
+    const bool comparable = fast && nseg == 1 && !debug && !theta_env && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) && st.tokens > 0;
+    if (!comparable || h->walk_cfg != rmax * 2 + (classified ? 1 : 0)) {
+        h->walk_phase = 0;
+        h->walk_cfg = comparable ? rmax * 2 + (classified ? 1 : 0) : -1;
+        if (comparable) h->walk_ns_a1 = 0.0;
+    }
+    if (comparable && !walk_any) h->walk_phase = 0;
+    if (comparable && walk_any) {
+        const double ns = (double)ms_k * 1e6 / (double)st.tokens;
+        if (h->walk_phase == 0) {
+            h->walk_ns_a1 = ns;
+            if (h->sweeps_done >= h->walk_idle_until) h->walk_phase = 1;
+        } else if (h->walk_phase == 1) {
+            h->walk_ns_b = ns; h->walk_b_i = h->walk_probe_i; h->walk_phase = 2;
+        } else {
+            const double base = 0.5 * (h->walk_ns_a1 + ns);
+            const int step = h->walk_b_i - h->walk_i;
+            const bool far = h->walk_far;
+            h->walk_far = false;
+            // leaving threshold 0 also changes the kernel flavour: ask for more there (no flapping between the two)
+            const double need = h->walk_i == 0 ? 0.005 : 0.0025;
+            if (std::fabs(h->walk_ns_a1 - ns) > 0.025 * base) {          // the A sweeps disagree (a variant change, a jump of the chain): no verdict
+                h->walk_ns_a1 = ns; h->walk_phase = 1; h->walk_far = far;
+            } else if (step != 0 && h->walk_ns_b < base * (1.0 - need)) {
+                h->walk_i = h->walk_b_i;
+                h->walk_ns_a1 = h->walk_ns_b;                            // the B sweep is the first A sweep of the next step
+                h->walk_fails = 0; h->walk_wait = 4; h->walk_phase = 1;
+                if (step > 0) h->walk_maxj = std::min(6, h->walk_maxj * 2);
+                if (far) h->walk_far = true;                             // half again
+            } else if (step > 1) {                                       // a long step that did not pay: a shorter one, same direction
+                h->walk_ns_a1 = ns;
+                h->walk_maxj = std::max(1, step / 2);
+                h->walk_phase = 1;
+            } else if (far) {                                            // half the threshold is no better: back to single steps
+                h->walk_ns_a1 = ns;
+                h->walk_dir = 1;
+                h->walk_phase = 1;
+            } else {
+                h->walk_ns_a1 = ns;
+                h->walk_dir = -h->walk_dir;
+                h->walk_phase = 1;
+                if (++h->walk_fails >= 2) {
+                    h->walk_fails = 0;
+                    h->walk_idle_until = h->sweeps_done + h->walk_wait;
+                    h->walk_wait = std::min(64, h->walk_wait * 2);
+                    h->walk_phase = 0;
+                    h->walk_far = true;
+                }
+            }
+        }
+    }
     if (stats) *stats = st;
     return ret;
 }

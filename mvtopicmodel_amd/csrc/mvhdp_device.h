@@ -6,6 +6,8 @@
 #include <stdint.h>
 
 #define MVHDP_MAXM 8
+#define MVHDP_WALK_BINS 20                      /* walk thresholds are multiples of 1/MVHDP_WALK_BINS */
+#define MVHDP_VIEW_STATS (2 + MVHDP_WALK_BINS)
 
 // Everything a kernel needs, passed by value (lands in SGPRs / constant memory).
 struct MvModel {
@@ -61,6 +63,11 @@ struct SweepLaunch {
     int64_t q_order_start, q_order_count, q_order_stride;
     int32_t* overflow_list;            // optimistic mode: entities whose topic list exceeds this variant's slots are appended here
     unsigned int* overflow_count;      //   and re-run by a wider kernel; nullptr in classified mode (an overflow is then an error)
+    // Speculative tree walk of the chunk head: a token's word tree is walked up front iff its first uniform u1 >= walk_theta[m]
+    // (only a large u1 can reach the tree branch, WRK:529-535); a token that reaches it unwalked walks on demand, same
+    // arithmetic, same result.  0 = walk every token.
+    double walk_theta[MVHDP_MAXM];
+    int32_t walk;                      // 1: launch the kernel flavour that knows about thresholds (and counts the per-view statistics)
     unsigned long long* slot_hist;     // [17] tokens of the entities with ceil(list size/64) = 1..16, >16 (sizes the next sweep's variant)
     // debug
     double* tok_dbg[MVHDP_MAXM];
@@ -70,7 +77,10 @@ struct SweepLaunch {
 };
 
 enum {
-    ST_TOKENS = 0, ST_CHANGED, ST_NEW, ST_DOC, ST_TREE, ST_OOV, ST_ABORT, ST_FALLBACK, ST_NEGATIVE, ST_MISCLASS,
+    ST_TOKENS = 0, ST_CHANGED, ST_NEW, ST_DOC, ST_TREE, ST_OOV, ST_ABORT, ST_FALLBACK, ST_NEGATIVE, ST_MISCLASS, ST_ONDEMAND,
+    // per view, MVHDP_VIEW_STATS words each: tokens sampled, tokens that took the tree branch, and the histogram of the latter's u1
+    // in MVHDP_WALK_BINS bins -- what a walk threshold would cost in walks on demand (mvhdp_sweep's threshold search)
+    ST_VIEW_BASE, ST_VIEW_LAST = ST_VIEW_BASE + MVHDP_VIEW_STATS * MVHDP_MAXM - 1,
     // wave cycles by segment, summed over waves; filled only by a -DMVHDP_TIMING build (diagnostics)
     ST_T_QUEUE, ST_T_PROLOGUE, ST_T_VIEW, ST_T_CHUNK_HEAD, ST_T_TOKENS, ST_T_CHUNK_END, ST_T_TOTAL, ST_COUNT
 };
@@ -114,8 +124,41 @@ struct ClassifyArgs {
 hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipStream_t s);
 size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax);
 hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);
-int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes);
+int mvhdp_sweep_fast_occupancy(int rmax, bool debug, bool walk, int block_threads, size_t lds_bytes);
 int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes);
 
 #define MVHDP_DOC_BATCH 2
 #define MVHDP_HIST_BINS 17
+
+// FTree.sample (FT:111-136) through the descent table (MvModel::dtab), one lane per token: the same reads, comparisons and
+// subtractions as the literal descent over FTree.tree, three levels per 64-byte block (see the chunk head of the
+// register-resident sweep kernel, which walks the same table the same way).
+__device__ __forceinline__ int dtab_sample(const MvModel& mm, int64_t row, double u01)
+{
+    const int K = mm.K;
+    const double* __restrict__ dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
+    double u = 0.0;
+    int i = 1;
+    for (int bd = 0; bd < mm.dt_nbd; bd++) {
+        if (bd == 0 || i < K) {
+            const double2* __restrict__ blk = (const double2*)(dt + (int64_t)(mm.dt_base[bd] + (i - (1 << mm.dt_depth[bd]))) * 8);
+            const double2 q0 = blk[0], q1 = blk[1], q2 = blk[2], q3 = blk[3];
+            const int levels = (bd == 0) ? mm.dt_f : 3;
+            if (bd == 0) u = u01 * q3.y;                                              // FT:120  u *= tree[1]
+            int path = 0;
+            if (i < K && levels > 0) {                                                // FT:122-130
+                const double l = q0.x;
+                if (u < l) { i = 2 * i; } else { u = u - l; i = 2 * i + 1; path = 1; }
+            }
+            if (i < K && levels > 1) {
+                const double l = path ? q1.x : q0.y;
+                if (u < l) { i = 2 * i; path = 2 * path; } else { u = u - l; i = 2 * i + 1; path = 2 * path + 1; }
+                if (i < K && levels > 2) {
+                    const double l3 = (path == 0) ? q1.y : (path == 1) ? q2.x : (path == 2) ? q2.y : q3.x;
+                    if (u < l3) { i = 2 * i; } else { u = u - l3; i = 2 * i + 1; }
+                }
+            }
+        }
+    }
+    return i - K;                                                                     // FT:132
+}

@@ -115,8 +115,8 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         if (write_full) {                                      // FTree.tree itself: generic kernel, get_tree, init_from_trees
             double* out = mm.trees + row * 2 * K;
             for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
-            if (lane == 0) mm.root[row] = t[1];
         }
+        if (lane == 0) mm.root[row] = t[1];                    // tree[1] by itself: 8 bytes a type, L2-resident (WRK:519 without the walk)
         // the same numbers once more, grouped for the descent (see MvModel::dtab)
         double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
         for (int x = lane; x < mm.dt_nblk; x += WAVE) {
@@ -969,39 +969,6 @@ hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipS
 // init_from_trees: INF:169-199.  One wave per (view, entity): each token's topic is drawn from its
 // type's tree (FTree.sample FT:111-136); out-of-vocabulary tokens get 0 (Java's new int[]).
 // ---------------------------------------------------------------------------
-// FTree.sample (FT:111-136) through the descent table (MvModel::dtab), one lane per token: the same reads, comparisons and
-// subtractions as the literal descent over FTree.tree, three levels per 64-byte block (see the chunk head of the
-// register-resident sweep kernel, which walks the same table the same way).
-__device__ __forceinline__ int dtab_sample(const MvModel& mm, int64_t row, double u01)
-{
-    const int K = mm.K;
-    const double* __restrict__ dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
-    double u = 0.0;
-    int i = 1;
-    for (int bd = 0; bd < mm.dt_nbd; bd++) {
-        if (bd == 0 || i < K) {
-            const double2* __restrict__ blk = (const double2*)(dt + (int64_t)(mm.dt_base[bd] + (i - (1 << mm.dt_depth[bd]))) * 8);
-            const double2 q0 = blk[0], q1 = blk[1], q2 = blk[2], q3 = blk[3];
-            const int levels = (bd == 0) ? mm.dt_f : 3;
-            if (bd == 0) u = u01 * q3.y;                                              // FT:120  u *= tree[1]
-            int path = 0;
-            if (i < K && levels > 0) {                                                // FT:122-130
-                const double l = q0.x;
-                if (u < l) { i = 2 * i; } else { u = u - l; i = 2 * i + 1; path = 1; }
-            }
-            if (i < K && levels > 1) {
-                const double l = path ? q1.x : q0.y;
-                if (u < l) { i = 2 * i; path = 2 * path; } else { u = u - l; i = 2 * i + 1; path = 2 * path + 1; }
-                if (i < K && levels > 2) {
-                    const double l3 = (path == 0) ? q1.y : (path == 1) ? q2.x : (path == 2) ? q2.y : q3.x;
-                    if (u < l3) { i = 2 * i; } else { u = u - l3; i = 2 * i + 1; }
-                }
-            }
-        }
-    }
-    return i - K;                                                                     // FT:132
-}
-
 __global__ __launch_bounds__(256) void init_from_trees_kernel(MvModel mm, uint32_t seed_lo, uint32_t seed_hi)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

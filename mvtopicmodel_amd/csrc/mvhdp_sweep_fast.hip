@@ -37,7 +37,10 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 // Minimum waves per SIMD asked of the register allocator for each variant (measured on C4: the
 // 2-slot variant gains 5 % at 6 waves despite 64 B/lane of scratch and loses 15 % at 7).
 #ifndef MVHDP_LB1
-#define MVHDP_LB1 1
+#define MVHDP_LB1 1          // the plain 1-slot variant allocates 70 VGPRs by itself (7 waves); bounding it costs 2 % on C2
+#endif
+#ifndef MVHDP_LB1W
+#define MVHDP_LB1W 7         // with the thresholded walk it would take 75 (6 waves): C3 loses 4 % there
 #endif
 #ifndef MVHDP_LB2
 #define MVHDP_LB2 6
@@ -48,8 +51,11 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #ifndef MVHDP_LB8
 #define MVHDP_LB8 1          // 3 waves/SIMD (168 VGPRs) spills 100 B/lane and is 13 % slower on C5 than 2 waves at 199
 #endif
-template <int RMAX, bool DEBUG>
-__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : 1)))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+// WALK: the flavour with the thresholded tree walk of the chunk head (SweepLaunch::walk_theta), the walk on demand in the token
+// loop and the per-view branch statistics the threshold search feeds on.  Without it every token is walked up front and nothing
+// is counted: where the best threshold is 0 (C2, C3) that code is 2-5 % faster for not carrying the rest.
+template <int RMAX, bool DEBUG, bool WALK>
+__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : 1))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -66,7 +72,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     const int nkd_len = sl.nk_global ? 0 : M * K;
     int* nkd = (int*)smem;
     unsigned int* hist_s = (unsigned int*)(nkd + nkd_len);
-    for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS; i += blockDim.x) nkd[i] = 0;
+    unsigned int* vstat_s = hist_s + MVHDP_HIST_BINS;     // [MVHDP_MAXM][MVHDP_VIEW_STATS] per-view branch statistics of this block
+    for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS + (WALK ? MVHDP_MAXM * MVHDP_VIEW_STATS : 0); i += blockDim.x) nkd[i] = 0;
     int32_t* const dnk_g = mm.delta + mm.rowbase[M] * K;    // n_k part of the delta buffer
     __syncthreads();
 
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     const int32_t* nk_all = mm.counts + mm.rowbase[M] * K;
     int32_t* dnwk = mm.delta;
 
-    unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0;
+    unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0, n_od = 0;
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
     const long long q_n1 = sl.q_list_count ? (long long)*sl.q_list_count : 0;
@@ -228,6 +235,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             const int64_t base = mm.doc_off[m][d];
             const int64_t row0 = mm.rowbase[m];
             const int Vm = mm.V[m];
+            const double walk_theta = sl.walk_theta[m];
+            const unsigned int v_tok0 = n_tok, v_tree0 = c_tree;
+            unsigned int whist_l = 0;                                        // lane b < MVHDP_WALK_BINS: tree-branch tokens of this view with u1 in bin b
 
             MVHDP_TSEG(tv);
             for (int c0 = 0; c0 < lenm && !aborted; c0 += WAVE) {
@@ -258,10 +268,16 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 // does not depend on the entity's state: every lane walks its own word's tree here, 64
                 // dependent-load chains in flight at once, and the sequential loop below only picks the
                 // result up.  root_l = tree[1] (WRK:519), zt_l = the sampled topic, st_l = its slot or -1.
+                // Only a large u1 reaches the tree branch (s1 >= mass, WRK:529), so a token whose u1 is below the view's
+                // threshold is not walked here: it takes tree[1] from the 8-byte-per-type root array and, should it reach the
+                // branch after all, walks on demand in the token loop (same table, same arithmetic, same topic).
                 double root_l = 0.0;
                 int zt_l = -1, st_l = -1;
+                const bool walk_l = tvalid && w_l >= 0 && (!WALK || u1_l >= walk_theta);
+                const unsigned long long walked = WALK ? __ballot(walk_l) : ~0ull;
+                if (WALK && tvalid && w_l >= 0 && !walk_l) root_l = mm.root[row0 + w_l];
                 {
-                    const bool act = tvalid && w_l >= 0;
+                    const bool act = walk_l;
                     const double* __restrict__ dt = mm.dtab + (row0 + max(w_l, 0)) * (int64_t)mm.dt_nblk * 8;
                     double u = 0.0;
                     int i = 1;
@@ -365,6 +381,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 const int i = lane * R_eff + r;
                 if (r < R_eff && i < S_used) sn_set(m * S + i, cn[r]);
             }
+            if (WALK && n_tok != v_tok0) {                                           // per-view branch statistics (block-local): one LDS atomic
+                const unsigned int v = lane < MVHDP_WALK_BINS ? whist_l : lane == MVHDP_WALK_BINS ? n_tok - v_tok0 : c_tree - v_tree0;
+                const int idx = lane < MVHDP_WALK_BINS ? 2 + lane : lane - MVHDP_WALK_BINS;
+                if (lane < MVHDP_WALK_BINS + 2 && v) atomicAdd(&vstat_s[m * MVHDP_VIEW_STATS + idx], v);
+            }
             LDS_FENCE();
         }
         if (aborted) n_abort++;
@@ -376,6 +397,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     for (int i = threadIdx.x; i < nkd_len; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk_g[i], nkd[i]);
     if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
+    if (WALK && threadIdx.x < MVHDP_MAXM * MVHDP_VIEW_STATS && vstat_s[threadIdx.x])
+        atomicAdd(&sl.stats[ST_VIEW_BASE + threadIdx.x], (unsigned long long)vstat_s[threadIdx.x]);
     if (lane == 0) {
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
@@ -385,6 +408,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         if (n_oov) atomicAdd(&sl.stats[ST_OOV], (unsigned long long)n_oov);
         if (n_abort) atomicAdd(&sl.stats[ST_ABORT], (unsigned long long)n_abort);
         if (n_fb) atomicAdd(&sl.stats[ST_FALLBACK], (unsigned long long)n_fb);
+        if (n_od) atomicAdd(&sl.stats[ST_ONDEMAND], (unsigned long long)n_od);
         if (n_misclass) atomicAdd(&sl.stats[ST_MISCLASS], (unsigned long long)n_misclass);
 #ifdef MVHDP_TIMING
         atomicAdd(&sl.stats[ST_T_QUEUE], tq); atomicAdd(&sl.stats[ST_T_PROLOGUE], tp); atomicAdd(&sl.stats[ST_T_VIEW], tv);
@@ -397,18 +421,26 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #undef sn_get
 #undef sn_set
 
+// debug launches always take the WALK flavour (one instantiation fewer per variant; a threshold of 0 walks every token)
+template <int RMAX>
+static const void* fast_kernel_ptr(bool debug, bool walk)
+{
+    return debug ? (const void*)sweep_fast_kernel<RMAX, true, true>
+                 : walk ? (const void*)sweep_fast_kernel<RMAX, false, true> : (const void*)sweep_fast_kernel<RMAX, false, false>;
+}
+
 template <int RMAX>
 static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s)
 {
     size_t lds = sl.block_shared_bytes + (size_t)sl.waves_per_block * sl.wave_bytes;
     dim3 block(64 * sl.waves_per_block);
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(debug ? (const void*)sweep_fast_kernel<RMAX, true> : (const void*)sweep_fast_kernel<RMAX, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (debug) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true>), dim3(grid_blocks), block, lds, s, mm, sl);
-    else       hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false>), dim3(grid_blocks), block, lds, s, mm, sl);
+    if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else if (sl.walk) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else              hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, false>), dim3(grid_blocks), block, lds, s, mm, sl);
     return hipGetLastError();
 }
 
@@ -446,21 +478,20 @@ static int blocks_per_cu_from(const void* func, int threads, size_t lds)
 }
 
 template <int RMAX>
-static int occ_fast(bool debug, int threads, size_t lds)
+static int occ_fast(bool debug, bool walk, int threads, size_t lds)
 {
-    return debug ? blocks_per_cu_from((const void*)sweep_fast_kernel<RMAX, true>, threads, lds)
-                 : blocks_per_cu_from((const void*)sweep_fast_kernel<RMAX, false>, threads, lds);
+    return blocks_per_cu_from(fast_kernel_ptr<RMAX>(debug, walk), threads, lds);
 }
 
-int mvhdp_sweep_fast_occupancy(int rmax, bool debug, int block_threads, size_t lds_bytes)
+int mvhdp_sweep_fast_occupancy(int rmax, bool debug, bool walk, int block_threads, size_t lds_bytes)
 {
     switch (rmax) {
-    case 1: return occ_fast<1>(debug, block_threads, lds_bytes);
-    case 2: return occ_fast<2>(debug, block_threads, lds_bytes);
+    case 1: return occ_fast<1>(debug, walk, block_threads, lds_bytes);
+    case 2: return occ_fast<2>(debug, walk, block_threads, lds_bytes);
     case 3:
-    case 4: return occ_fast<4>(debug, block_threads, lds_bytes);
-    case 8: return occ_fast<8>(debug, block_threads, lds_bytes);
-    case 16: return occ_fast<16>(debug, block_threads, lds_bytes);
+    case 4: return occ_fast<4>(debug, walk, block_threads, lds_bytes);
+    case 8: return occ_fast<8>(debug, walk, block_threads, lds_bytes);
+    case 16: return occ_fast<16>(debug, walk, block_threads, lds_bytes);
     default: return 0;
     }
 }

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round-2 profiling recipe (GPU box, through gpurun):  bash profiles/profile_r02.sh
+# Round-2 profiling recipe (GPU box, through gpurun):  bash profiles/profile_r02.sh [tag]      (tag r02b: the build with the thresholded tree walk)
 # kernel trace + stats of the default bench command (C4) and of the C5 bench; the bench lines themselves (with the CPU leg
 # for C4); PMC passes are profiles/calib.sh.
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r02
+T=${1:-r02}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$T
 mkdir -p $OUT/c4 $OUT/c5 $OUT/c4live
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --live-steps 0 > $OUT/c4.log 2>&1 || exit 1

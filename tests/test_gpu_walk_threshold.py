@@ -1,0 +1,94 @@
+"""The thresholded tree walk of the chunk head (SweepLaunch::walk_theta, mvhdp_sweep_fast.hip): a token whose first
+uniform is below the view's threshold is not walked up front and, if it reaches the tree branch (WRK:533-535) after all,
+walks its word's tree on demand inside the token loop.  The threshold decides WHEN FTree.sample (FT:111-136) is
+evaluated, never what it returns: whatever the thresholds, assignments, counts, branch counters and masses must be the
+oracle's, bit for bit.  MVHDP_WALK_THETA fixes the thresholds (a diagnostic switch read by every mvhdp_sweep call);
+without it the library searches for them by the clock, which the last test lets run."""
+import numpy as np
+import pytest
+
+from mvtopicmodel_amd.native import Hyper, SWEEP_EXACT_CHAIN
+from tests.helpers import assert_same_state, make_native, make_oracle, small_corpus
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (20, [300, 40, 50], 64, [30, 4, 6], 12),
+    (100, [2000], 96, [127], 13),
+    (200, [3000, 300, 300], 80, [127, 7, 15], 15),        # 8 levels: blocks of 3 + 3 + 2
+    (400, [5000, 500, 500], 48, [127, 7, 15], 16),        # 9 levels, 2-round variant
+    (1000, [3000, 200, 200, 200, 200], 24, [600, 20, 20, 20, 20], 17),   # wide variants (LDS slot counts)
+]
+
+
+@pytest.mark.parametrize("theta", ["0", "0.5", "0.85", "1.1"])
+@pytest.mark.parametrize("K,V,D,lam,cseed", CASES)
+def test_any_threshold_gives_the_oracles_sweep(monkeypatch, K, V, D, lam, cseed, theta):
+    """theta 0: every token walked up front; 0.5 / 0.85: a mix; 1.1: no token walked up front, every tree-branch
+    token walks on demand."""
+    monkeypatch.setenv("MVHDP_WALK_THETA", ",".join([theta] * len(V)))
+    c = small_corpus(K, V, D, lam, cseed)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    s = make_native(c, hy, z0)
+    for it in range(2):
+        ro = o.sweep(it, 0xBEEF, want_dbg=(it == 1))
+        rs = s.sweep(it, 0xBEEF, want_dbg=(it == 1))
+        for f in ("tokens", "changed", "new_mass_cnt", "topic_doc_mass_cnt", "word_ftree_mass_cnt", "oov_skipped", "aborted_docs"):
+            assert ro["stats"][f] == getattr(rs, f), f
+        assert rs.word_ftree_mass_cnt > 0
+        assert_same_state(o, s, c.M)
+    for m in range(c.M):
+        a, b = ro["dbg"][m], rs.dbg[m]
+        assert np.array_equal(a[:, 0], b[:, 0])
+        assert np.array_equal(a[:, 2], b[:, 2])              # tree[1]: from the walked block or from the root array, same double
+        assert np.allclose(a[:, 1], b[:, 1], rtol=1e-12, atol=0)
+    s.close()
+
+
+@pytest.mark.parametrize("theta", ["0.6", "1.1"])
+def test_threshold_with_inactive_topics_oov_and_exact_chain(monkeypatch, theta):
+    """The truncated-HDP branch (new topic, WRK:515-526), out-of-vocabulary types and the sequential-sum mode under a threshold."""
+    monkeypatch.setenv("MVHDP_WALK_THETA", f"{theta},{theta}")
+    K, V = 40, [400, 60]
+    c = small_corpus(K, V, 64, [50, 6], 21)
+    oov = np.arange(0, c.tokens[0].size, 17)
+    c.tokens[0][oov] = V[0] + 5                                  # OOV types (WRK:427-428)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[33, 36, 39]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive)
+    hy.alpha[:, K] = 25.0                                        # make the new-topic branch likely
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(2)]
+    for m in range(2):                                           # inactive topics hold no tokens, OOV tokens no topic
+        z0[m][np.isin(z0[m], [33, 36, 39])] = 1
+    z0[0][oov] = -1
+    for m in range(2):
+        o.set_assignments(m, z0[m])
+    o.build_counts()
+    s = make_native(c, hy, z0)
+    s2 = make_native(c, hy, z0)
+    for it in range(3):
+        ro = o.sweep(it, 7)
+        rs = s.sweep(it, 7)
+        s2.sweep(it, 7, flags=SWEEP_EXACT_CHAIN)
+        assert ro["stats"]["new_mass_cnt"] == rs.new_mass_cnt and ro["stats"]["oov_skipped"] == rs.oov_skipped > 0
+        assert_same_state(o, s, c.M)
+        assert_same_state(o, s2, c.M)
+    s.close(); s2.close()
+
+
+def test_threshold_search_never_changes_the_chain():
+    """The library's own search (no MVHDP_WALK_THETA): over 14 sweeps it runs base and probe sweeps at different
+    thresholds, in both kernel flavours; the chain stays the oracle's."""
+    K, V = 100, [1500, 200]
+    c = small_corpus(K, V, 200, [100, 8], 31)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(m) for m in range(c.M)]
+    s = make_native(c, hy, z0)
+    for it in range(14):
+        o.sweep(it, 99)
+        s.sweep(it, 99)
+        assert_same_state(o, s, c.M)
+    s.close()
