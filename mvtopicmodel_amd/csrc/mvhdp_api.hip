@@ -1164,11 +1164,12 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         } else if (rmax == 1) h->two_round_ns_per_token = 0;         // the trial is over: the 1-round variant stays
         h->last_primary = rmax; h->last_ns_per_token = ns;
     } else h->last_primary = 0;
-    // the walk-threshold search (see mvhdp_ctx::walk_t): full sweeps of one kernel configuration only
-    const bool comparable = fast && nseg == 1 && !debug && !theta_env && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) && st.tokens > 0;
-    if (!comparable || h->walk_cfg != rmax * 2 + (classified ? 1 : 0)) {
+    // the walk-threshold search (see mvhdp_ctx::walk_i): among sweeps of one kernel configuration and update mode only
+    const bool comparable = fast && !debug && !theta_env && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) && st.tokens > 0;
+    const int walk_cfg = rmax * 2 + (classified ? 1 : 0) + 64 * nseg + (live ? 1 << 16 : 0) + (seg_apply ? 1 << 17 : 0);
+    if (!comparable || h->walk_cfg != walk_cfg) {
         h->walk_phase = 0;
-        h->walk_cfg = comparable ? rmax * 2 + (classified ? 1 : 0) : -1;
+        h->walk_cfg = comparable ? walk_cfg : -1;
         if (comparable) h->walk_ns_a1 = 0.0;
     }
     if (comparable && !walk_any) h->walk_phase = 0;

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Kernel / total ms per sweep of one chain in the three update modes, for A/B runs of two library builds on one box.
+
+  python tools/mode_times.py --workload C4 --mode seg8 --sweeps 40        (mode: deferred | live4 | live1 | seg8 | seg4)
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C4")
+    ap.add_argument("--mode", default="deferred")
+    ap.add_argument("--sweeps", type=int, default=40)
+    a = ap.parse_args()
+    from mvtopicmodel_amd import NativeSampler, synth
+    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
+    flags = 0
+    if a.mode.startswith("live"):
+        flags = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(int(a.mode[4:]))
+    elif a.mode.startswith("seg"):
+        flags = SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(int(a.mode[3:]))
+    c = synth.make_config(a.workload)
+    inactive, K_init = synth.config_inactive(a.workload)
+    z0 = init_assignments(K_init, c.doc_off, seed=1)
+    s = NativeSampler(c.K, c.V)
+    for m in range(c.M):
+        s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z0[m])
+    s.set_hyper(Hyper.defaults(c.K, c.V, inactive=inactive)); s.build_counts()
+    ks, ts = [], []
+    for it in range(a.sweeps):
+        st = s.sweep(it, 20260101, flags=flags)
+        ks.append(round(st.sweep_kernel_ms, 3)); ts.append(round(st.total_ms, 3))
+    h = len(ts) // 2
+    print(json.dumps({"workload": a.workload, "mode": a.mode, "total_ms_sweeps_5_24": round(sum(ts[5:25]) / 20, 3),
+                      "total_ms_last_half": round(sum(ts[h:]) / (len(ts) - h), 3), "total_ms": ts, "kernel_ms": ks}))
+    s.close()
+
+
+if __name__ == "__main__":
+    main()
