@@ -162,3 +162,39 @@ __device__ __forceinline__ int dtab_sample(const MvModel& mm, int64_t row, doubl
     }
     return i - K;                                                                     // FT:132
 }
+
+// The same walk for ONE token on behalf of the whole wave (row and u01 wave-uniform): the blocks come through the scalar
+// data cache (s_load, counted by lgkmcnt), so the walk never waits behind the vector-memory operations the wave has in
+// flight -- the n_wk gather of the next token, the previous chunk's atomics.  The descent table is read-only for the
+// duration of a kernel (the scalar cache is invalidated at every kernel start), the arithmetic is that of dtab_sample.
+__device__ __forceinline__ int dtab_sample_uniform(const MvModel& mm, int64_t row, double u01)
+{
+    typedef const __attribute__((address_space(4))) double* cdptr;
+    const int K = mm.K;
+    const cdptr dt = (cdptr)(mm.dtab + row * (int64_t)mm.dt_nblk * 8);
+    double u = 0.0;
+    int i = 1;
+    for (int bd = 0; bd < mm.dt_nbd; bd++) {
+        if (bd == 0 || i < K) {
+            const cdptr blk = dt + (int64_t)(mm.dt_base[bd] + (i - (1 << mm.dt_depth[bd]))) * 8;
+            const double q0x = blk[0], q0y = blk[1], q1x = blk[2], q1y = blk[3], q2x = blk[4], q2y = blk[5], q3x = blk[6], q3y = blk[7];
+            const int levels = (bd == 0) ? mm.dt_f : 3;
+            if (bd == 0) u = u01 * q3y;                                               // FT:120  u *= tree[1]
+            int path = 0;
+            if (i < K && levels > 0) {                                                // FT:122-130
+                const double l = q0x;
+                if (u < l) { i = 2 * i; } else { u = u - l; i = 2 * i + 1; path = 1; }
+            }
+            if (i < K && levels > 1) {
+                const double l = path ? q1x : q0y;
+                if (u < l) { i = 2 * i; path = 2 * path; } else { u = u - l; i = 2 * i + 1; path = 2 * path + 1; }
+                if (i < K && levels > 2) {
+                    const double l3 = (path == 0) ? q1y : (path == 1) ? q2x : (path == 2) ? q2y : q3x;
+                    if (u < l3) { i = 2 * i; } else { u = u - l3; i = 2 * i + 1; }
+                }
+            }
+            i = __builtin_amdgcn_readfirstlane(i);                                    // the next block's address stays scalar
+        }
+    }
+    return i - K;                                                                     // FT:132
+}
