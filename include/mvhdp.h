@@ -81,6 +81,10 @@ typedef struct {
     int64_t activation_key;       /* ordering key of that first delta, MVHDP_ACT_KEY(doc, view, pos, topic); INT64_MAX if none */
     double  sweep_kernel_ms;      /* device time of the sweep kernel alone (hipEvents on the handle's stream) */
     double  total_ms;             /* device time of the whole call: trees + view weights + sweep + apply */
+    int32_t activations;          /* topics that left inActiveTopicIndex during this call: 0 or 1 for a deferred sweep; a LIVE or
+                                     SEGMENT_APPLY sweep activates at every segment border (activated_topic is then the first);
+                                     0 with MVHDP_SWEEP_NO_APPLY / FROZEN (the caller activates) */
+    int32_t reserved;
 } mvhdp_sweep_stats;
 
 /* Activation key: the FastQDelta that activates a topic first in (global entity, view, position) order wins (UPD:263-270
@@ -128,7 +132,10 @@ typedef struct {
  * With NO_APPLY the delta buffer receives (counts after - counts before) of this shard and counts are restored, so the
  * multi-GPU sequence all-reduce + mvhdp_apply_delta is the same as for a deferred sweep.  Not combinable with FROZEN.
  * (LIVE_SEGMENTS without LIVE cuts a deferred sweep into the same segments: same integers as one segment.)
- * A topic activation (UPD:263-270) still takes effect at the end of the sweep, as in the deferred mode. */
+ * Topic activation (UPD:263-270): the first delta of a SEGMENT that lands on an inactive topic activates it at the segment's
+ * end -- alpha[m][k] takes alpha[m][K], the topic leaves inActiveTopicIndex, the next segment's new-topic draws go to the
+ * next inactive index (WRK:523-526) -- so one sweep can give birth to up to n topics (mvhdp_sweep_stats.activations); the
+ * reference's updater does it delta by delta.  With NO_APPLY nothing is activated here (the caller reduces the key first). */
 #define MVHDP_SWEEP_LIVE        0x20u
 #define MVHDP_SWEEP_LIVE_SEGMENTS(n) (((uint32_t)(n) & 0xffu) << 16)
 
@@ -136,8 +143,8 @@ typedef struct {
  * segment is a snapshot sweep over its entities (trees rebuilt from the current counts, deltas collected), then its deltas
  * are applied before the next segment starts.  Bit-reproducible like the plain deferred sweep (the oracle follows it
  * segment by segment), and statistically between the deferred and the live sweep: a token sees counts that are at most
- * one segment old.  Single handle only (not combinable with NO_APPLY, LIVE or FROZEN); a topic activation takes effect
- * at the end of the sweep.  The segments are the interleaved ones of the live sweep: positions s, s+n, s+2n, ... of the
+ * one segment old.  Single handle only (not combinable with NO_APPLY, LIVE or FROZEN); a topic is activated at the end of
+ * the segment whose delta reached it first (as for LIVE above).  The segments are the interleaved ones of the live sweep: positions s, s+n, s+2n, ... of the
  * entities ordered by decreasing token count (ties by entity index). */
 #define MVHDP_SWEEP_SEGMENT_APPLY 0x40u
 

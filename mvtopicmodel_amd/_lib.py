@@ -47,7 +47,8 @@ class SweepStatsC(C.Structure):
                 ("topic_doc_mass_cnt", C.c_int64), ("word_ftree_mass_cnt", C.c_int64),
                 ("oov_skipped", C.c_int64), ("aborted_docs", C.c_int64), ("exact_fallbacks", C.c_int64),
                 ("activated_topic", C.c_int32), ("activated_modality", C.c_int32),
-                ("activation_key", C.c_int64), ("sweep_kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("activation_key", C.c_int64), ("sweep_kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("activations", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DebugC(C.Structure):

@@ -846,10 +846,13 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         if (!h->d_overflow && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow, (size_t)mm.D * sizeof(int32_t)));
         if (n_chain > 1 && !h->d_overflow2 && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow2, (size_t)mm.D * sizeof(int32_t)));
     }
-    if (getenv("MVHDP_DEBUG"))
-        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) %s H=%lld chain=%d,%d,%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu\n",
+    if (getenv("MVHDP_DEBUG")) {
+        double tot = 0, b1 = 0, b2 = 0;                           // token share by topic-list size (last sweep): <= 64, <= 128 slots
+        for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b < 1) b1 += (double)h->last_hist[b]; if (b < 2) b2 += (double)h->last_hist[b]; }
+        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) %s H=%lld chain=%d,%d,%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu | tokens in lists <=64: %.4f <=128: %.4f\n",
                 sweep_idx, (int)fast, rmax, h->rmax_hint, classified ? "classified" : "optimistic", (long long)H, chain[0], chain[1], chain[2], S_cap,
-                fst[0].grid, fst[0].wpb, fst[0].lds, gen.grid, gen.wpb, gen.lds);
+                fst[0].grid, fst[0].wpb, fst[0].lds, gen.grid, gen.wpb, gen.lds, b1 / std::max(1.0, tot), b2 / std::max(1.0, tot));
+    }
     sl.stats = h->d_stats;
     sl.act_key = h->d_act_key;
     // d_ovf_meta (u32 words): 0,1 = overflow counts of passes 1,2; 2..35 = u64 hist[17]; 36 = overflow count of pass 3;
@@ -947,11 +950,31 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         if (h->tokens_desc.empty()) return mm.D;
         return std::upper_bound(h->tokens_desc.begin(), h->tokens_desc.end(), tokens, std::greater<int64_t>()) - h->tokens_desc.begin();
     };
+    int n_activations = 0;                                   // topics activated at segment borders, and the key of the first
+    long long first_act = LLONG_MAX;
     for (int seg = 0; seg < nseg && e == hipSuccess && mm.D > 0; seg++) {
         // segment seg = positions seg, seg + nseg, ... of the order; a prefix [0, P) of the order holds share(P) of them
         auto share = [&](int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
         const int64_t n_seg = share(mm.D);
         if (seg > 0) {
+            // UPD:263-270 acts as soon as a delta lands on an inactive topic, and the samplers then draw the NEXT inactive
+            // index (WRK:523-526): a sweep whose counts are kept current does the same at every segment border -- the
+            // segment's first such delta (by entity, view, position) activates its topic before the next segment starts.
+            // Not with MVHDP_SWEEP_NO_APPLY: there the caller reduces the key over all document shards first.
+            if ((live || seg_apply) && !(flags & MVHDP_SWEEP_NO_APPLY) && mm.first_inactive >= 0 && e == hipSuccess) {
+                long long key = LLONG_MAX;
+                step(hipMemcpyAsync(&key, h->d_act_key, sizeof key, hipMemcpyDeviceToHost, s));
+                step(hipStreamSynchronize(s));
+                if (e == hipSuccess && key != LLONG_MAX) {
+                    const int rc = apply_activation(h, MVHDP_ACT_KEY_TOPIC(key), MVHDP_ACT_KEY_VIEW(key));
+                    if (rc != MVHDP_OK) { cleanup(); return rc; }
+                    if (n_activations++ == 0) first_act = key;
+                    mk.first_inactive = mm.first_inactive;
+                    const long long none = LLONG_MAX;
+                    step(hipMemcpyAsync(h->d_act_key, &none, sizeof none, hipMemcpyHostToDevice, s));
+                    step(hipStreamSynchronize(s));                       // (`none` lives on this stack frame)
+                }
+            }
             if ((live && !(flags & MVHDP_SWEEP_REUSE_TREES)) || seg_apply) rebuild_trees();   // from the live / just-updated counts
             step(hipMemsetAsync(h->d_ovf_meta, 0, 2 * sizeof(unsigned int), s));         // overflow counts of passes 1, 2
             step(hipMemsetAsync(h->d_ovf_meta + ovf_word[2], 0, sizeof(unsigned int), s));
@@ -1136,12 +1159,18 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     } else if (flags & MVHDP_SWEEP_NO_APPLY) {
         h->delta_pending = true;
     } else if (live || seg_apply) {
-        // the counts are already updated; what is left of the updater's work is the topic activation
+        // the counts are already updated; what is left of the updater's work is the topic activation of the last segment
         h->have_trees = false;
         if (seg_apply) h->delta_clean = true;                        // apply_delta_kernel zeroed what it added
         ret = apply_activation(h, st.activated_topic, st.activated_modality);
+        if (st.activated_topic >= 0) n_activations++;
+        if (first_act != LLONG_MAX) {                                // report the sweep's first activation
+            st.activation_key = first_act;
+            st.activated_topic = MVHDP_ACT_KEY_TOPIC(first_act); st.activated_modality = MVHDP_ACT_KEY_VIEW(first_act);
+        }
         if (ret == MVHDP_OK && hs[ST_NEGATIVE]) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
     } else {
+        if (st.activated_topic >= 0) n_activations = 1;
         ret = mvhdp_apply_delta(h, st.activated_topic, st.activated_modality);
     }
     HIPC(h, hipEventRecord(h->ev[3], s));
@@ -1150,6 +1179,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     hipEventElapsedTime(&ms_k, h->ev[1], h->ev[2]);
     hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
     st.sweep_kernel_ms = ms_k; st.total_ms = ms_t;
+    st.activations = n_activations; st.reserved = 0;
     // the 1-round trial (see mvhdp_ctx::last_primary): plain full sweeps only, so that the two times are comparable
     h->sweeps_done++;
     const bool plain = fast && !classified && nseg == 1 && !debug && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) &&

@@ -249,6 +249,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv*
     setL("oovSkipped", st.oov_skipped); setL("abortedDocs", st.aborted_docs); setL("exactFallbacks", st.exact_fallbacks);
     setI("activatedTopic", st.activated_topic); setI("activatedModality", st.activated_modality);
     setL("activationKey", st.activation_key); setD("sweepKernelMs", st.sweep_kernel_ms); setD("totalMs", st.total_ms);
+    setI("activations", st.activations);
 }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nApplyDelta(JNIEnv* env, jclass, jlong p, jint topic, jint modality)

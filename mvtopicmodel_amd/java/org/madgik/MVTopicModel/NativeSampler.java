@@ -30,6 +30,7 @@ public final class NativeSampler implements AutoCloseable {
         public int activatedTopic, activatedModality;
         public long activationKey;
         public double sweepKernelMs, totalMs;
+        public int activations;          // topics activated during the call (a live / segmented sweep activates at every segment border)
     }
 
     private long handle;   // mvhdp_handle

@@ -87,6 +87,8 @@ class SweepStats:
     activation_key: int = 0
     sweep_kernel_ms: float = 0.0
     total_ms: float = 0.0
+    activations: int = 0
+    reserved: int = 0
     dbg: list = field(default=None, repr=False)
     trace: np.ndarray = field(default=None, repr=False)
 

@@ -196,6 +196,8 @@ def test_random_shapes_segmented(seed, monkeypatch):
         st = s.sweep(it, 31 + seed, flags=(flags & 0xFFFF) | SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(nseg))
         assert (st.tokens, st.changed, st.new_mass_cnt, st.topic_doc_mass_cnt, st.word_ftree_mass_cnt) == \
                (so["tokens"], so["changed"], so["new_mass_cnt"], so["topic_doc_mass_cnt"], so["word_ftree_mass_cnt"])
-        assert (st.activated_topic, st.activated_modality) == (best[1], best[2])
+        assert (st.activated_topic, st.activated_modality, st.activations) == (best[1], best[2], best[3])
         assert_same_state(o, s, c.M)
+        if inactive is not None:
+            assert np.array_equal(s.get_alpha()[0], o.get_alpha()) and np.array_equal(s.get_alpha()[1], o.get_inactive())
     s.close()

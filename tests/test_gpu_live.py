@@ -104,26 +104,34 @@ def test_live_flag_errors():
     s.close()
 
 
-def test_live_inactive_topic_is_activated_at_sweep_end():
+def test_live_inactive_topics_are_activated_at_segment_borders():
+    """UPD:263-270 in a live sweep: the first delta of a segment that lands on an inactive topic activates it before the
+    next segment starts (and the last segment's at the end of the call), so one sweep can give birth to several topics;
+    every activation hands alpha[m][K] to the topic (UPD:268) and the samplers move on to the next inactive index."""
     K, V = 30, [400, 50, 60]
     c = small_corpus(K, V, 90, [25, 4, 6], 36)
-    inactive = np.zeros(K, dtype=np.uint8); inactive[[25, 28]] = 1
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[22, 25, 27, 28]] = 1
     hy = Hyper.defaults(K, V, inactive=inactive)
     hy.alpha[:, K] = 30.0
     o = make_oracle(c, hy)
     z = [o.get_assignments(m) for m in range(c.M)]
     for m in range(c.M):
-        z[m][np.isin(z[m], [25, 28])] = 2
+        z[m][np.isin(z[m], [22, 25, 27, 28])] = 2
     s = make_native(c, hy, z)
-    act = 0
+    born, most = 0, 0
     for it in range(4):
-        st = s.sweep(it, 3, flags=SWEEP_LIVE)
-        if st.activated_topic >= 0:
-            act += 1
-            a, ina = s.get_alpha()
+        ina_before = s.get_alpha()[1].copy()
+        st = s.sweep(it, 3, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(4))
+        a, ina = s.get_alpha()
+        assert int(ina_before.sum()) - int(ina.sum()) == st.activations          # one topic per activation left the inactive set
+        if st.activations:
+            assert st.activated_topic == int(np.flatnonzero(ina_before)[0])      # the first inactive index goes first (WRK:523-526)
             assert ina[st.activated_topic] == 0 and a[st.activated_modality, st.activated_topic] == 30.0     # UPD:268
+            newly = np.flatnonzero(ina_before & ~ina.astype(bool))
+            assert np.array_equal(newly, np.flatnonzero(ina_before)[:st.activations])   # in index order, no gaps
+        born += st.activations; most = max(most, st.activations)
         _check_counts_are_counts_of_z(c, s, K)
-    assert act >= 1
+    assert born >= 2 and most >= 2
     s.close()
 
 

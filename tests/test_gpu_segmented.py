@@ -22,21 +22,25 @@ def segment_lists(c, nseg):
 
 
 def oracle_segmented_sweep(o, c, it, seed, nseg):
+    """The deferred sweep cut into nseg interleaved segments with the updater catching up in between: counts += delta, and
+    -- UPD:263-270 -- the segment's first delta on an inactive topic activates it before the next segment starts (the
+    samplers then draw the next inactive index, WRK:523-526).  Returns the summed statistics and (key, topic, view,
+    activations) of the sweep's first activation."""
     from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY
-    best = (KEY_NONE, -1, -1)
+    first = (KEY_NONE, -1, -1)
+    n_act = 0
     stats = dict(tokens=0, changed=0, new_mass_cnt=0, topic_doc_mass_cnt=0, word_ftree_mass_cnt=0)
     for docs in segment_lists(c, nseg):
         r = o.sweep_list(it, seed, docs, flags=ORC_NO_APPLY, want_delta=True)
-        o.apply_delta(r["delta_nwk"], r["delta_nk"], -1, -1)
         st = r["stats"]
+        o.apply_delta(r["delta_nwk"], r["delta_nk"], st["activated_topic"], st["activated_modality"])
         for k in stats:
             stats[k] += st[k]
-        if st["activated_topic"] >= 0 and st["activation_key"] < best[0]:
-            best = (st["activation_key"], st["activated_topic"], st["activated_modality"])
-    if best[1] >= 0:                                         # UPD:263-270, at the end of the sweep
-        z = np.zeros((sum(o.V), o.K), dtype=np.int32)
-        o.apply_delta(z, np.zeros((o.M, o.K), dtype=np.int32), best[1], best[2])
-    return stats, best
+        if st["activated_topic"] >= 0:
+            if n_act == 0:
+                first = (st["activation_key"], st["activated_topic"], st["activated_modality"])
+            n_act += 1
+    return stats, first + (n_act,)
 
 
 @pytest.mark.parametrize("force,mode", [("", ""), ("1", "optimistic"), ("2", "classified"), ("8", "optimistic")])
@@ -77,13 +81,41 @@ def test_segmented_sweep_with_inactive_topics_and_errors():
     for it in range(4):
         so, best = oracle_segmented_sweep(o, c, it, 3, 3)
         st = s.sweep(it, 3, flags=SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(3))
-        assert (st.activated_topic, st.activated_modality) == (best[1], best[2])
+        assert (st.activated_topic, st.activated_modality, st.activations) == (best[1], best[2], best[3])
         assert st.new_mass_cnt == so["new_mass_cnt"]
-        acts += st.activated_topic >= 0
+        acts += st.activations
         assert_same_state(o, s, c.M)
         assert np.array_equal(s.get_alpha()[0], o.get_alpha()) and np.array_equal(s.get_alpha()[1], o.get_inactive())
-    assert acts >= 1
+    assert acts >= 2                                       # both inactive topics were born
     for bad in (SWEEP_LIVE, SWEEP_NO_APPLY):
         with pytest.raises(MvhdpError):
             s.sweep(9, 3, flags=SWEEP_SEGMENT_APPLY | bad)
+    s.close()
+
+
+def test_segmented_sweep_activates_a_topic_at_every_segment_border():
+    """Many inactive topics and a large new-topic weight: every segment draws the new-topic branch often enough to land on
+    the current first inactive index, so one sweep gives birth to several topics, one per segment, as the reference's
+    updater does while the samplers run (UPD:263-270, WRK:523-526) -- and exactly as the oracle's segmented schedule."""
+    K, V = 40, [500, 60]
+    c = small_corpus(K, V, 160, [30, 5], 44)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[20:] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive)
+    hy.alpha[:, K] = 50.0
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) % 20 for m in range(c.M)]
+    for m in range(c.M):
+        o.set_assignments(m, z[m])
+    o.build_counts()
+    s = make_native(c, hy, z)
+    born = 0
+    for it in range(3):
+        so, best = oracle_segmented_sweep(o, c, it, 11, 6)
+        st = s.sweep(it, 11, flags=SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(6))
+        assert (st.activated_topic, st.activated_modality, st.activations) == (best[1], best[2], best[3])
+        assert st.new_mass_cnt == so["new_mass_cnt"] > 0
+        born += st.activations
+        assert_same_state(o, s, c.M)
+        assert np.array_equal(s.get_alpha()[0], o.get_alpha()) and np.array_equal(s.get_alpha()[1], o.get_inactive())
+    assert born >= 6 and st.activations >= 2
     s.close()
