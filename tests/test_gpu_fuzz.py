@@ -45,6 +45,12 @@ def _case(seed):
     flags |= SWEEP_LIVE_SEGMENTS(int(rng.choice([0, 0, 1, 2, 3, 7, 40])))
     env = {"MVHDP_FORCE_MODE": str(rng.choice(["", "optimistic", "classified"])),
            "MVHDP_FORCE_RMAX": str(rng.choice(["", "", "1", "2", "4", "8", "16"]))}
+    # the walk threshold of the chunk head (when a token's word tree is walked, never what it returns): left to the library's
+    # search, or pinned -- 0 = every token up front, > 1 = every tree-branch token on demand, or a random one per view
+    walk = str(rng.choice(["", "", "0", "1.1", "rand"]))             # (drawn last: the shapes of earlier rounds' cases stay)
+    if walk == "rand":
+        walk = ",".join("%.2f" % t for t in rng.uniform(0.0, 1.0, M))
+    env["MVHDP_WALK_THETA"] = walk
     return c, hy, inactive, flags, env, rng
 
 
