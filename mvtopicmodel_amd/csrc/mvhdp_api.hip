@@ -65,13 +65,14 @@ struct mvhdp_ctx {
     int64_t* d_carry[MVHDP_MAXM]{};          // doc_topic_proportions: per view, the entity whose view-m counts score entity d (lazily built)
     unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class, from the last sweep (or the probe)
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
-    // 1-round or 2-round primary variant?  Measured, not tabulated: when the histogram first allows the 1-round variant with an
-    // optimistic overflow pass, it runs for ONE sweep; if its kernel time per token is not better than the 2-round variant's of
-    // the sweep before, the choice goes back to 2 rounds and is not tried again for 20 sweeps.
+    // 1-round or 2-round primary variant?  Measured, not tabulated: once 85 % of the tokens sit in topic lists of at most 64 slots
+    // the 1-round variant runs for ONE sweep (the longer lists on their own class kernels, or -- below 0.5 % -- in an optimistic
+    // overflow pass); if its kernel time per token is not better than the 2-round variant's of the sweep before, the choice goes
+    // back to 2 rounds and is not tried again for 4 sweeps (8, 16, 32 after repeated failures).
     int last_primary = 0;                    // primary variant of the last plain sweep (0: none)
     double last_ns_per_token = 0;            //   and its sweep-kernel time per token
     double two_round_ns_per_token = 0;       // the 2-round variant's time per token just before a 1-round trial
-    long long sweeps_done = 0, one_round_banned_until = 0;
+    long long sweeps_done = 0, one_round_banned_until = 0, one_round_ban = 4;
     // Walk threshold of the chunk head (SweepLaunch::walk_theta, in steps of 1/MVHDP_WALK_BINS): which tokens have their word tree
     // walked up front.  It changes when the walk is done, never what is sampled, so it is steered by the clock: sweeps at the current
     // threshold (A) alternate with sweeps a step away (B); B replaces A when its kernel time per token beats the mean of the A sweeps
@@ -1110,12 +1111,13 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         // between sweeps); entities counted twice (overflow re-run) only make the choice more conservative
         std::copy(ovf + 1, ovf + 1 + MVHDP_HIST_BINS, h->last_hist);
         h->rmax_hint = rmax_from_hist(ovf + 1);
-        if (h->rmax_hint == 1) {
-            // proposed by the table: taken only if almost nothing would overflow it (no classify pass for a 1-round primary)
-            // and if it is not banned by an earlier measurement
+        if (h->rmax_hint <= 2) {
+            // 1 round or 2?  The 1-round variant is proposed as soon as 85 % of the tokens sit in lists of at most 64 topics
+            // (the others then run on their own class kernels: classified dispatch below) and kept only if the sweep's clock
+            // agrees (the trial at the end of this function); a failed trial bans it for a while.
             double tot = 0, beyond = 0;
             for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)ovf[1 + b]; if (b >= 1) beyond += (double)ovf[1 + b]; }
-            if (beyond > 0.005 * tot || h->sweeps_done < h->one_round_banned_until) h->rmax_hint = 2;
+            h->rmax_hint = (beyond <= 0.15 * tot && h->sweeps_done >= h->one_round_banned_until) ? 1 : 2;
         }
     }
     if (e != hipSuccess) { cleanup(); HIPC(h, e); }
@@ -1182,16 +1184,20 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     st.activations = n_activations; st.reserved = 0;
     // the 1-round trial (see mvhdp_ctx::last_primary): plain full sweeps only, so that the two times are comparable
     h->sweeps_done++;
-    const bool plain = fast && !classified && nseg == 1 && !debug && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) &&
-                       !getenv("MVHDP_FORCE_RMAX") && st.tokens > 0;
+    const bool plain = fast && nseg == 1 && !debug && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) &&
+                       !getenv("MVHDP_FORCE_RMAX") && !getenv("MVHDP_FORCE_MODE") && st.tokens > 0;
     if (plain) {
-        const double ns = (double)ms_k * 1e6 / (double)st.tokens;
+        const double ns = (double)ms_k * 1e6 / (double)st.tokens;    // (a classify pass is inside ms_k)
         if (rmax == 1 && h->last_primary == 2 && h->last_ns_per_token > 0) h->two_round_ns_per_token = h->last_ns_per_token;
         if (rmax == 1 && h->two_round_ns_per_token > 0 && ns > 0.995 * h->two_round_ns_per_token) {
             if (h->rmax_hint == 1) h->rmax_hint = 2;
-            h->one_round_banned_until = h->sweeps_done + 20;
+            h->one_round_banned_until = h->sweeps_done + h->one_round_ban;
+            h->one_round_ban = std::min<long long>(32, h->one_round_ban * 2);
             h->two_round_ns_per_token = 0;
-        } else if (rmax == 1) h->two_round_ns_per_token = 0;         // the trial is over: the 1-round variant stays
+        } else if (rmax == 1) {                                      // the trial is over: the 1-round variant stays
+            if (h->two_round_ns_per_token > 0) h->one_round_ban = 4;
+            h->two_round_ns_per_token = 0;
+        }
         h->last_primary = rmax; h->last_ns_per_token = ns;
     } else h->last_primary = 0;
     // the walk-threshold search (see mvhdp_ctx::walk_i): among sweeps of one kernel configuration and update mode only
