@@ -77,13 +77,17 @@ struct mvhdp_ctx {
     // walked up front.  It changes when the walk is done, never what is sampled, so it is steered by the clock: sweeps at the current
     // threshold (A) alternate with sweeps a step away (B); B replaces A when its kernel time per token beats the mean of the A sweeps
     // on either side (the chain's own drift cancels).  An upward step is as long as the last sweep's histogram of the tree-branch
-    // tokens' u1 says is nearly free (<= 0.4 % of the tokens more to walk on demand), a downward step is one bin.  A step that does
+    // tokens' u1 says is nearly free (<= 0.4 % of the tokens more to walk on demand; the allowance doubles after a step that paid
+    // more than 0.8 % and halves after a long step that did not pay), a downward step is one bin.  A step that does
     // not pay turns the search around; two in a row let it rest for a growing number of sweeps, and the first B sweep after a rest
     // tries half the threshold (a slope too shallow for single steps to see, e.g. where the kernel is not bandwidth-bound and
     // the best threshold is 0).  Views where most tokens take the tree branch anyway (walk_f >= 0.35) are always walked.
     int walk_i = 0, walk_probe_i = 0, walk_b_i = 0, walk_phase = 0, walk_dir = 1, walk_fails = 0, walk_wait = 4, walk_cfg = -1, walk_maxj = 6;
     bool walk_far = false;                   // the next B sweep after a rest tries half the threshold (slopes too shallow for single steps)
     double walk_ns_a1 = 0.0, walk_ns_b = 0.0;
+    int walk_cls = 1, walk_i_by[2] = {-1, -1}; // the threshold is kept per variant class ([0] the 1-round variant, [1] the wider ones; -1: inherits on first use)
+    bool one_round_retry = false;            // the 1-round trial failed at a low threshold: one more sweep at a high one before the ban
+    double walk_cap = 0.004;                 // share of the tokens an upward step may add to the walks on demand: doubles after a step that paid well
     long long walk_idle_until = 0, walk_refresh_at = 0;
     double walk_f[MVHDP_MAXM] = {-1, -1, -1, -1, -1, -1, -1, -1};   // tree-branch share per view in the last sweep (< 0: not known yet)
     double walk_hist[MVHDP_WALK_BINS] = {0};  // tree-branch tokens of those views by u1 bin, as a share of all tokens (last sweep)
@@ -715,45 +719,6 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     sl.nk_global = ((size_t)M * K * sizeof(int) > 24 * 1024) ? 1 : 0;
     sl.block_shared_bytes = (uint32_t)((((size_t)(sl.nk_global ? 0 : M * K) + MVHDP_HIST_BINS + MVHDP_MAXM * MVHDP_VIEW_STATS) * sizeof(int) + 15) & ~(size_t)15);
     const bool debug = dbg != nullptr;
-    // walk thresholds of this sweep (see mvhdp_ctx::walk_i) and the kernel flavour that goes with them
-    const char* theta_env = getenv("MVHDP_WALK_THETA");         // diagnostics: "t0,t1,..." fixes the thresholds
-    auto walk_controlled = [&](int m) { return h->walk_f[m] >= 0.0 && h->walk_f[m] < 0.35; };
-    bool walk_any = false, walk_unknown = false;                 // (walk_f < 0: not measured yet)
-    for (int m = 0; m < M; m++) { walk_any = walk_any || walk_controlled(m); walk_unknown = walk_unknown || h->walk_f[m] < 0.0; }
-    if (theta_env) {
-        int m = 0;
-        for (const char* q = theta_env; *q && m < MVHDP_MAXM; m++) {
-            sl.walk_theta[m] = atof(q);
-            while (*q && *q != ',') q++;
-            if (*q == ',') q++;
-        }
-        for (; m < MVHDP_MAXM; m++) sl.walk_theta[m] = 0.0;
-        sl.walk = 1;
-    } else {
-        const int top = MVHDP_WALK_BINS * 17 / 20;               // thresholds up to 0.85
-        h->walk_probe_i = h->walk_i;
-        if (h->walk_phase == 1 && walk_any) {
-            if (h->walk_far && h->walk_i < 4) h->walk_far = false;
-            if (h->walk_far) h->walk_dir = -1;
-            if (h->walk_dir > 0 && h->walk_i >= top) h->walk_dir = -1;
-            if (h->walk_dir < 0 && h->walk_i <= 0) h->walk_dir = 1;
-            if (h->walk_dir > 0) {
-                int j = 1;
-                double extra = h->walk_hist[h->walk_i];
-                while (h->walk_i + j < top && j < h->walk_maxj && extra + h->walk_hist[h->walk_i + j] <= 0.004) { extra += h->walk_hist[h->walk_i + j]; j++; }
-                h->walk_probe_i = h->walk_i + j;
-            } else h->walk_probe_i = h->walk_far ? h->walk_i / 2 : h->walk_i - 1;
-        }
-        sl.walk = 0;
-        for (int m = 0; m < MVHDP_MAXM; m++) {
-            sl.walk_theta[m] = (m < M && walk_controlled(m)) ? (double)h->walk_probe_i / MVHDP_WALK_BINS : 0.0;
-            if (sl.walk_theta[m] > 0.0) sl.walk = 1;
-        }
-        // no view qualifies: look again every 16th sweep (the statistics come from the walk flavour only)
-        if (!walk_any && h->sweeps_done >= h->walk_refresh_at) { sl.walk = 1; h->walk_refresh_at = h->sweeps_done + 16; }
-        if (walk_unknown) sl.walk = 1;                           // the first sweep measures (threshold 0)
-    }
-    if (debug) sl.walk = 1;
     // Primary kernel variant: the register-resident kernel with 64*rmax topic slots per entity that is
     // cheapest for the topic-list histogram of the previous sweep (first time: of a probe pass over z).
     bool fast = !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
@@ -788,6 +753,54 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     //    long sequential chains overlap the bulk instead of following it.
     int pc = 0;                                              // class of the primary variant: rmax == 1 << pc
     while ((1 << pc) < rmax) pc++;
+    // walk thresholds of this sweep (see mvhdp_ctx::walk_i) and the kernel flavour that goes with them
+    const char* theta_env = getenv("MVHDP_WALK_THETA");         // diagnostics: "t0,t1,..." fixes the thresholds
+    {   // the 1-round variant and the wider ones want different thresholds: each keeps its own
+        const int cls = (fast && rmax == 1) ? 0 : 1;
+        if (cls != h->walk_cls) {
+            h->walk_i_by[h->walk_cls] = h->walk_i;
+            if (h->walk_i_by[cls] >= 0) h->walk_i = h->walk_i_by[cls];
+            h->walk_cls = cls;
+            h->walk_phase = 0; h->walk_far = false;
+        }
+    }
+    auto walk_controlled = [&](int m) { return h->walk_f[m] >= 0.0 && h->walk_f[m] < 0.35; };
+    bool walk_any = false, walk_unknown = false;                 // (walk_f < 0: not measured yet)
+    for (int m = 0; m < M; m++) { walk_any = walk_any || walk_controlled(m); walk_unknown = walk_unknown || h->walk_f[m] < 0.0; }
+    if (theta_env) {
+        int m = 0;
+        for (const char* q = theta_env; *q && m < MVHDP_MAXM; m++) {
+            sl.walk_theta[m] = atof(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        for (; m < MVHDP_MAXM; m++) sl.walk_theta[m] = 0.0;
+        sl.walk = 1;
+    } else {
+        const int top = MVHDP_WALK_BINS;                         // thresholds up to 1 (= no token of the view walked up front)
+        h->walk_probe_i = h->walk_i;
+        if (h->walk_phase == 1 && walk_any) {
+            if (h->walk_far && h->walk_i < 4) h->walk_far = false;
+            if (h->walk_far) h->walk_dir = -1;
+            if (h->walk_dir > 0 && h->walk_i >= top) h->walk_dir = -1;
+            if (h->walk_dir < 0 && h->walk_i <= 0) h->walk_dir = 1;
+            if (h->walk_dir > 0) {
+                int j = 1;
+                double extra = h->walk_hist[h->walk_i];
+                while (h->walk_i + j < top && j < h->walk_maxj && extra + h->walk_hist[h->walk_i + j] <= h->walk_cap) { extra += h->walk_hist[h->walk_i + j]; j++; }
+                h->walk_probe_i = h->walk_i + j;
+            } else h->walk_probe_i = h->walk_far ? h->walk_i / 2 : h->walk_i - 1;
+        }
+        sl.walk = 0;
+        for (int m = 0; m < MVHDP_MAXM; m++) {
+            sl.walk_theta[m] = (m < M && walk_controlled(m)) ? (double)h->walk_probe_i / MVHDP_WALK_BINS : 0.0;
+            if (sl.walk_theta[m] > 0.0) sl.walk = 1;
+        }
+        // no view qualifies: look again every 16th sweep (the statistics come from the walk flavour only)
+        if (!walk_any && h->sweeps_done >= h->walk_refresh_at) { sl.walk = 1; h->walk_refresh_at = h->sweeps_done + 16; }
+        if (walk_unknown) sl.walk = 1;                           // the first sweep measures (threshold 0)
+    }
+    if (debug) sl.walk = 1;
     int64_t H = 0;                                           // entities that may exceed the primary variant
     bool classified = false;
     if (fast && h->d_doc_order && !h->tokens_desc.empty()) {
@@ -1190,13 +1203,23 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         const double ns = (double)ms_k * 1e6 / (double)st.tokens;    // (a classify pass is inside ms_k)
         if (rmax == 1 && h->last_primary == 2 && h->last_ns_per_token > 0) h->two_round_ns_per_token = h->last_ns_per_token;
         if (rmax == 1 && h->two_round_ns_per_token > 0 && ns > 0.995 * h->two_round_ns_per_token) {
-            if (h->rmax_hint == 1) h->rmax_hint = 2;
-            h->one_round_banned_until = h->sweeps_done + h->one_round_ban;
-            h->one_round_ban = std::min<long long>(32, h->one_round_ban * 2);
-            h->two_round_ns_per_token = 0;
+            const int high = MVHDP_WALK_BINS * 4 / 5;
+            if (!h->one_round_retry && !theta_env && walk_any && h->walk_cls == 0 && h->walk_i < high) {
+                // The 1-round variant is the bandwidth-bound one: it gets its edge from a HIGH walk threshold, and the search
+                // has not taken it there yet (it inherits nothing from the wider variants).  One more sweep at 0.8 decides.
+                h->one_round_retry = true;
+                h->walk_i = high; h->walk_phase = 0; h->walk_idle_until = h->sweeps_done + 1;
+            } else {
+                h->one_round_retry = false;
+                if (h->rmax_hint == 1) h->rmax_hint = 2;
+                h->one_round_banned_until = h->sweeps_done + h->one_round_ban;
+                h->one_round_ban = std::min<long long>(32, h->one_round_ban * 2);
+                h->two_round_ns_per_token = 0;
+            }
         } else if (rmax == 1) {                                      // the trial is over: the 1-round variant stays
             if (h->two_round_ns_per_token > 0) h->one_round_ban = 4;
             h->two_round_ns_per_token = 0;
+            h->one_round_retry = false;
         }
         h->last_primary = rmax; h->last_ns_per_token = ns;
     } else h->last_primary = 0;
@@ -1230,10 +1253,12 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
                 h->walk_ns_a1 = h->walk_ns_b;                            // the B sweep is the first A sweep of the next step
                 h->walk_fails = 0; h->walk_wait = 4; h->walk_phase = 1;
                 if (step > 0) h->walk_maxj = std::min(6, h->walk_maxj * 2);
+                if (step > 0 && h->walk_ns_b < base * (1.0 - 0.008)) h->walk_cap = std::min(0.05, h->walk_cap * 2.0);
                 if (far) h->walk_far = true;                             // half again
             } else if (step > 1) {                                       // a long step that did not pay: a shorter one, same direction
                 h->walk_ns_a1 = ns;
                 h->walk_maxj = std::max(1, step / 2);
+                h->walk_cap = std::max(0.004, h->walk_cap * 0.5);
                 h->walk_phase = 1;
             } else if (far) {                                            // half the threshold is no better: back to single steps
                 h->walk_ns_a1 = ns;
