@@ -735,6 +735,13 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             h->rmax_hint = rmax_from_hist(hist + 1);
         }
         rmax = h->rmax_hint;
+        if (rmax == 1 && (nseg != 1 || dbg || (flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)))) {
+            // an early 1-round proposal (15 % of the tokens still in longer lists) stands only where the clock can confirm it;
+            // this sweep cannot be timed against its neighbours (segments, debug, frozen): the old rule, at most 0.5 % beyond
+            double tot = 0, beyond = 0;
+            for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b >= 1) beyond += (double)h->last_hist[b]; }
+            if (beyond > 0.005 * tot && S_cap > 64) rmax = 2;
+        }
         if (const char* f = getenv("MVHDP_FORCE_RMAX")) { int v = atoi(f); if (v >= 1 && v <= 16) rmax = v; }   // diagnostics only
         if (rmax > 16) fast = false;
         else {

@@ -1,9 +1,11 @@
 """Per-token memory-side counters of the sweep kernels over the timed sweeps of `bench.py --steps 20 --warmup 5` (profiles/pmc_r02b.sh).
-A sweep is one primary kernel (sweep_fast_kernel<1|2|4,...>) plus its overflow passes; the first 5 sweeps are the warm-up."""
+A sweep is what runs between two build_trees_kernel launches (all sweep kernels of every class / overflow pass); the first 5
+sweeps are the warm-up."""
 import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -16,18 +18,20 @@ for d in sorted(glob.glob(f"{out_dir}/s[0-9]*")):
         continue
     rows = collections.defaultdict(dict)
     names = {}
-    for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+    files = sorted(glob.glob(f"{d}/*/*_counter_collection.csv"), key=os.path.getmtime)
+    for f in files[-1:]:                     # (gpurun_out/ keeps the files of earlier runs of the recipe: the newest only)
         for r in csv.DictReader(open(f)):
+            k = int(r["Dispatch_Id"])
+            names[k] = r["Kernel_Name"]
             if "sweep_fast_kernel" in r["Kernel_Name"] or "sweep_kernel" in r["Kernel_Name"]:
-                k = int(r["Dispatch_Id"])
                 rows[k][r["Counter_Name"]] = rows[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-                names[k] = r["Kernel_Name"]
+    # a deferred sweep starts with ONE build_trees_kernel launch (then the view weights, a classify pass if any, the sweep
+    # kernels of every class / overflow pass, the apply): the sweep kernels between two of them belong to one sweep
     sweep = -1
-    for k in sorted(rows):
-        m = re.search(r"sweep_fast_kernel<(\d+)", names[k])
-        if m and int(m.group(1)) <= 4:
-            sweep += 1                      # a primary kernel opens a sweep
-        if WARM <= sweep < WARM + STEPS:
+    for k in sorted(names):
+        if names[k].startswith("build_trees_kernel"):
+            sweep += 1
+        if k in rows and WARM <= sweep < WARM + STEPS:
             for c, v in rows[k].items():
                 tot[c] += v
     tot["_sweeps_seen_" + d.rsplit("/", 1)[1]] = sweep + 1
