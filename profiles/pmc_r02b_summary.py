@@ -11,7 +11,7 @@ import sys
 
 out_dir = sys.argv[1]
 TOK = 147225025
-WARM, STEPS = 5, 20
+WARM, STEPS = int(os.environ.get("PMC_WARM", "5")), int(os.environ.get("PMC_STEPS", "20"))   # the bench command's --warmup / --steps
 tot = collections.defaultdict(float)
 for d in sorted(glob.glob(f"{out_dir}/s[0-9]*")):
     if d.endswith(".log"):
