@@ -215,6 +215,8 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMalloc(&mm.counts, cbytes));
     CREATE_HIP(hipMalloc(&mm.delta, cbytes));
     CREATE_HIP(hipMemset(mm.counts, 0, cbytes));
+    CREATE_HIP(hipMalloc(&mm.counts16, (size_t)nrows * K * sizeof(uint16_t)));
+    CREATE_HIP(hipMemset(mm.counts16, 0, (size_t)nrows * K * sizeof(uint16_t)));
     CREATE_HIP(hipMemset(mm.delta, 0, cbytes));
     CREATE_HIP(hipMalloc(&mm.trees, (size_t)nrows * 2 * K * sizeof(double)));
     CREATE_HIP(hipMalloc(&mm.root, (size_t)nrows * sizeof(double)));
@@ -255,7 +257,7 @@ static void release_device_resources(mvhdp_ctx* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
     for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); }
-    fr(h->mm.counts); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
+    fr(h->mm.counts); fr(h->mm.counts16); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
     fr(h->d_alpha); fr(h->d_inactive); fr(h->d_stats); fr(h->d_act_key); fr(h->d_doc_counter);
     fr(h->d_doc_order); fr(h->d_overflow); fr(h->d_overflow2); fr(h->d_ovf_meta); fr(h->d_lists);
     for (auto& e : h->ev) if (e) { hipEventDestroy(e); e = nullptr; }
@@ -808,6 +810,12 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         if (walk_unknown) sl.walk = 1;                           // the first sweep measures (threshold 0)
     }
     if (debug) sl.walk = 1;
+    // the 16-bit mirror of n_wk (written with the trees) for the 1-round walk flavour -- the bandwidth-bound one: half the lines
+    // of every gathered row.  Needs the mirror to be this sweep's start counts: trees built in this call or still current, and
+    // no live updates (the mirror is a snapshot).
+    sl.narrow = (fast && rmax == 1 && sl.walk && !debug && !live &&
+                 (!(flags & MVHDP_SWEEP_REUSE_TREES) || h->have_trees)) ? 1 : 0;
+    if (const char* f = getenv("MVHDP_NARROW")) sl.narrow = (sl.narrow && atoi(f) != 0) ? 1 : 0;     // diagnostics: 0 switches it off
     int64_t H = 0;                                           // entities that may exceed the primary variant
     bool classified = false;
     if (fast && h->d_doc_order && !h->tokens_desc.empty()) {

@@ -21,6 +21,8 @@ struct MvModel {
     int32_t* z[MVHDP_MAXM];
     // model: counts = [sumV*K n_wk | M*K n_k], delta same layout
     int32_t* counts;
+    uint16_t* counts16;                // [sumV*K] min(n_wk, 65535): written row by row whenever the row's tree is built (build_trees_kernel),
+                                       //   so it is the sweep-start n_wk of every sweep that starts with the trees; read by the NARROW kernel flavour
     int32_t* delta;
     double* trees;                     // [sumV][2K]  FTree.tree (FT:21)
     double* root;                      // [sumV]      tree[1]
@@ -68,6 +70,7 @@ struct SweepLaunch {
     // arithmetic, same result.  0 = walk every token.
     double walk_theta[MVHDP_MAXM];
     int32_t walk;                      // 1: launch the kernel flavour that knows about thresholds (and counts the per-view statistics)
+    int32_t narrow;                    // 1: the flavour that gathers n_wk from the 16-bit mirror (1-round walk flavour only; never with LIVE)
     unsigned long long* slot_hist;     // [17] tokens of the entities with ceil(list size/64) = 1..16, >16 (sizes the next sweep's variant)
     // debug
     double* tok_dbg[MVHDP_MAXM];

@@ -85,12 +85,14 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         const int32_t* nk = nk_all + (int64_t)m * K;
         const double* al = mm.alpha + (int64_t)m * (K + 1);
         const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
+        uint16_t* c16 = mm.counts16 ? mm.counts16 + row * K : nullptr;
         for (int k = lane; k < K; k += WAVE) {
             int c = cnt[k];
             if (apply_first) {
                 const int d = dl[k];
                 if (d) { c += d; cnt[k] = c; dl[k] = 0; neg += c < 0; }    // UPD:202-215 logs a negative count; here it is reported
             }
+            if (c16) c16[k] = (uint16_t)(c < 0 ? 0 : c > 65535 ? 65535 : c);   // the 16-bit mirror: 65535 = "look in the 32-bit table"
             double leaf;
             if (inference_leaves) {                                // INF:576: p_wt alone
                 leaf = ((double)c + beta) / ((double)nk[k] + beta_sum);

@@ -54,7 +54,10 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 // WALK: the flavour with the thresholded tree walk of the chunk head (SweepLaunch::walk_theta), the walk on demand in the token
 // loop and the per-view branch statistics the threshold search feeds on.  Without it every token is walked up front and nothing
 // is counted: where the best threshold is 0 (C2, C3) that code is 2-5 % faster for not carrying the rest.
-template <int RMAX, bool DEBUG, bool WALK>
+// NARROW (1-round walk flavour only): the n_wk gather reads the 16-bit mirror of the counts (MvModel::counts16, written with the
+// trees at the start of the sweep) -- half the lines of the row; a saturated value (65535) sends the lane to the 32-bit table.
+// Same numbers, so same results; not for MVHDP_SWEEP_LIVE (the mirror is a snapshot).
+template <int RMAX, bool DEBUG, bool WALK, bool NARROW>
 __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : 1))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 
     // no __restrict__: with MVHDP_SWEEP_LIVE the atomics below update this very array (mm.delta == mm.counts)
     const int32_t* nwk = mm.counts;
+    const uint16_t* nwk16 = mm.counts16;
     const int32_t* nk_all = mm.counts + mm.rowbase[M] * K;
     int32_t* dnwk = mm.delta;
 
@@ -323,9 +327,14 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     const int w0 = bcast_i(w_l, min(a, nt - 1));
                     const int64_t r0 = row0 + max(w0, 0);
                     const char* __restrict__ c0p = (const char*)(nwk + r0 * K);
+                    const char* __restrict__ c0q = (const char*)(nwk16 + r0 * K);
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) {
-                        const int v = (NB == 2 || r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
+                        int v;
+                        if (NARROW) {
+                            v = (int)*(const uint16_t*)(c0q + (koff[r] >> 1));
+                            if (v == 65535) v = *(const int32_t*)(c0p + koff[r]);
+                        } else v = (NB == 2 || r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
                         if (a == 0) gn[r] = v; else gn2[r] = v;
                     }
                 }
@@ -421,12 +430,14 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #undef sn_get
 #undef sn_set
 
-// debug launches always take the WALK flavour (one instantiation fewer per variant; a threshold of 0 walks every token)
+// debug launches always take the WALK flavour (one instantiation fewer per variant; a threshold of 0 walks every token);
+// the NARROW flavour exists for the 1-round walk kernel only
 template <int RMAX>
-static const void* fast_kernel_ptr(bool debug, bool walk)
+static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow)
 {
-    return debug ? (const void*)sweep_fast_kernel<RMAX, true, true>
-                 : walk ? (const void*)sweep_fast_kernel<RMAX, false, true> : (const void*)sweep_fast_kernel<RMAX, false, false>;
+    if (RMAX == 1 && narrow && walk && !debug) return (const void*)sweep_fast_kernel<1, false, true, true>;
+    return debug ? (const void*)sweep_fast_kernel<RMAX, true, true, false>
+                 : walk ? (const void*)sweep_fast_kernel<RMAX, false, true, false> : (const void*)sweep_fast_kernel<RMAX, false, false, false>;
 }
 
 template <int RMAX>
@@ -434,13 +445,15 @@ static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid
 {
     size_t lds = sl.block_shared_bytes + (size_t)sl.waves_per_block * sl.wave_bytes;
     dim3 block(64 * sl.waves_per_block);
+    const bool narrow = RMAX == 1 && sl.narrow && sl.walk && !debug;
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0, narrow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
-    else if (sl.walk) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true>), dim3(grid_blocks), block, lds, s, mm, sl);
-    else              hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, false>), dim3(grid_blocks), block, lds, s, mm, sl);
+    if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else if (narrow)  hipLaunchKernelGGL((sweep_fast_kernel<1, false, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else if (sl.walk) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else              hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, false, false>), dim3(grid_blocks), block, lds, s, mm, sl);
     return hipGetLastError();
 }
 
@@ -480,7 +493,7 @@ static int blocks_per_cu_from(const void* func, int threads, size_t lds)
 template <int RMAX>
 static int occ_fast(bool debug, bool walk, int threads, size_t lds)
 {
-    return blocks_per_cu_from(fast_kernel_ptr<RMAX>(debug, walk), threads, lds);
+    return blocks_per_cu_from(fast_kernel_ptr<RMAX>(debug, walk, false), threads, lds);
 }
 
 int mvhdp_sweep_fast_occupancy(int rmax, bool debug, bool walk, int block_threads, size_t lds_bytes)

@@ -92,3 +92,30 @@ def test_threshold_search_never_changes_the_chain():
         s.sweep(it, 99)
         assert_same_state(o, s, c.M)
     s.close()
+
+
+@pytest.mark.parametrize("narrow", ["1", "0"])
+def test_16_bit_mirror_of_the_counts_including_saturated_cells(monkeypatch, narrow):
+    """The 1-round walk flavour gathers n_wk from the 16-bit mirror the tree build writes (MvModel::counts16); a cell
+    that does not fit 16 bits reads 65535 there and is fetched from the 32-bit table.  Two types and 600 k tokens put
+    most cells far beyond 65535; the sweep must still be the oracle's (and the same with the mirror switched off)."""
+    monkeypatch.setenv("MVHDP_WALK_THETA", "0.5")           # the walk flavour (a threshold of 0 would run the plain one)
+    monkeypatch.setenv("MVHDP_NARROW", narrow)
+    from mvtopicmodel_amd.synth import Corpus
+    K, V, D = 6, [2], 3000
+    rng = np.random.RandomState(5)
+    lens = np.full(D, 200, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    tok = (rng.rand(off[-1]) < 0.7).astype(np.int32)
+    c = Corpus(K, V, [off], [tok])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z0 = [o.get_assignments(0)]
+    s = make_native(c, hy, z0)
+    assert s.get_counts(0)[0].max() > 65535
+    for it in range(2):
+        ro = o.sweep(it, 4)
+        rs = s.sweep(it, 4)
+        assert ro["stats"]["word_ftree_mass_cnt"] == rs.word_ftree_mass_cnt and ro["stats"]["changed"] == rs.changed
+        assert_same_state(o, s, 1)
+    s.close()
