@@ -55,8 +55,10 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 // loop and the per-view branch statistics the threshold search feeds on.  Without it every token is walked up front and nothing
 // is counted: where the best threshold is 0 (C2, C3) that code is 2-5 % faster for not carrying the rest.
 // NARROW (1-round walk flavour only): the n_wk gather reads the 16-bit mirror of the counts (MvModel::counts16, written with the
-// trees at the start of the sweep) -- half the lines of the row; a saturated value (65535) sends the lane to the 32-bit table.
-// Same numbers, so same results; not for MVHDP_SWEEP_LIVE (the mirror is a snapshot).
+// trees at the start of the sweep) -- half the lines of the row; a saturated value (65535) sends the lane to the 32-bit table,
+// checked when the value is used, not when the gather is issued (the prefetch for the next token stays asynchronous).
+// Same numbers, so same results; not for MVHDP_SWEEP_LIVE (the mirror is a snapshot).  The 2-round variant is 4 % slower
+// with it (two 2-byte loads per lane cost it more than the lines are worth): 32-bit gathers there.
 template <int RMAX, bool DEBUG, bool WALK, bool NARROW>
 __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : 1))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
@@ -331,10 +333,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) {
                         int v;
-                        if (NARROW) {
-                            v = (int)*(const uint16_t*)(c0q + (koff[r] >> 1));
-                            if (v == 65535) v = *(const int32_t*)(c0p + koff[r]);
-                        } else v = (NB == 2 || r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
+                        if (NARROW) v = (int)*(const uint16_t*)(c0q + (koff[r] >> 1));          // (a saturated cell is resolved at use)
+                        else v = (NB == 2 || r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
                         if (a == 0) gn[r] = v; else gn2[r] = v;
                     }
                 }
