@@ -65,7 +65,7 @@ struct mvhdp_ctx {
     int64_t* d_carry[MVHDP_MAXM]{};          // doc_topic_proportions: per view, the entity whose view-m counts score entity d (lazily built)
     unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class, from the last sweep (or the probe)
     int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
-    // 1-round or 2-round primary variant?  Measured, not tabulated: once 85 % of the tokens sit in topic lists of at most 64 slots
+    // 1-round or 2-round primary variant?  Measured, not tabulated: once half of the tokens sit in topic lists of at most 64 slots
     // the 1-round variant runs for ONE sweep (the longer lists on their own class kernels, or -- below 0.5 % -- in an optimistic
     // overflow pass); if its kernel time per token is not better than the 2-round variant's of the sweep before, the choice goes
     // back to 2 rounds and is not tried again for 4 sweeps (8, 16, 32 after repeated failures).
@@ -738,7 +738,7 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         }
         rmax = h->rmax_hint;
         if (rmax == 1 && (nseg != 1 || dbg || (flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)))) {
-            // an early 1-round proposal (15 % of the tokens still in longer lists) stands only where the clock can confirm it;
+            // an early 1-round proposal (up to half of the tokens still in longer lists) stands only where the clock can confirm it;
             // this sweep cannot be timed against its neighbours (segments, debug, frozen): the old rule, at most 0.5 % beyond
             double tot = 0, beyond = 0;
             for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b >= 1) beyond += (double)h->last_hist[b]; }
@@ -1140,12 +1140,12 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         std::copy(ovf + 1, ovf + 1 + MVHDP_HIST_BINS, h->last_hist);
         h->rmax_hint = rmax_from_hist(ovf + 1);
         if (h->rmax_hint <= 2) {
-            // 1 round or 2?  The 1-round variant is proposed as soon as 85 % of the tokens sit in lists of at most 64 topics
+            // 1 round or 2?  The 1-round variant is proposed as soon as half of the tokens sit in lists of at most 64 topics
             // (the others then run on their own class kernels: classified dispatch below) and kept only if the sweep's clock
             // agrees (the trial at the end of this function); a failed trial bans it for a while.
             double tot = 0, beyond = 0;
             for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)ovf[1 + b]; if (b >= 1) beyond += (double)ovf[1 + b]; }
-            h->rmax_hint = (beyond <= 0.15 * tot && h->sweeps_done >= h->one_round_banned_until) ? 1 : 2;
+            h->rmax_hint = (beyond <= 0.5 * tot && h->sweeps_done >= h->one_round_banned_until) ? 1 : 2;
         }
     }
     if (e != hipSuccess) { cleanup(); HIPC(h, e); }
