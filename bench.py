@@ -211,8 +211,9 @@ def main():
             traffic_note = (f"{bpt_meas:.0f} B/token = TCC_EA0_RDREQ x 128 B (= 2 x FETCH_SIZE: the gfx950 correction, calibrated "
                             "on this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits "
                             "included; PMC passes of profiles/pmc_r02b.sh over the 20 timed sweeps of `--steps 20 --warmup 5` "
-                            "(a rocprofv3 run of its own; the walk threshold of the chunk head moves during those sweeps, so the "
-                            "per-token figure belongs to that window), the rate is this run's")
+                            "(a rocprofv3 run of its own; the walk threshold of the chunk head moves during those sweeps and the "
+                            "1-round kernel with its 16-bit mirror of the counts takes over at sweep 13, so the per-token figure "
+                            "belongs to that window and is BELOW the algorithmic 4K+8 bytes, which assume 4-byte counts), the rate is this run's")
     except Exception:
         pass
     out = {
