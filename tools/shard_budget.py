@@ -51,6 +51,7 @@ def exact(args):
         g.counts_written()
     chunks, _ = shards[0].row_chunks(PIPELINE_CHUNKS)
     ph = {"sweep_call_host": 0.0, "sweep_kernel_dev": 0.0, "apply_and_trees_host": 0.0}
+    per_sweep = []                                    # rank 0's sweep-kernel ms, every sweep (warm-up included)
     for it in range(args.warmup + args.steps):
         sts = []
         for r, g in enumerate(shards):
@@ -58,6 +59,8 @@ def exact(args):
             st = g.sweep_local(it, 1, SWEEP_REUSE_TREES if g.trees_current() else 0)
             t1 = time.perf_counter()
             sts.append(st)
+            if r == 0:
+                per_sweep.append(round(st.sweep_kernel_ms, 3))
             if r == 0 and it >= args.warmup:
                 ph["sweep_call_host"] += (t1 - t0) * 1e3; ph["sweep_kernel_dev"] += st.sweep_kernel_ms
         torch.cuda.synchronize()
@@ -77,7 +80,7 @@ def exact(args):
                 ph["apply_and_trees_host"] += (time.perf_counter() - t0) * 1e3
     out = {k: v / args.steps for k, v in ph.items()}
     nk_fp = [int(np.asarray(shards[0].s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]
-    out.update(workload=args.workload, ranks=args.of, shard0_tokens=int(tot[bounds[0][0]:bounds[0][1]].sum()), final_nk_fingerprint=nk_fp,
+    out.update(rank0_sweep_kernel_ms_per_sweep=per_sweep, workload=args.workload, ranks=args.of, shard0_tokens=int(tot[bounds[0][0]:bounds[0][1]].sum()), final_nk_fingerprint=nk_fp,
                note="all shards on one GPU, true global counts; rank 0's calls timed; the collective itself is not (device-side sum instead)")
     print(json.dumps(out))
     for g in shards:
@@ -148,7 +151,7 @@ def main():
             ph["sweep_call_host"] += (t1 - t0) * 1e3; ph["apply_host"] += (t2 - t1) * 1e3
             ph["sweep_kernel_dev"] += st.sweep_kernel_ms; ph["sweep_total_dev"] += st.total_ms
     out = {k: v / args.steps for k, v in ph.items()}
-    out.update(workload=args.workload, ranks=args.of, shard_entities=c.D, shard_tokens=c.total_tokens,
+    out.update(rank0_sweep_kernel_ms_per_sweep=per_sweep, workload=args.workload, ranks=args.of, shard_entities=c.D, shard_tokens=c.total_tokens,
                per_rank_ms_without_collective=out["sweep_call_host"] + out["apply_host"],
                delta_bytes=int(shard.delta.numel() * 4), mode="live" if args.live else "deferred",
                sequence="plain" if args.plain else "pipelined (apply + tree rebuild by row ranges, hidden behind the collective on a real run)")
