@@ -62,8 +62,8 @@ def cpu_baseline(workload, sample_docs, iters, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C4")
     ap.add_argument("--docs", type=int, default=None, help="override the entity count (smoke runs)")
     ap.add_argument("--seed", type=int, default=20260101)
