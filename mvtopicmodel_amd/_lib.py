@@ -58,6 +58,63 @@ class DebugC(C.Structure):
 
 
 _lib = None
+_preloaded = []            # keeps the handles of the runtime libraries loaded on the library's behalf alive
+
+
+def _torch_lib_dir():
+    """Directory of the ROCm runtime libraries a PyTorch-ROCm wheel bundles (None when torch is not installed).
+    Found from the package's location alone: torch is NOT imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    return d if os.path.isdir(d) else None
+
+
+def mapped_runtime_libraries():
+    """{'libamdhip64': [paths], 'libhsa-runtime64': [paths], 'librccl': [paths]} from /proc/self/maps: the distinct
+    files of each ROCm runtime library mapped into this process."""
+    found = {"libamdhip64": set(), "libhsa-runtime64": set(), "librccl": set()}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                base = os.path.basename(path)
+                for name in found:
+                    if base.startswith(name + ".so"):
+                        found[name].add(os.path.realpath(path))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+def _preload_one_hip_runtime():
+    """One HIP runtime per process, whatever is imported first.
+
+    libmvhdp.so needs `libamdhip64.so.7` (RUNPATH /opt/rocm/lib); a PyTorch-ROCm wheel bundles its own copy with the
+    SAME soname but asks for it by the file name `libamdhip64.so`, which the loader does not match against an already
+    mapped `libamdhip64.so.7` from /opt/rocm: a process that creates a sampler first and touches torch.cuda later ends up
+    with two HIP runtimes over two ROCr copies, and torch then fails with "No HIP GPUs are available".  The other order
+    is fine (libmvhdp's `libamdhip64.so.7` matches the soname of torch's copy).  So when a torch wheel with a bundled
+    runtime is installed, its libamdhip64.so is mapped FIRST,
+    process-wide, and both libmvhdp.so and a later `import torch` resolve to that one copy.  A host without torch (the
+    Java host of INTEGRATION.md) is not affected: the library then runs on /opt/rocm's runtime."""
+    d = _torch_lib_dir()
+    if d is None:
+        return
+    path = os.path.join(d, "libamdhip64.so")
+    if os.path.exists(path):
+        _preloaded.append(C.CDLL(path, mode=C.RTLD_GLOBAL))
+    # RCCL is opened by the library itself, lazily, in mvhdp_group_create (dlopen by soname: a copy torch has mapped
+    # already is re-used).  When torch is installed but not imported yet, point the library at the wheel's copy so that
+    # a later `import torch` maps the same file (mapping it here, process-wide and ahead of torch, aborts at exit).
+    rccl = os.path.join(d, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("MVHDP_RCCL_LIB", rccl)
 
 
 def load_library():
@@ -69,7 +126,15 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C mvtopicmodel_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    _preload_one_hip_runtime()
     L = C.CDLL(LIB_PATH)
+    maps = mapped_runtime_libraries()
+    for name in ("libamdhip64", "libhsa-runtime64"):
+        if len(maps[name]) > 1:
+            raise ImportError(
+                f"two copies of {name} are mapped into this process ({', '.join(maps[name])}): a HIP runtime was loaded "
+                "before mvtopicmodel_amd could pick one.  Import mvtopicmodel_amd (or torch) before any other library "
+                "that links /opt/rocm's libamdhip64 in a process that also uses torch.")
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
     L.mvhdp_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.mvhdp_destroy.argtypes = [vp]

@@ -79,3 +79,22 @@ def test_activation_key_layout_is_defined_once():
     for name in ("REUSE_TREES", "NO_APPLY", "EXACT_CHAIN", "GENERIC_KERNEL", "FROZEN", "LIVE", "SEGMENT_APPLY"):
         assert getattr(native, "SWEEP_" + name) == int(re.search(r"#define\s+MVHDP_SWEEP_%s\s+(0x[0-9a-fA-F]+)u" % name, hdr).group(1), 16)
     assert native.SWEEP_LIVE_SEGMENTS(5) == 5 << 16
+
+
+def test_one_hip_runtime_whatever_is_loaded_first():
+    """The library first, torch second (the order that used to leave two HIP runtimes mapped): one
+    libamdhip64 and one libhsa-runtime64 in the process, and torch.cuda still answers."""
+    import subprocess
+    import sys
+    code = (
+        "import sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from mvtopicmodel_amd import _lib\n"
+        "_lib.load_library()\n"
+        "import torch\n"
+        "torch.cuda.is_available()\n"
+        "m = _lib.mapped_runtime_libraries()\n"
+        "assert len(m['libamdhip64']) == 1 and len(m['libhsa-runtime64']) <= 1, m\n"
+        "print('one runtime', m['libamdhip64'][0])\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "one runtime" in r.stdout, (r.returncode, r.stdout, r.stderr)

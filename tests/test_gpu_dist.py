@@ -160,3 +160,39 @@ def test_shards_on_one_gpu_equal_single_shard():
                 assert np.array_equal(a, o.get_counts(m)[0]) and np.array_equal(b, o.get_counts(m)[1])
     for sh in shards:
         sh.close()
+
+
+def test_sampler_first_torch_second_in_a_fresh_process():
+    """a process that creates a NativeSampler BEFORE anything touches torch.cuda, then a GpuShard and a
+    1-rank RCCL group: the loader keeps one HIP runtime mapped (mvtopicmodel_amd/_lib.py), so torch's lazy init works."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np\n"
+        "from mvtopicmodel_amd import NativeSampler, synth, _lib\n"
+        "from mvtopicmodel_amd.native import Hyper\n"
+        "K, V = 20, [200, 30]\n"
+        "c = synth.generate(K, V, 60, [20, 4], seed=5)\n"
+        "s = NativeSampler(K, V, device=0)\n"
+        "rng = np.random.default_rng(1)\n"
+        "for m in range(2):\n"
+        "    s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, rng.integers(0, K, len(c.tokens[m]), dtype=np.int32))\n"
+        "s.set_hyper(Hyper.defaults(K, V)); s.build_counts(); s.sweep(0, 1)\n"
+        "assert 'torch' not in sys.modules\n"
+        "import torch, torch.distributed as dist\n"
+        "from mvtopicmodel_amd.dist import GpuShard, sweep_all_reduce\n"
+        "assert torch.cuda.is_available()\n"
+        "shard = GpuShard(s, 'cuda:0')\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29631')\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))\n"
+        "st = sweep_all_reduce(shard, 1, 1, force_exchange=True)\n"
+        "assert st.tokens == c.total_tokens\n"
+        "m = _lib.mapped_runtime_libraries()\n"
+        "assert len(m['libamdhip64']) == 1 and len(m['libhsa-runtime64']) == 1, m\n"
+        "dist.destroy_process_group(); shard.close(); s.close()\n"
+        "print('order ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "order ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
