@@ -215,6 +215,12 @@ int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_weights /*[M]
  * Synchronous. */
 int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
                 const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats);
+/* n sweeps, indices first_idx .. first_idx+n-1, enqueued back to back: the iteration loop PTM:1146-1239 without a host
+ * round trip per iteration (one plan for the batch, statistics collected on the device, one synchronisation at the end).
+ * Same integers as n calls of mvhdp_sweep with p_override = dbg = NULL.  stats: [n] or NULL (total_ms is the batch's time / n).
+ * Falls back to n single calls where every sweep needs the host: a model with inactive topics (activation UPD:263-270),
+ * MVHDP_SWEEP_NO_APPLY. */
+int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats /*[n]*/);
 /* n_wk += delta, n_k += delta, delta = 0; also performs the topic activation
  * recorded by the sweep when (topic,modality) >= 0 (multi-GPU: the host passes
  * the winner of the min-reduction over activation_key). */
@@ -234,6 +240,56 @@ int mvhdp_apply_delta_end(mvhdp_handle h, int32_t activated_topic, int32_t activ
 int mvhdp_trees_current(mvhdp_handle h);    /* 1: the F+trees match the counts and hyper-parameters, 0: not, < 0: error */
 /* the per-document view weights used by the last sweep */
 int mvhdp_get_view_weights(mvhdp_handle h, double* p /*[D][M][M]*/);
+
+/* ---- tuning: the sweep's own choices, pinned or carried over ----
+ * None of these changes a result: they decide which kernel variant visits an entity and when a word tree is walked, never
+ * what is sampled.  The library reads the environment ONCE, in mvhdp_create (MVHDP_FORCE_RMAX, MVHDP_NARROW, MVHDP_LIVE16,
+ * MVHDP_WALK_THETA, MVHDP_SINGLE_STREAM, MVHDP_PRIMARY_MIN_SHARE, MVHDP_DEBUG: diagnostics); a host uses this block.
+ * learnt_walk_step / tree_branch_share are what the walk-threshold search has found: read them from one handle
+ * (mvhdp_get_tuning) and hand them to another -- a document shard, a resumed chain -- and it does not search again. */
+typedef struct {
+    int32_t force_primary;                       /* 0: the library chooses; 1,2,4,8,16: primary register variant; 32: generic kernel only */
+    int32_t narrow;                              /* -1: 16-bit mirror of n_wk wherever legal (default); 0: never */
+    int32_t walk_fixed;                          /* 1: walk_theta[] as given, no search */
+    int32_t single_stream;                       /* 1: all class kernels on the handle's stream (diagnostics) */
+    int32_t live16;                              /* MVHDP_SWEEP_LIVE keeps the light n_wk rows current in the 16-bit mirror (half-width gathers): -1 where K >= 256 (default), 0 never, 1 always */
+    int32_t reserved;
+    double  walk_theta[MVHDP_MAX_MODALITIES];    /* with walk_fixed: walk a token's word tree up front iff u1 >= walk_theta[view] */
+    double  primary_min_share;                   /* narrowest kernel class holding this share of the tokens gets its own kernel (0 = default 0.10) */
+    int32_t learnt_walk_step[4];                 /* searched threshold in 1/20 steps per kernel flavour: [0] 1-round variant on the 16-bit mirror, [1] 1-round
+                                                    variant on 32-bit rows, [2] the wider variants; -1: none yet (the library's default); [3] reserved */
+    double  tree_branch_share[MVHDP_MAX_MODALITIES]; /* tree-branch (WRK:533) share of each view's tokens in the last measured sweep; < 0: not measured */
+} mvhdp_tuning;
+int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t);
+int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t);
+
+/* The sweep's planner and its walk-threshold search are pure functions (mvtopicmodel_amd/csrc/mvhdp_plan.h); these two run
+ * them WITHOUT a device or a handle, on recorded inputs (tests/test_plan.py). */
+typedef struct {
+    int32_t num_topics, num_modalities;
+    int64_t num_entities;
+    int64_t max_entity_tokens;                   /* longest entity, all views together */
+    int64_t entities_longer_than[5];             /* entities with more than 64, 128, 256, 512, 1024 tokens */
+    uint64_t tokens_by_list_rounds[17];          /* tokens of the entities whose topic list needs 1..16, >16 rounds of 64 slots */
+    uint64_t entities_by_class[8];               /* entities per kernel class 0..5 (64 << c slots; 5: generic kernel); [6]: list size not known */
+    uint32_t flags;                              /* MVHDP_SWEEP_* */
+    int32_t debug, batch, trees_current;
+    int32_t num_cus;                             /* 0 = 256 */
+    int32_t kernel_registers[6][3];              /* VGPRs of each kernel class: plain, walk flavour, debug build */
+} mvhdp_plan_input;
+typedef struct {
+    int32_t status;                              /* what mvhdp_sweep would return for these flags (MVHDP_OK or an error) */
+    int32_t segments, primary_class, register_resident, need_full_trees, dominant_class;
+    int64_t routed_prefix;                       /* entities of the longest-first order that go through the route pass */
+    int32_t class_used[6], class_map[6], class_stream[6], class_grid[6], class_walk[6], class_narrow[6], class_register_resident[6];
+    int64_t class_lds_bytes[6];
+    double  class_theta0[6];                     /* walk threshold of view 0 for that class's kernel */
+} mvhdp_plan_output;
+int mvhdp_plan_probe(const mvhdp_plan_input* in, const mvhdp_tuning* tuning /* or NULL */, mvhdp_plan_output* out);
+/* The search alone: a kernel whose time per token at threshold step i is ns_by_step[i] (i = 0..20); steps_out[k] = the
+ * threshold step proposed for sweep k. */
+int mvhdp_tuner_probe(int32_t num_modalities, const double* tree_branch_share /*[M]*/, const double* u1_hist /*[20] or NULL*/,
+                      const double* ns_by_step /*[21]*/, int32_t n_sweeps, int32_t group, int32_t* steps_out /*[n_sweeps]*/);
 
 /* ---- interop for collectives and stream sharing ---- */
 int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** dev_ptr, size_t* bytes);

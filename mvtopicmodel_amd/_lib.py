@@ -16,7 +16,8 @@ ABI_SYMBOLS = [
     "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
     "mvhdp_get_count_histogram", "mvhdp_view_overlap_sums", "mvhdp_model_log_likelihood", "mvhdp_doc_topic_proportions",
     "mvhdp_gamma_doc_statistics",
-    "mvhdp_sweep", "mvhdp_apply_delta", "mvhdp_apply_delta_begin", "mvhdp_apply_delta_rows", "mvhdp_apply_delta_end",
+    "mvhdp_sweep", "mvhdp_sweep_many", "mvhdp_get_tuning", "mvhdp_set_tuning", "mvhdp_plan_probe", "mvhdp_tuner_probe",
+    "mvhdp_apply_delta", "mvhdp_apply_delta_begin", "mvhdp_apply_delta_rows", "mvhdp_apply_delta_end",
     "mvhdp_trees_current", "mvhdp_get_view_weights",
     "mvhdp_device_buffer", "mvhdp_counts_written", "mvhdp_set_stream", "mvhdp_synchronize",
 ]
@@ -55,6 +56,29 @@ class DebugC(C.Structure):
     _fields_ = [("tok_dbg", C.c_void_p * MAX_M), ("n_trace", C.c_int32),
                 ("trace_doc", C.c_void_p), ("trace_view", C.c_void_p), ("trace_pos", C.c_void_p),
                 ("trace_out", C.c_void_p)]
+
+
+class TuningC(C.Structure):
+    _fields_ = [("force_primary", C.c_int32), ("narrow", C.c_int32), ("walk_fixed", C.c_int32), ("single_stream", C.c_int32),
+                ("live16", C.c_int32), ("reserved", C.c_int32),
+                ("walk_theta", C.c_double * MAX_M), ("primary_min_share", C.c_double),
+                ("learnt_walk_step", C.c_int32 * 4), ("tree_branch_share", C.c_double * MAX_M)]
+
+
+class PlanInputC(C.Structure):
+    _fields_ = [("num_topics", C.c_int32), ("num_modalities", C.c_int32), ("num_entities", C.c_int64),
+                ("max_entity_tokens", C.c_int64), ("entities_longer_than", C.c_int64 * 5),
+                ("tokens_by_list_rounds", C.c_uint64 * 17), ("entities_by_class", C.c_uint64 * 8),
+                ("flags", C.c_uint32), ("debug", C.c_int32), ("batch", C.c_int32), ("trees_current", C.c_int32),
+                ("num_cus", C.c_int32), ("kernel_registers", (C.c_int32 * 3) * 6)]
+
+
+class PlanOutputC(C.Structure):
+    _fields_ = [("status", C.c_int32), ("segments", C.c_int32), ("primary_class", C.c_int32), ("register_resident", C.c_int32),
+                ("need_full_trees", C.c_int32), ("dominant_class", C.c_int32), ("routed_prefix", C.c_int64),
+                ("class_used", C.c_int32 * 6), ("class_map", C.c_int32 * 6), ("class_stream", C.c_int32 * 6),
+                ("class_grid", C.c_int32 * 6), ("class_walk", C.c_int32 * 6), ("class_narrow", C.c_int32 * 6),
+                ("class_register_resident", C.c_int32 * 6), ("class_lds_bytes", C.c_int64 * 6), ("class_theta0", C.c_double * 6)]
 
 
 _lib = None
@@ -105,16 +129,23 @@ def _preload_one_hip_runtime():
     Java host of INTEGRATION.md) is not affected: the library then runs on /opt/rocm's runtime."""
     d = _torch_lib_dir()
     if d is None:
-        return
+        return False
+    already = mapped_runtime_libraries()
+    if already["libamdhip64"] or already["libhsa-runtime64"]:
+        # a HIP runtime is mapped already (torch imported first -- fine, libmvhdp.so will use that copy -- or a profiler's
+        # preloaded tool library brought /opt/rocm's): nothing to choose any more
+        return False
     path = os.path.join(d, "libamdhip64.so")
-    if os.path.exists(path):
-        _preloaded.append(C.CDLL(path, mode=C.RTLD_GLOBAL))
+    if not os.path.exists(path):
+        return False
+    _preloaded.append(C.CDLL(path, mode=C.RTLD_GLOBAL))
     # RCCL is opened by the library itself, lazily, in mvhdp_group_create (dlopen by soname: a copy torch has mapped
     # already is re-used).  When torch is installed but not imported yet, point the library at the wheel's copy so that
     # a later `import torch` maps the same file (mapping it here, process-wide and ahead of torch, aborts at exit).
     rccl = os.path.join(d, "librccl.so")
     if os.path.exists(rccl):
         os.environ.setdefault("MVHDP_RCCL_LIB", rccl)
+    return True
 
 
 def load_library():
@@ -126,11 +157,11 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C mvtopicmodel_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
-    _preload_one_hip_runtime()
+    chose = _preload_one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     maps = mapped_runtime_libraries()
     for name in ("libamdhip64", "libhsa-runtime64"):
-        if len(maps[name]) > 1:
+        if chose and len(maps[name]) > 1:
             raise ImportError(
                 f"two copies of {name} are mapped into this process ({', '.join(maps[name])}): a HIP runtime was loaded "
                 "before mvtopicmodel_amd could pick one.  Import mvtopicmodel_amd (or torch) before any other library "
@@ -159,6 +190,11 @@ def load_library():
     L.mvhdp_doc_topic_proportions.argtypes = [vp, vp, i64, i64, vp]
     L.mvhdp_gamma_doc_statistics.argtypes = [vp, i32, C.c_double, u64, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mvhdp_sweep.argtypes = [vp, u32, u64, u32, vp, C.POINTER(DebugC), C.POINTER(SweepStatsC)]
+    L.mvhdp_sweep_many.argtypes = [vp, u32, i32, u64, u32, vp]
+    L.mvhdp_get_tuning.argtypes = [vp, C.POINTER(TuningC)]
+    L.mvhdp_set_tuning.argtypes = [vp, C.POINTER(TuningC)]
+    L.mvhdp_plan_probe.argtypes = [C.POINTER(PlanInputC), C.POINTER(TuningC), C.POINTER(PlanOutputC)]
+    L.mvhdp_tuner_probe.argtypes = [i32, vp, vp, vp, i32, i32, vp]
     L.mvhdp_apply_delta.argtypes = [vp, i32, i32]
     L.mvhdp_apply_delta_begin.argtypes = [vp]
     L.mvhdp_apply_delta_rows.argtypes = [vp, i64, i64]

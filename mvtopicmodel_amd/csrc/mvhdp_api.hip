@@ -4,6 +4,7 @@
 // There is NO CPU fallback: without a gfx950 device mvhdp_create fails.
 #include "mvhdp_device.h"
 #include "../../include/mvhdp.h"
+#include "mvhdp_plan.h"
 
 #include <algorithm>
 #include <functional>
@@ -51,46 +52,30 @@ struct mvhdp_ctx {
     int64_t rows_applied = -1;               // mvhdp_apply_delta_rows progress of the current begin/end bracket (-1: no bracket open)
     bool device_released = false;            // release_device_resources has run (mvhdp_destroy, or the exit handler)
 
-    unsigned long long* d_stats = nullptr;   // [ST_COUNT]
-    long long* d_act_key = nullptr;
+    unsigned long long* d_ctl = nullptr;     // ONE block: [ST_COUNT] counters | activation key | META_WORDS64 | 8 work-queue heads (one reset launch, one read-back)
+    unsigned long long* d_stats = nullptr;   //   = d_ctl
+    long long* d_act_key = nullptr;          //   = d_ctl + ST_COUNT
     unsigned long long* d_doc_counter = nullptr;
     int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
-    int32_t* d_overflow = nullptr;           // [D] entities handed from the primary register-resident variant to the next pass
-    int32_t* d_overflow2 = nullptr;          // [D] entities that exceed even the 16-slot variant: generic LDS kernel
-    unsigned int* d_ovf_meta = nullptr;      // u32 overflow counts of pass 1 and 2, at byte 8: u64[17] tokens by ceil(topic list/64), then the count of pass 3
-    int32_t* d_lists = nullptr;              // classified mode: [MVHDP_N_CLASSES][D] entity lists written by classify_kernel
-    hipStream_t side[MVHDP_N_CLASSES]{};     // one stream per wider kernel class (created on first use)
-    hipEvent_t ev_fork = nullptr, ev_join[MVHDP_N_CLASSES]{};
+    unsigned int* d_ovf_meta = nullptr;      // META_*: the next sweep's histograms (tokens by list size, entities by kernel class), per-class list lengths, misroutes
+    int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
+    uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
+    hipStream_t side[PLAN_N_STREAMS]{};      // side streams of the wider kernel classes (created on first use; [0] unused: the handle's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[PLAN_N_STREAMS]{};
+    std::vector<hipEvent_t> ev_many;         // mvhdp_sweep_many: two events per sweep of the batch
+    unsigned long long* d_stats_many = nullptr;   // mvhdp_sweep_many: [n][ST_COUNT]
+    int stats_many_cap = 0;
     std::vector<int64_t> tokens_desc;        // entity token counts, descending (the order of d_doc_order)
     int64_t* d_carry[MVHDP_MAXM]{};          // doc_topic_proportions: per view, the entity whose view-m counts score entity d (lazily built)
-    unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class, from the last sweep (or the probe)
-    int rmax_hint = 0;                       // slots/64 the next sweep's register-resident kernel is sized for (0 = estimate)
-    // 1-round or 2-round primary variant?  Measured, not tabulated: once half of the tokens sit in topic lists of at most 64 slots
-    // the 1-round variant runs for ONE sweep (the longer lists on their own class kernels, or -- below 0.5 % -- in an optimistic
-    // overflow pass); if its kernel time per token is not better than the 2-round variant's of the sweep before, the choice goes
-    // back to 2 rounds and is not tried again for 4 sweeps (8, 16, 32 after repeated failures).
-    int last_primary = 0;                    // primary variant of the last plain sweep (0: none)
-    double last_ns_per_token = 0;            //   and its sweep-kernel time per token
-    double two_round_ns_per_token = 0;       // the 2-round variant's time per token just before a 1-round trial
-    long long sweeps_done = 0, one_round_banned_until = 0, one_round_ban = 4;
-    // Walk threshold of the chunk head (SweepLaunch::walk_theta, in steps of 1/MVHDP_WALK_BINS): which tokens have their word tree
-    // walked up front.  It changes when the walk is done, never what is sampled, so it is steered by the clock: sweeps at the current
-    // threshold (A) alternate with sweeps a step away (B); B replaces A when its kernel time per token beats the mean of the A sweeps
-    // on either side (the chain's own drift cancels).  An upward step is as long as the last sweep's histogram of the tree-branch
-    // tokens' u1 says is nearly free (<= 0.4 % of the tokens more to walk on demand; the allowance doubles after a step that paid
-    // more than 0.8 % and halves after a long step that did not pay), a downward step is one bin.  A step that does
-    // not pay turns the search around; two in a row let it rest for a growing number of sweeps, and the first B sweep after a rest
-    // tries half the threshold (a slope too shallow for single steps to see, e.g. where the kernel is not bandwidth-bound and
-    // the best threshold is 0).  Views where most tokens take the tree branch anyway (walk_f >= 0.35) are always walked.
-    int walk_i = 0, walk_probe_i = 0, walk_b_i = 0, walk_phase = 0, walk_dir = 1, walk_fails = 0, walk_wait = 4, walk_cfg = -1, walk_maxj = 6;
-    bool walk_far = false;                   // the next B sweep after a rest tries half the threshold (slopes too shallow for single steps)
-    double walk_ns_a1 = 0.0, walk_ns_b = 0.0;
-    int walk_cls = 1, walk_i_by[2] = {-1, -1}; // the threshold is kept per variant class ([0] the 1-round variant, [1] the wider ones; -1: inherits on first use)
-    bool one_round_retry = false;            // the 1-round trial failed at a low threshold: one more sweep at a high one before the ban
-    double walk_cap = 0.004;                 // share of the tokens an upward step may add to the walks on demand: doubles after a step that paid well
-    long long walk_idle_until = 0, walk_refresh_at = 0;
-    double walk_f[MVHDP_MAXM] = {-1, -1, -1, -1, -1, -1, -1, -1};   // tree-branch share per view in the last sweep (< 0: not known yet)
-    double walk_hist[MVHDP_WALK_BINS] = {0};  // tree-branch tokens of those views by u1 bin, as a share of all tokens (last sweep)
+    // what the last sweep (or the recount after new assignments) left behind for the next plan
+    unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class
+    unsigned long long last_ent[MVHDP_ENT_BINS]{};     // entities by kernel class
+    bool nslots_valid = false;               // MvModel::nslots and the two histograms describe the current assignments
+    bool counts_stale = false;               // assignments were replaced (set_assignments / init_from_trees) and the counts not rebuilt since
+    PlanRegs regs{};                         // register counts of the compiled kernels (occupancy)
+    PlanTuning tu;                           // what the host pinned (mvhdp_set_tuning; environment read once at create)
+    WalkTuner wt;                            // the walk-threshold search
+    bool dbg_env = false;                    // MVHDP_DEBUG was set at create
     size_t lds_attr_set = 0;
 };
 
@@ -133,37 +118,39 @@ static bool is_live(mvhdp_ctx* h)
     (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
 #define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
 
-// Which register-resident variant (64*r topic slots per entity, r = 1,2,4,8,16) should the next sweep's
-// first pass use?  hist[b] = tokens of the entities whose topic list needs b+1 rounds of 64 slots
-// (b = 16: more than 1024 slots).  A larger r costs registers, i.e. resident waves (relative cost per
-// token below, measured on C4/C5); entities that do not fit go to a second pass with the 16-slot
-// variant and, beyond 1024 slots, to the generic LDS kernel.  Returns 32 when the generic kernel alone
-// is the cheapest.
-static int rmax_from_hist(const unsigned long long* hist)
-{
-    static const int variants[5] = {1, 2, 4, 8, 16};
-    // The 1-round variant against the 2-round one is config-dependent (12 % faster on C3, K = 200; 0.6 % SLOWER on C4,
-    // K = 400, where its seventh wave per SIMD buys nothing): the table only proposes it, the sweep measures it
-    // (try_one_round below).
-    static const double cost[5] = {0.95, 1.0, 1.45, 2.6, 4.5};
-    const double cost_generic = 6.0;
-    double tot = 0;
-    for (int i = 0; i < MVHDP_HIST_BINS; i++) tot += (double)hist[i];
-    if (tot == 0) return 1;
-    int best = 32; double best_cost = cost_generic * tot;
-    for (int v = 0; v < 5; v++) {
-        double c = 0;
-        for (int b = 0; b < MVHDP_HIST_BINS; b++) {
-            const double t = (double)hist[b];
-            if (b + 1 <= variants[v]) c += t * cost[v];
-            else c += t * (0.02 * cost[v] + (b + 1 <= 8 ? cost[3] : (b + 1 <= 16 ? cost[4] : cost_generic)));   // prologue in pass 1 + the later pass
-        }
-        if (c < best_cost) { best_cost = c; best = variants[v]; }
-    }
-    return best;
-}
-
 static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
+
+// d_ovf_meta (u64 words unless said otherwise): [META_HIST .. +MVHDP_HIST_BINS+MVHDP_ENT_BINS) what the sweep kernels leave for the next
+// plan (SweepLaunch::slot_hist); u32 words [META_CLASS_COUNTS .. +MVHDP_N_CLASSES) lengths of the route pass's class lists;
+// [META_MISROUTED] entities the route pass could not place
+enum { META_HIST = 0, META_MISROUTED = 40, META_WORDS64 = 48, META_BYTES = META_WORDS64 * 8, META_CLASS_COUNTS = 64 /* u32 index = byte 256 */ };
+static_assert(MVHDP_HIST_BINS + MVHDP_ENT_BINS <= 32, "histograms overlap the class counts");
+enum { CTL_WORDS = ST_COUNT + 1 + META_WORDS64 + 8 };
+
+// The environment is read ONCE, here (diagnostics; a host uses mvhdp_set_tuning):
+//   MVHDP_FORCE_RMAX=1|2|4|8|16   primary variant          MVHDP_NARROW=0        never the 16-bit mirror
+//   MVHDP_WALK_THETA=t0,t1,...    fixed walk thresholds    MVHDP_SINGLE_STREAM=1 class kernels one after another
+//   MVHDP_DEBUG=1                 the plan of every sweep on stderr
+static void read_environment(mvhdp_ctx* h)
+{
+    if (const char* f = getenv("MVHDP_FORCE_RMAX")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) h->tu.force_primary = v; }
+    if (const char* f = getenv("MVHDP_NARROW")) h->tu.narrow = atoi(f) != 0 ? -1 : 0;
+    if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
+    if (const char* f = getenv("MVHDP_FORCE_MODE")) { if (!strcmp(f, "serial")) h->tu.single_stream = 1; }   // "streams" (default): class kernels side by side
+    if (const char* f = getenv("MVHDP_PRIMARY_MIN_SHARE")) { const double v = atof(f); if (v > 0.0 && v <= 1.0) h->tu.primary_min_share = v; }
+    if (const char* t = getenv("MVHDP_WALK_THETA")) {
+        int m = 0;
+        for (const char* q = t; *q && m < MVHDP_MAXM; m++) {
+            h->tu.walk_theta[m] = atof(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        for (; m < MVHDP_MAXM; m++) h->tu.walk_theta[m] = 0.0;
+        h->tu.walk_fixed = 1;
+    }
+    h->dbg_env = getenv("MVHDP_DEBUG") != nullptr;
+}
 
 extern "C" const char* mvhdp_version(void) { return "mvhdp 0.1 (gfx950)"; }
 
@@ -217,6 +204,8 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMemset(mm.counts, 0, cbytes));
     CREATE_HIP(hipMalloc(&mm.counts16, (size_t)nrows * K * sizeof(uint16_t)));
     CREATE_HIP(hipMemset(mm.counts16, 0, (size_t)nrows * K * sizeof(uint16_t)));
+    CREATE_HIP(hipMalloc(&mm.heavy, (size_t)nrows));
+    CREATE_HIP(hipMemset(mm.heavy, 1, (size_t)nrows));
     CREATE_HIP(hipMemset(mm.delta, 0, cbytes));
     CREATE_HIP(hipMalloc(&mm.trees, (size_t)nrows * 2 * K * sizeof(double)));
     CREATE_HIP(hipMalloc(&mm.root, (size_t)nrows * sizeof(double)));
@@ -236,14 +225,20 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMalloc(&h->d_alpha, (size_t)M * (K + 1) * sizeof(double)));
     CREATE_HIP(hipMalloc(&h->d_inactive, (size_t)K));
     CREATE_HIP(hipMemset(h->d_inactive, 0, (size_t)K));
-    CREATE_HIP(hipMalloc(&h->d_stats, ST_COUNT * sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc(&h->d_act_key, sizeof(long long)));
-    CREATE_HIP(hipMalloc(&h->d_doc_counter, 8 * sizeof(unsigned long long)));     // one work-queue head per kernel class
-    CREATE_HIP(hipMalloc(&h->d_ovf_meta, 256));                                       // see META_* below
+    CREATE_HIP(hipMalloc(&h->d_ctl, CTL_WORDS * sizeof(unsigned long long)));
+    CREATE_HIP(hipMemset(h->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long)));
+    h->d_stats = h->d_ctl;
+    h->d_act_key = (long long*)(h->d_ctl + ST_COUNT);
+    h->d_ovf_meta = (unsigned int*)(h->d_ctl + ST_COUNT + 1);
+    h->d_doc_counter = h->d_ctl + ST_COUNT + 1 + META_WORDS64;                       // one work-queue head per kernel class
+    for (int c = 0; c < MVHDP_N_CLASSES; c++)
+        for (int f = 0; f < 3; f++) h->regs.regs[c][f] = mvhdp_sweep_kernel_regs(c, f);
+    read_environment(h);
     mm.alpha = h->d_alpha;
     mm.inactive = h->d_inactive;
     h->h_alpha.assign((size_t)M * (K + 1), 0.0);
     h->h_inactive.assign((size_t)K, 0);
+    h->wt.init_defaults(K);
     *out = h;
     return MVHDP_OK;
 }
@@ -257,9 +252,11 @@ static void release_device_resources(mvhdp_ctx* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
     for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); }
-    fr(h->mm.counts); fr(h->mm.counts16); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
-    fr(h->d_alpha); fr(h->d_inactive); fr(h->d_stats); fr(h->d_act_key); fr(h->d_doc_counter);
-    fr(h->d_doc_order); fr(h->d_overflow); fr(h->d_overflow2); fr(h->d_ovf_meta); fr(h->d_lists);
+    fr(h->mm.counts); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
+    fr(h->d_alpha); fr(h->d_inactive); fr(h->d_ctl);
+    h->d_stats = nullptr; h->d_act_key = nullptr; h->d_doc_counter = nullptr; h->d_ovf_meta = nullptr;
+    fr(h->d_doc_order); fr(h->d_lists); fr(h->d_nslots); fr(h->d_stats_many);
+    for (auto& e : h->ev_many) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& e : h->ev) if (e) { hipEventDestroy(e); e = nullptr; }
     if (h->ev_fork) { hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
     for (auto& e : h->ev_join) if (e) { hipEventDestroy(e); e = nullptr; }
@@ -338,11 +335,11 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     h->have_corpus[m] = true;
     h->max_doc_tokens = -1;
     if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
-    if (h->d_overflow) { hipFree(h->d_overflow); h->d_overflow = nullptr; }
-    if (h->d_overflow2) { hipFree(h->d_overflow2); h->d_overflow2 = nullptr; }
     if (h->d_lists) { hipFree(h->d_lists); h->d_lists = nullptr; }
+    if (h->d_nslots) { hipFree(h->d_nslots); h->d_nslots = nullptr; }
+    mm.nslots = nullptr;
     for (auto& c : h->d_carry) if (c) { hipFree(c); c = nullptr; }
-    h->rmax_hint = 0;
+    h->nslots_valid = false;
     mm.D = D;
     mm.doc_off[m] = (const int64_t*)h->d_doc_off[m];
     mm.tok[m] = (const int32_t*)h->d_tok[m];
@@ -370,7 +367,10 @@ extern "C" int mvhdp_set_assignments(mvhdp_handle h, int32_t m, const int32_t* z
     HIPC(h, hipSetDevice(h->device));
     HIPC(h, hipStreamSynchronize(h->stream));
     if (h->N[m] > 0) HIPC(h, hipMemcpy(h->d_z[m], z, (size_t)h->N[m] * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->rmax_hint = 0;
+    h->nslots_valid = false;
+    // the counts no longer describe these assignments: a sampling sweep is refused until build_counts / set_counts /
+    // counts_written says they do again (a frozen sweep, whose counts are a trained model's by design, is not)
+    if (h->have_counts) h->counts_stale = true;
     return MVHDP_OK;
 }
 
@@ -436,7 +436,7 @@ extern "C" int mvhdp_build_counts(mvhdp_handle h)
         h->delta_pending = false; h->delta_clean = true;
     }
     HIPC(h, hipStreamSynchronize(h->stream));
-    h->have_counts = true; h->have_trees = false;
+    h->have_counts = true; h->have_trees = false; h->counts_stale = false;
     return MVHDP_OK;
 }
 
@@ -483,7 +483,8 @@ extern "C" int mvhdp_init_assignments_from_trees(mvhdp_handle h, uint64_t seed)
     HIPC(h, hipSetDevice(h->device));
     HIPC(h, mvhdp_launch_init_from_trees(h->mm, (uint32_t)seed, (uint32_t)(seed >> 32), h->stream));     // reads the descent table only
     HIPC(h, hipStreamSynchronize(h->stream));
-    h->rmax_hint = 0;
+    h->nslots_valid = false;
+    if (h->have_counts) h->counts_stale = true;
     return MVHDP_OK;
 }
 
@@ -510,7 +511,7 @@ extern "C" int mvhdp_set_counts(mvhdp_handle h, int32_t m, const int32_t* n_wk, 
     const int K = mm.K;
     if (n_wk) HIPC(h, hipMemcpy(mm.counts + mm.rowbase[m] * K, n_wk, (size_t)mm.V[m] * K * sizeof(int32_t), hipMemcpyHostToDevice));
     if (n_k) HIPC(h, hipMemcpy(mm.counts + mm.rowbase[mm.M] * K + (int64_t)m * K, n_k, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->have_counts = true; h->have_trees = false;
+    h->have_counts = true; h->have_trees = false; h->counts_stale = false;
     return MVHDP_OK;
 }
 
@@ -675,258 +676,127 @@ extern "C" int mvhdp_trees_current(mvhdp_handle h)
     return h->have_trees ? 1 : 0;
 }
 
-extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
-                           const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats)
+// ---------------------------------------------------------------------------------------------------------------
+// The sweep: plan (mvhdp_plan.h, pure) -> enqueue (launches only, nothing waits) -> finish (one synchronisation:
+// statistics, the next plan's histograms, the walk search).
+// ---------------------------------------------------------------------------------------------------------------
+static int ensure_slot_counts(mvhdp_ctx* h)
 {
-    CHECK_H(h);
+    // MvModel::nslots and the histograms come from the sweep kernels themselves; after assignments arrived from the host (or an
+    // entity was abandoned, Q11) they are recounted from z: one pass
     MvModel& mm = h->mm;
-    int rc = require_corpus(h); if (rc) return rc;
-    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "sweep before set_hyper");
-    if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "sweep before build_counts/set_counts");
-    if (flags & MVHDP_SWEEP_FROZEN) flags |= MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY;   // nut == 0: the model is read-only
-    if ((flags & MVHDP_SWEEP_REUSE_TREES) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES / FROZEN without trees");
-    if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL | MVHDP_SWEEP_FROZEN |
-                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff) | MVHDP_SWEEP_SEGMENT_APPLY)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
-    const bool live = (flags & MVHDP_SWEEP_LIVE) != 0;
-    const bool seg_apply = (flags & MVHDP_SWEEP_SEGMENT_APPLY) != 0;
-    if (seg_apply && (flags & (MVHDP_SWEEP_LIVE | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_REUSE_TREES)))
-        FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: SEGMENT_APPLY excludes LIVE, NO_APPLY, FROZEN and REUSE_TREES");
-    if (live && (flags & MVHDP_SWEEP_FROZEN)) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep: LIVE and FROZEN exclude each other");
-    if (h->rows_applied >= 0) FAIL(h, MVHDP_ERR_STATE, "sweep: an mvhdp_apply_delta_begin bracket is open (call mvhdp_apply_delta_end)");
-    if (h->delta_pending && !(flags & MVHDP_SWEEP_FROZEN))
-        FAIL(h, MVHDP_ERR_STATE, "sweep: the previous NO_APPLY sweep's deltas have not been applied (mvhdp_apply_delta)");
-    // live sweep: the entities are cut into nseg interleaved segments of the longest-first order, the trees are rebuilt
-    // from the live counts before each
-    // (a deferred sweep accepts a segment count too: same integers as one segment, the trees being those of the snapshot)
-    int nseg = (int)((flags >> 16) & 0xffu);
-    if (nseg == 0) nseg = (live || seg_apply) ? 4 : 1;
-    if ((int64_t)nseg > mm.D) nseg = (int)std::max<int64_t>(1, mm.D);
-    const int K = mm.K, M = mm.M;
-    HIPC(h, hipSetDevice(h->device));
-    hipStream_t s = h->stream;
+    if (mm.D > 0 && !h->d_nslots) {
+        HIPC(h, hipMalloc(&h->d_nslots, (size_t)mm.D * sizeof(uint16_t)));
+        mm.nslots = h->d_nslots;
+        h->nslots_valid = false;
+    }
+    if (h->nslots_valid) return MVHDP_OK;
+    unsigned long long hist[MVHDP_HIST_BINS + MVHDP_ENT_BINS] = {0};
+    HIPC(h, hipMemsetAsync(h->d_ovf_meta, 0, META_BYTES, h->stream));
+    HIPC(h, mvhdp_launch_slot_hist(mm, (unsigned long long*)h->d_ovf_meta + META_HIST, h->stream));
+    HIPC(h, hipMemcpyAsync(hist, (unsigned long long*)h->d_ovf_meta + META_HIST, sizeof hist, hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    std::copy(hist, hist + MVHDP_HIST_BINS, h->last_hist);
+    std::copy(hist + MVHDP_HIST_BINS, hist + MVHDP_HIST_BINS + MVHDP_ENT_BINS, h->last_ent);
+    h->nslots_valid = true;
+    return MVHDP_OK;
+}
 
-    // launch geometry
-    int64_t mdt = compute_max_doc_tokens(h);
-    int S_cap = (int)std::min<int64_t>(K, std::max<int64_t>(mdt, 1));
-    S_cap = (S_cap + 63) / 64 * 64;
-    SweepLaunch sl{};
-    sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
-    sl.flags = flags & 0xffffu; sl.S_cap = S_cap;
-    sl.q_order_stride = 1;
-    // the block's private n_k delta table: in LDS up to 24 KiB (C5: 20 KB), beyond that (e.g. K = 2048 with 8 views:
-    // 64 KB, which would not leave room for the slot state) the deltas go straight to the delta buffer.  A live sweep
-    // keeps the private table too: M*K hot words would take every token's two atomics one after the other at the
-    // memory side (measured on C3: 28 ms per sweep instead of 5.7), so tokensPerTopic becomes current at each
-    // segment end -- together with the trees -- while n_wk is updated in place (UPD:197-207).
-    sl.nk_global = ((size_t)M * K * sizeof(int) > 24 * 1024) ? 1 : 0;
-    sl.block_shared_bytes = (uint32_t)((((size_t)(sl.nk_global ? 0 : M * K) + MVHDP_HIST_BINS + MVHDP_MAXM * MVHDP_VIEW_STATS) * sizeof(int) + 15) & ~(size_t)15);
-    const bool debug = dbg != nullptr;
-    // Primary kernel variant: the register-resident kernel with 64*rmax topic slots per entity that is
-    // cheapest for the topic-list histogram of the previous sweep (first time: of a probe pass over z).
-    bool fast = !(flags & MVHDP_SWEEP_GENERIC_KERNEL);
-    int rmax = 0;
-    if (fast) {
-        if (h->rmax_hint <= 0) {
-            // first sweep on these assignments: measure the topic lists (one pass over z)
-            unsigned long long hist[1 + MVHDP_HIST_BINS] = {0};
-            HIPC(h, hipMemsetAsync(h->d_ovf_meta, 0, 256, h->stream));
-            HIPC(h, mvhdp_launch_slot_hist(mm, (unsigned long long*)(h->d_ovf_meta + 2), h->stream));
-            HIPC(h, hipMemcpyAsync(hist, h->d_ovf_meta, sizeof hist, hipMemcpyDeviceToHost, h->stream));
-            HIPC(h, hipStreamSynchronize(h->stream));
-            std::copy(hist + 1, hist + 1 + MVHDP_HIST_BINS, h->last_hist);
-            h->rmax_hint = rmax_from_hist(hist + 1);
-        }
-        rmax = h->rmax_hint;
-        if (rmax == 1 && (nseg != 1 || dbg || (flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)))) {
-            // an early 1-round proposal (up to half of the tokens still in longer lists) stands only where the clock can confirm it;
-            // this sweep cannot be timed against its neighbours (segments, debug, frozen): the old rule, at most 0.5 % beyond
-            double tot = 0, beyond = 0;
-            for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b >= 1) beyond += (double)h->last_hist[b]; }
-            if (beyond > 0.005 * tot && S_cap > 64) rmax = 2;
-        }
-        if (const char* f = getenv("MVHDP_FORCE_RMAX")) { int v = atoi(f); if (v >= 1 && v <= 16) rmax = v; }   // diagnostics only
-        if (rmax > 16) fast = false;
-        else {
-            { int v = 1; while (v < rmax) v <<= 1; rmax = v; }              // variants exist for 1, 2, 4, 8, 16
-            while (rmax > 1 && 64 * (rmax / 2) >= S_cap) rmax /= 2;          // no larger than the corpus can need
-        }
-    }
-    // Two ways to deal with the entities whose topic list exceeds the primary variant's 64*rmax slots.
-    //  * optimistic (few of them): the primary kernel runs over every entity and appends the ones that do
-    //    not fit to an overflow list; the 8-round, the 16-round and the generic kernel then take the rest,
-    //    one pass after another.
-    //  * classified (many of them, e.g. power-law lengths with K = 1000): only an entity with more tokens
-    //    than slots can overflow -- a static prefix of the longest-first order.  classify_kernel measures
-    //    that prefix and lists every entity for the narrowest kernel that holds it; the kernels of all
-    //    classes then run side by side on their own streams, the widest (longest entities) first, so the
-    //    long sequential chains overlap the bulk instead of following it.
-    int pc = 0;                                              // class of the primary variant: rmax == 1 << pc
-    while ((1 << pc) < rmax) pc++;
-    // walk thresholds of this sweep (see mvhdp_ctx::walk_i) and the kernel flavour that goes with them
-    const char* theta_env = getenv("MVHDP_WALK_THETA");         // diagnostics: "t0,t1,..." fixes the thresholds
-    {   // the 1-round variant and the wider ones want different thresholds: each keeps its own
-        const int cls = (fast && rmax == 1) ? 0 : 1;
-        if (cls != h->walk_cls) {
-            h->walk_i_by[h->walk_cls] = h->walk_i;
-            if (h->walk_i_by[cls] >= 0) h->walk_i = h->walk_i_by[cls];
-            h->walk_cls = cls;
-            h->walk_phase = 0; h->walk_far = false;
-        }
-    }
-    auto walk_controlled = [&](int m) { return h->walk_f[m] >= 0.0 && h->walk_f[m] < 0.35; };
-    bool walk_any = false, walk_unknown = false;                 // (walk_f < 0: not measured yet)
-    for (int m = 0; m < M; m++) { walk_any = walk_any || walk_controlled(m); walk_unknown = walk_unknown || h->walk_f[m] < 0.0; }
-    if (theta_env) {
-        int m = 0;
-        for (const char* q = theta_env; *q && m < MVHDP_MAXM; m++) {
-            sl.walk_theta[m] = atof(q);
-            while (*q && *q != ',') q++;
-            if (*q == ',') q++;
-        }
-        for (; m < MVHDP_MAXM; m++) sl.walk_theta[m] = 0.0;
-        sl.walk = 1;
-    } else {
-        const int top = MVHDP_WALK_BINS;                         // thresholds up to 1 (= no token of the view walked up front)
-        h->walk_probe_i = h->walk_i;
-        if (h->walk_phase == 1 && walk_any) {
-            if (h->walk_far && h->walk_i < 4) h->walk_far = false;
-            if (h->walk_far) h->walk_dir = -1;
-            if (h->walk_dir > 0 && h->walk_i >= top) h->walk_dir = -1;
-            if (h->walk_dir < 0 && h->walk_i <= 0) h->walk_dir = 1;
-            if (h->walk_dir > 0) {
-                int j = 1;
-                double extra = h->walk_hist[h->walk_i];
-                while (h->walk_i + j < top && j < h->walk_maxj && extra + h->walk_hist[h->walk_i + j] <= h->walk_cap) { extra += h->walk_hist[h->walk_i + j]; j++; }
-                h->walk_probe_i = h->walk_i + j;
-            } else h->walk_probe_i = h->walk_far ? h->walk_i / 2 : h->walk_i - 1;
-        }
-        sl.walk = 0;
-        for (int m = 0; m < MVHDP_MAXM; m++) {
-            sl.walk_theta[m] = (m < M && walk_controlled(m)) ? (double)h->walk_probe_i / MVHDP_WALK_BINS : 0.0;
-            if (sl.walk_theta[m] > 0.0) sl.walk = 1;
-        }
-        // no view qualifies: look again every 16th sweep (the statistics come from the walk flavour only)
-        if (!walk_any && h->sweeps_done >= h->walk_refresh_at) { sl.walk = 1; h->walk_refresh_at = h->sweeps_done + 16; }
-        if (walk_unknown) sl.walk = 1;                           // the first sweep measures (threshold 0)
-    }
-    if (debug) sl.walk = 1;
-    // the 16-bit mirror of n_wk (written with the trees) for the 1-round walk flavour -- the bandwidth-bound one: half the lines
-    // of every gathered row.  Needs the mirror to be this sweep's start counts: trees built in this call or still current, and
-    // no live updates (the mirror is a snapshot).
-    sl.narrow = (fast && rmax == 1 && sl.walk && !debug && !live &&
-                 (!(flags & MVHDP_SWEEP_REUSE_TREES) || h->have_trees)) ? 1 : 0;
-    if (const char* f = getenv("MVHDP_NARROW")) sl.narrow = (sl.narrow && atoi(f) != 0) ? 1 : 0;     // diagnostics: 0 switches it off
-    int64_t H = 0;                                           // entities that may exceed the primary variant
-    bool classified = false;
-    if (fast && h->d_doc_order && !h->tokens_desc.empty()) {
-        H = std::upper_bound(h->tokens_desc.begin(), h->tokens_desc.end(), (int64_t)64 * rmax, std::greater<int64_t>()) - h->tokens_desc.begin();
-        double tot = 0, beyond = 0;
-        for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b + 1 > rmax) beyond += (double)h->last_hist[b]; }
-        classified = H > 0 && beyond > 0.005 * tot;
-        if (const char* f = getenv("MVHDP_FORCE_MODE")) {                 // diagnostics / tests
-            if (!strcmp(f, "classified")) classified = H > 0;
-            else if (!strcmp(f, "optimistic")) classified = false;
-        }
-    }
-    int chain[3] = {0, 0, 0}, n_chain = 0;
-    if (fast && !classified) {
-        chain[n_chain++] = rmax;
-        if (rmax < 8 && S_cap > 64 * rmax) chain[n_chain++] = 8;
-        if (rmax < 16 && S_cap > 512) chain[n_chain++] = 16;
-    }
-    struct Geo { uint32_t wave_bytes; int wpb; size_t lds; int grid; };
-    auto geometry = [&](bool is_fast, int r, Geo& g) -> int {
-        // a register-resident variant never holds more than 64*r slots (longer lists are diverted before any slot write)
-        g.wave_bytes = (uint32_t)(is_fast ? mvhdp_sweep_fast_wave_bytes(M, std::min(S_cap, 64 * r), r) : mvhdp_sweep_wave_bytes(M, S_cap));
-        g.wpb = 4;
-        while (g.wpb > 1 && sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes > h->max_lds) g.wpb >>= 1;
-        g.lds = sl.block_shared_bytes + (size_t)g.wpb * g.wave_bytes;
-        if (g.lds > h->max_lds) return MVHDP_ERR_UNSUPPORTED;
-        int bpc = is_fast ? mvhdp_sweep_fast_occupancy(r, debug, sl.walk != 0, 64 * g.wpb, g.lds) : mvhdp_sweep_generic_occupancy(debug, 64 * g.wpb, g.lds);
-        if (bpc < 1) bpc = 1;
-        int64_t need = (mm.D + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
-        g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->num_cus * bpc));
-        return MVHDP_OK;
-    };
-    Geo gen{}, fst[3] = {}, cls[MVHDP_N_CLASSES] = {};
-    bool cls_fast[MVHDP_N_CLASSES] = {};
-    {
-        // the generic kernel may need > 64 KiB of dynamic LDS
-        uint32_t wb = (uint32_t)mvhdp_sweep_wave_bytes(M, S_cap);
-        int wpb = 4;
-        while (wpb > 1 && sl.block_shared_bytes + (size_t)wpb * wb > h->max_lds) wpb >>= 1;
-        size_t lds = sl.block_shared_bytes + (size_t)wpb * wb;
-        if (lds > h->max_lds) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB (K * modalities too large)");
-        if (lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
-    }
-    if (geometry(false, 0, gen) != MVHDP_OK) FAIL(h, MVHDP_ERR_UNSUPPORTED, "per-entity LDS state exceeds 160 KiB");
-    if (fast && geometry(true, rmax, fst[0]) != MVHDP_OK) { fast = false; classified = false; n_chain = 0; }
-    for (int p = 1; p < n_chain; p++)
-        if (geometry(true, chain[p], fst[p]) != MVHDP_OK) { n_chain = p; break; }     // later passes fall to the generic kernel
-    if (classified) {
-        cls[pc] = fst[0]; cls_fast[pc] = true;
-        for (int c = pc + 1; c < MVHDP_N_CLASSES; c++) {
-            cls_fast[c] = c < 5 && geometry(true, 1 << c, cls[c]) == MVHDP_OK;
-            if (!cls_fast[c]) cls[c] = gen;                                           // no room for that variant: generic kernel
-        }
-        if (!h->d_lists) HIPC(h, hipMalloc(&h->d_lists, (size_t)MVHDP_N_CLASSES * mm.D * sizeof(int32_t)));
-        if (!h->ev_fork) HIPC(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    } else if (fast) {
-        if (!h->d_overflow && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow, (size_t)mm.D * sizeof(int32_t)));
-        if (n_chain > 1 && !h->d_overflow2 && mm.D > 0) HIPC(h, hipMalloc(&h->d_overflow2, (size_t)mm.D * sizeof(int32_t)));
-    }
-    if (getenv("MVHDP_DEBUG")) {
-        double tot = 0, b1 = 0, b2 = 0;                           // token share by topic-list size (last sweep): <= 64, <= 128 slots
-        for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b < 1) b1 += (double)h->last_hist[b]; if (b < 2) b2 += (double)h->last_hist[b]; }
-        fprintf(stderr, "[mvhdp] sweep %u: fast=%d rmax=%d (hint %d) %s H=%lld chain=%d,%d,%d S_cap=%d | fast grid=%d wpb=%d lds=%zu | generic grid=%d wpb=%d lds=%zu | tokens in lists <=64: %.4f <=128: %.4f\n",
-                sweep_idx, (int)fast, rmax, h->rmax_hint, classified ? "classified" : "optimistic", (long long)H, chain[0], chain[1], chain[2], S_cap,
-                fst[0].grid, fst[0].wpb, fst[0].lds, gen.grid, gen.wpb, gen.lds, b1 / std::max(1.0, tot), b2 / std::max(1.0, tot));
-    }
-    sl.stats = h->d_stats;
-    sl.act_key = h->d_act_key;
-    // d_ovf_meta (u32 words): 0,1 = overflow counts of passes 1,2; 2..35 = u64 hist[17]; 36 = overflow count of pass 3;
-    // 40..45 = entities per class (classified mode)
-    unsigned int* class_counts = h->d_ovf_meta + 40;
-    sl.doc_counter = h->d_doc_counter;
-    sl.q_list = nullptr; sl.q_list_count = nullptr;
-    sl.q_order = h->d_doc_order; sl.q_order_start = 0; sl.q_order_count = mm.D;      // default: every entity, longest first
-    sl.overflow_list = nullptr; sl.overflow_count = nullptr;
-    sl.slot_hist = (unsigned long long*)(h->d_ovf_meta + 2);
-    // debug buffers
+static void fill_plan_in(mvhdp_ctx* h, uint32_t flags, bool debug, bool batch, PlanIn& in)
+{
+    const MvModel& mm = h->mm;
+    in.K = mm.K; in.M = mm.M; in.D = mm.D;
+    in.mdt = compute_max_doc_tokens(h);
+    in.have_order = h->d_doc_order != nullptr && !h->tokens_desc.empty();
+    for (int c = 0; c < 5; c++)
+        in.n_longer[c] = in.have_order ? (int64_t)(std::upper_bound(h->tokens_desc.begin(), h->tokens_desc.end(), (int64_t)64 << c, std::greater<int64_t>()) - h->tokens_desc.begin()) : mm.D;
+    std::copy(h->last_hist, h->last_hist + MVHDP_HIST_BINS, in.tok_hist);
+    std::copy(h->last_ent, h->last_ent + MVHDP_ENT_BINS, in.ent_hist);
+    in.flags = flags; in.debug = debug; in.batch = batch;
+    in.trees_current = h->have_trees;
+    in.first_inactive = mm.first_inactive;
+    in.num_cus = h->num_cus; in.max_lds = h->max_lds;
+    in.regs = h->regs;
+}
+
+// device-side buffers of the parity tests' debug outputs
+struct DebugBufs {
     std::vector<void*> to_free;
-    auto cleanup = [&]() { for (void* p : to_free) hipFree(p); };
-    if (debug) {
-        for (int m = 0; m < M; m++) {
-            if (dbg->tok_dbg[m] && h->N[m] > 0) {
-                void* p = nullptr;
-                hipError_t e = hipMalloc(&p, (size_t)h->N[m] * 4 * sizeof(double));
-                if (e != hipSuccess) { cleanup(); HIPC(h, e); }
-                to_free.push_back(p);
-                hipMemsetAsync(p, 0, (size_t)h->N[m] * 4 * sizeof(double), s);
-                sl.tok_dbg[m] = (double*)p;
-            }
-        }
-        if (dbg->n_trace > 0) {
-            void *a = nullptr, *b = nullptr, *c = nullptr, *o = nullptr;
-            size_t n = (size_t)dbg->n_trace;
-            if (hipMalloc(&a, n * 8) != hipSuccess || hipMalloc(&b, n * 4) != hipSuccess ||
-                hipMalloc(&c, n * 4) != hipSuccess || hipMalloc(&o, n * (K + 1) * 8) != hipSuccess) {
-                cleanup(); FAIL(h, MVHDP_ERR_HIP, "debug trace allocation failed");
-            }
-            to_free.push_back(a); to_free.push_back(b); to_free.push_back(c); to_free.push_back(o);
-            hipMemcpyAsync(a, dbg->trace_doc, n * 8, hipMemcpyHostToDevice, s);
-            hipMemcpyAsync(b, dbg->trace_view, n * 4, hipMemcpyHostToDevice, s);
-            hipMemcpyAsync(c, dbg->trace_pos, n * 4, hipMemcpyHostToDevice, s);
-            hipMemsetAsync(o, 0, n * (K + 1) * 8, s);
-            sl.n_trace = dbg->n_trace;
-            sl.trace_doc = (const int64_t*)a; sl.trace_view = (const int32_t*)b; sl.trace_pos = (const int32_t*)c;
-            sl.trace_out = (double*)o;
+    double* tok_dbg[MVHDP_MAXM] = {};
+    int n_trace = 0;
+    const int64_t* trace_doc = nullptr; const int32_t* trace_view = nullptr; const int32_t* trace_pos = nullptr;
+    double* trace_out = nullptr;
+    void release() { for (void* p : to_free) hipFree(p); to_free.clear(); }
+};
+
+static int alloc_debug(mvhdp_ctx* h, const mvhdp_debug* dbg, DebugBufs& db)
+{
+    const int K = h->mm.K, M = h->mm.M;
+    hipStream_t s = h->stream;
+    for (int m = 0; m < M; m++) {
+        if (dbg->tok_dbg[m] && h->N[m] > 0) {
+            void* p = nullptr;
+            hipError_t e = hipMalloc(&p, (size_t)h->N[m] * 4 * sizeof(double));
+            if (e != hipSuccess) { db.release(); HIPC(h, e); }
+            db.to_free.push_back(p);
+            hipMemsetAsync(p, 0, (size_t)h->N[m] * 4 * sizeof(double), s);
+            db.tok_dbg[m] = (double*)p;
         }
     }
+    if (dbg->n_trace > 0) {
+        void *a = nullptr, *b = nullptr, *c = nullptr, *o = nullptr;
+        const size_t n = (size_t)dbg->n_trace;
+        if (hipMalloc(&a, n * 8) != hipSuccess || hipMalloc(&b, n * 4) != hipSuccess ||
+            hipMalloc(&c, n * 4) != hipSuccess || hipMalloc(&o, n * (K + 1) * 8) != hipSuccess) {
+            for (void* q : {a, b, c, o}) if (q) hipFree(q);
+            db.release(); FAIL(h, MVHDP_ERR_HIP, "debug trace allocation failed");
+        }
+        db.to_free.push_back(a); db.to_free.push_back(b); db.to_free.push_back(c); db.to_free.push_back(o);
+        hipMemcpyAsync(a, dbg->trace_doc, n * 8, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(b, dbg->trace_view, n * 4, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(c, dbg->trace_pos, n * 4, hipMemcpyHostToDevice, s);
+        hipMemsetAsync(o, 0, n * (K + 1) * 8, s);
+        db.n_trace = dbg->n_trace;
+        db.trace_doc = (const int64_t*)a; db.trace_view = (const int32_t*)b; db.trace_pos = (const int32_t*)c;
+        db.trace_out = (double*)o;
+    }
+    return MVHDP_OK;
+}
 
+struct SweepOutcome {                        // what enqueue_sweep learnt on the way (segment-border activations need the host)
+    int n_activations = 0;
+    long long first_act = LLONG_MAX;
+};
+
+// Everything one sweep puts on the device, in stream order; returns without waiting (except at the segment borders of a live /
+// segmented sweep over a model with inactive topics, where the host performs the activation UPD:263-270).
+// d_stats: [ST_COUNT] counters of THIS sweep; ev_k0/ev_k1: recorded around the sweep kernels.
+static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, uint64_t seed, const double* p_override,
+                         const DebugBufs* db, unsigned long long* d_stats, hipEvent_t ev_k0, hipEvent_t ev_k1, SweepOutcome& oc)
+{
+    MvModel& mm = h->mm;
+    const int M = mm.M;
+    const uint32_t flags = p.flags;
+    const int nseg = p.nseg;
+    hipStream_t s = h->stream;
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    step(hipEventRecord(h->ev[0], s));
+
+    SweepLaunch sl{};
+    sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
+    sl.flags = flags & 0xffffu; sl.S_cap = p.S_cap;
+    sl.q_order_stride = 1;
+    sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
+    sl.live16 = p.live16 ? 1 : 0;
+    sl.stats = d_stats;
+    sl.act_key = h->d_act_key;
+    sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;
+    if (db) {
+        for (int m = 0; m < M; m++) sl.tok_dbg[m] = db->tok_dbg[m];
+        sl.n_trace = db->n_trace; sl.trace_doc = db->trace_doc; sl.trace_view = db->trace_view; sl.trace_pos = db->trace_pos; sl.trace_out = db->trace_out;
+    }
+    unsigned int* class_counts = h->d_ovf_meta + META_CLASS_COUNTS;
+
     if (M > 1) {
         if (!mm.p && mm.D > 0) step(hipMalloc(&mm.p, (size_t)mm.D * M * M * sizeof(double)));
         if (e == hipSuccess) {
@@ -934,53 +804,37 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, s));
         }
     }
-    // FTree.tree itself is read by the generic kernel (and the debug trace) only: when no entity can reach it, the
-    // rebuild refreshes just the descent table (0.13 instead of 0.24 ms at C4)
-    const bool generic_reachable = S_cap > 1024 || mdt > 65535;      // lists beyond the 16-round variant, or views beyond its 16-bit counts
-    bool need_full = !fast || debug || generic_reachable;
-    if (fast && classified) {
-        for (int c = pc + 1; c < MVHDP_N_CLASSES; c++)
-            if (!(S_cap <= (32 << c) && !(c == 5 && mdt > 65535)) && !cls_fast[c]) need_full = true;
-    } else if (fast) {
-        need_full = need_full || n_chain == 0 || S_cap > 64 * chain[n_chain - 1];
-    }
-    h->last_need_full = need_full;
+    h->last_need_full = p.need_full;
     auto rebuild_trees = [&]() {
-        step(mvhdp_launch_build_trees(mm, false, need_full, s));
-        h->have_trees = true; h->full_trees = need_full; h->trees_inference = false;
+        step(mvhdp_launch_build_trees(mm, false, p.need_full, s));
+        h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
     };
     if (!(flags & MVHDP_SWEEP_REUSE_TREES)) rebuild_trees();
-    else if (need_full && !h->full_trees) {
+    else if (p.need_full && !h->full_trees) {
         step(mvhdp_launch_build_trees(mm, h->trees_inference, true, s));
         h->full_trees = true;
     }
     // where the sweep's atomics land: the delta replica (deferred), or the shared counts themselves (live)
     MvModel mk = mm;
-    if (live) {
+    if (p.live) {
         mk.delta = mm.counts;
-        if (flags & MVHDP_SWEEP_NO_APPLY) { step(mvhdp_launch_live_helper(mm, 0, h->d_stats, s)); h->delta_clean = false; }
-    } else if (!(flags & MVHDP_SWEEP_FROZEN)) {                  // a frozen sweep queues nothing (WRK:587) and leaves the buffer alone
+        if (flags & MVHDP_SWEEP_NO_APPLY) { step(mvhdp_launch_live_helper(mm, 0, d_stats, s)); h->delta_clean = false; }
+    } else if (!p.frozen) {                                      // a frozen sweep queues nothing (WRK:587) and leaves the buffer alone
         if (!h->delta_clean) step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
         h->delta_clean = false;
     }
-    step(hipMemsetAsync(h->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
-    const long long kmax = LLONG_MAX;
-    step(hipMemcpyAsync(h->d_act_key, &kmax, sizeof kmax, hipMemcpyHostToDevice, s));
-    step(hipMemsetAsync(h->d_ovf_meta, 0, 256, s));
-    step(hipEventRecord(h->ev[1], s));
-    unsigned long long ovf[1 + MVHDP_HIST_BINS] = {0};      // [0]: two u32 overflow counts, [1..17]: token histogram
-    static const int ovf_word[3] = {0, 1, 2 + 2 * MVHDP_HIST_BINS};
-    auto blocks_for = [&](int64_t n, const Geo& g) {
-        int64_t need = (n + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
+    // this sweep's counters, "no activation yet", the histograms for the next plan, the class list lengths, the queue heads: one launch
+    step(mvhdp_launch_ctl_reset(d_stats, ST_COUNT, h->d_act_key, (unsigned long long*)h->d_ovf_meta, META_WORDS64, nullptr, h->d_doc_counter, s));
+    step(hipEventRecord(ev_k0, s));
+
+    // entities a class kernel of this segment is sized for (an upper bound is enough: the queue is dynamic)
+    double tok_tot = 0;
+    for (int b = 0; b < MVHDP_HIST_BINS; b++) tok_tot += (double)h->last_hist[b];
+    const bool sizes_known = h->last_ent[MVHDP_N_CLASSES] == 0 && tok_tot > 0;
+    auto blocks_for = [&](int64_t n, const ClassLaunch& g) {
+        const int64_t need = (n + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
         return (int)std::max<int64_t>(1, std::min<int64_t>(need, g.grid));
     };
-    // entities of the longest-first order with more than `tokens` tokens: a prefix of that order (0 without the order)
-    auto longer_than = [&](int64_t tokens) -> int64_t {
-        if (h->tokens_desc.empty()) return mm.D;
-        return std::upper_bound(h->tokens_desc.begin(), h->tokens_desc.end(), tokens, std::greater<int64_t>()) - h->tokens_desc.begin();
-    };
-    int n_activations = 0;                                   // topics activated at segment borders, and the key of the first
-    long long first_act = LLONG_MAX;
     for (int seg = 0; seg < nseg && e == hipSuccess && mm.D > 0; seg++) {
         // segment seg = positions seg, seg + nseg, ... of the order; a prefix [0, P) of the order holds share(P) of them
         auto share = [&](int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
@@ -990,191 +844,112 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
             // index (WRK:523-526): a sweep whose counts are kept current does the same at every segment border -- the
             // segment's first such delta (by entity, view, position) activates its topic before the next segment starts.
             // Not with MVHDP_SWEEP_NO_APPLY: there the caller reduces the key over all document shards first.
-            if ((live || seg_apply) && !(flags & MVHDP_SWEEP_NO_APPLY) && mm.first_inactive >= 0 && e == hipSuccess) {
+            if ((p.live || p.seg_apply) && !(flags & MVHDP_SWEEP_NO_APPLY) && mm.first_inactive >= 0 && e == hipSuccess) {
                 long long key = LLONG_MAX;
                 step(hipMemcpyAsync(&key, h->d_act_key, sizeof key, hipMemcpyDeviceToHost, s));
                 step(hipStreamSynchronize(s));
                 if (e == hipSuccess && key != LLONG_MAX) {
                     const int rc = apply_activation(h, MVHDP_ACT_KEY_TOPIC(key), MVHDP_ACT_KEY_VIEW(key));
-                    if (rc != MVHDP_OK) { cleanup(); return rc; }
-                    if (n_activations++ == 0) first_act = key;
+                    if (rc != MVHDP_OK) return rc;
+                    if (oc.n_activations++ == 0) oc.first_act = key;
                     mk.first_inactive = mm.first_inactive;
-                    const long long none = LLONG_MAX;
-                    step(hipMemcpyAsync(h->d_act_key, &none, sizeof none, hipMemcpyHostToDevice, s));
-                    step(hipStreamSynchronize(s));                       // (`none` lives on this stack frame)
+                    step(mvhdp_launch_ctl_reset(nullptr, 0, h->d_act_key, nullptr, 0, nullptr, nullptr, s));
                 }
             }
-            if ((live && !(flags & MVHDP_SWEEP_REUSE_TREES)) || seg_apply) rebuild_trees();   // from the live / just-updated counts
-            step(hipMemsetAsync(h->d_ovf_meta, 0, 2 * sizeof(unsigned int), s));         // overflow counts of passes 1, 2
-            step(hipMemsetAsync(h->d_ovf_meta + ovf_word[2], 0, sizeof(unsigned int), s));
-            step(hipMemsetAsync(class_counts, 0, MVHDP_N_CLASSES * sizeof(unsigned int), s));
+            if (p.seg_apply) {
+                // the updater catches up before the next segment (UPD:197-218) and the trees follow: tokensPerTopic first (every
+                // leaf needs all of it), then ONE pass per row: counts += delta, delta = 0, the row's tree and 16-bit mirror
+                step(mvhdp_launch_apply_nk(mm, d_stats + ST_NEGATIVE, s));
+                step(mvhdp_launch_build_trees_rows(mm, false, p.need_full, 0, mm.rowbase[M], true, d_stats + ST_NEGATIVE, s));
+                h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
+            } else if (p.live && !(flags & MVHDP_SWEEP_REUSE_TREES)) {                   // from the live counts
+                if (p.live16) {                                                          // (the light rows' live counts are in the mirror)
+                    step(mvhdp_launch_build_trees_from_mirror(mm, p.need_full, s));
+                    h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
+                } else rebuild_trees();
+            }
+            step(mvhdp_launch_ctl_reset(nullptr, 0, nullptr, nullptr, 0, class_counts, h->d_doc_counter, s));
         }
-        step(hipMemsetAsync(h->d_doc_counter, 0, 8 * sizeof(unsigned long long), s));
         if (e != hipSuccess) break;
-        if (classified) {
-            const int64_t H_seg = share(H);
-            ClassifyArgs ca{};
-            ca.order = h->d_doc_order; ca.n = H_seg; ca.start = seg; ca.stride = nseg; ca.primary = pc; ca.counts = class_counts;
-            for (int c = 0; c < MVHDP_N_CLASSES; c++) ca.lists[c] = h->d_lists + (size_t)c * mm.D;
+        const int64_t H_seg = p.route ? share(p.H) : 0;
+        ClassifyArgs ca{};
+        bool used_stream[PLAN_N_STREAMS] = {};
+        if (p.route && H_seg > 0) {
+            if (!h->d_lists) step(hipMalloc(&h->d_lists, (size_t)MVHDP_N_CLASSES * mm.D * sizeof(int32_t)));
+            if (!h->ev_fork) step(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            if (e != hipSuccess) break;
+            ca.order = h->d_doc_order; ca.n = H_seg; ca.start = seg; ca.stride = nseg;
+            for (int c = 0; c < MVHDP_N_CLASSES; c++) { ca.class_map[c] = p.class_map[c]; ca.lists[c] = h->d_lists + (size_t)c * mm.D; }
+            ca.check_views = compute_max_doc_tokens(h) > 65535 ? 1 : 0;
+            ca.counts = class_counts;
+            ca.misrouted = (unsigned long long*)h->d_ovf_meta + META_MISROUTED;
             step(mvhdp_launch_classify(mm, ca, s));
             step(hipEventRecord(h->ev_fork, s));
-            // Streams: the generic and the 16-round class share side stream 4, the 8-round class has side
-            // stream 3 (the runtime multiplexes streams onto few hardware queues: more side streams only
-            // serialise behind each other); narrower classes run on the sweep's own stream ahead of the primary.
-            bool used[MVHDP_N_CLASSES] = {};
-            for (int c = MVHDP_N_CLASSES - 1; c > pc && e == hipSuccess; c--) {       // widest first
-                // class c holds lists of more than 32 << c topics: skipped when the corpus has none -- except that the
-                // generic class also takes the entities with a view too long for the 16-bit counts of the wide variants
-                if (S_cap <= (32 << c) && !(c == 5 && mdt > 65535)) continue;
-                if (H_seg == 0) continue;
-                const int si = (c >= 4) ? 4 : c;
-                hipStream_t st = s;
-                if (c >= 3) {
-                    if (!h->side[si]) step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
-                    if (!h->ev_join[si]) step(hipEventCreateWithFlags(&h->ev_join[si], hipEventDisableTiming));
-                    if (e != hipSuccess) break;
-                    if (!used[si]) step(hipStreamWaitEvent(h->side[si], h->ev_fork, 0));
-                    used[si] = true;
-                    st = h->side[si];
-                }
-                SweepLaunch sc = sl;
+        }
+        // every class kernel of the segment, the widest (longest entities: the sweep's critical path) first; the plan says on which
+        // stream (the widest on the handle's own, the primary on a side stream behind the fork event, see mvhdp_plan.h)
+        for (int c = MVHDP_N_CLASSES - 1; c >= p.pc && e == hipSuccess; c--) {
+            const ClassLaunch& g = p.cls[c];
+            if (!g.used) continue;
+            if (c != p.pc && !(p.route && H_seg > 0)) continue;   // nothing was routed in this segment: the primary alone
+            hipStream_t st = s;
+            if (g.stream != PLAN_STREAM_MAIN && p.route && H_seg > 0) {
+                const int si = g.stream;
+                if (!h->side[si]) step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
+                if (!h->ev_join[si]) step(hipEventCreateWithFlags(&h->ev_join[si], hipEventDisableTiming));
+                if (e != hipSuccess) break;
+                if (!used_stream[si]) step(hipStreamWaitEvent(h->side[si], h->ev_fork, 0));
+                used_stream[si] = true;
+                st = h->side[si];
+            }
+            SweepLaunch sc = sl;
+            sc.doc_counter = h->d_doc_counter + c;
+            sc.wave_bytes = g.wave_bytes; sc.waves_per_block = g.wpb; sc.S_cap = g.S_cap;
+            sc.walk = g.walk; sc.narrow = g.narrow;
+            for (int m = 0; m < MVHDP_MAXM; m++) sc.walk_theta[m] = g.theta[m];
+            int64_t n_c;
+            if (c == p.pc) {
+                // the primary: the routed entities that fit it, then everything too short to exceed it
+                if (p.route && H_seg > 0) { sc.q_list = ca.lists[c]; sc.q_list_count = class_counts + c; }
+                sc.q_order = h->d_doc_order; sc.q_order_start = seg + H_seg * nseg; sc.q_order_stride = nseg; sc.q_order_count = n_seg - H_seg;
+                n_c = n_seg;
+            } else {
                 sc.q_list = ca.lists[c]; sc.q_list_count = class_counts + c;
                 sc.q_order = nullptr; sc.q_order_start = 0; sc.q_order_count = 0;
-                sc.doc_counter = h->d_doc_counter + c;
-                sc.wave_bytes = cls[c].wave_bytes; sc.waves_per_block = cls[c].wpb;
-                if (cls_fast[c]) {
-                    sc.S_cap = std::min(S_cap, 64 << c);
-                    step(mvhdp_launch_sweep_fast(mk, sc, 1 << c, blocks_for(H_seg, cls[c]), debug, st));
-                } else {
-                    sc.S_cap = S_cap;
-                    step(mvhdp_launch_sweep(mk, sc, blocks_for(H_seg, cls[c]), debug, st));
+                // entities this class can receive: those the plan's histogram puts there (and into classes mapped onto it), doubled
+                // for the unevenness of a segment; everything of the prefix when the sizes are not known
+                n_c = H_seg;
+                if (sizes_known) {
+                    unsigned long long cnt = 0;
+                    for (int q = 0; q < MVHDP_N_CLASSES; q++) if (p.class_map[q] == c) cnt += h->last_ent[q];
+                    n_c = std::min<int64_t>(H_seg, (int64_t)(2 * cnt / (unsigned)nseg) + 64);
                 }
             }
-            for (int si = 0; si < MVHDP_N_CLASSES; si++) if (used[si]) step(hipEventRecord(h->ev_join[si], h->side[si]));
-            if (e == hipSuccess) {
-                // the primary variant: the measured entities that fit it, then everything too short to overflow
-                SweepLaunch sp = sl;
-                sp.q_list = ca.lists[pc]; sp.q_list_count = class_counts + pc;
-                sp.q_order = h->d_doc_order; sp.q_order_start = seg + H_seg * nseg; sp.q_order_stride = nseg; sp.q_order_count = n_seg - H_seg;
-                sp.doc_counter = h->d_doc_counter + pc;
-                sp.wave_bytes = fst[0].wave_bytes; sp.waves_per_block = fst[0].wpb;
-                sp.S_cap = std::min(S_cap, 64 * rmax);
-                step(mvhdp_launch_sweep_fast(mk, sp, rmax, blocks_for(n_seg, fst[0]), debug, s));
-            }
-            for (int si = 0; si < MVHDP_N_CLASSES; si++) if (used[si]) step(hipStreamWaitEvent(s, h->ev_join[si], 0));
-        } else if (fast) {
-            // Optimistic chain.  Each later pass reads its entity list and the list's length from device memory (written
-            // by the pass before it, earlier in stream order): no host round trip between passes.  Its grid is sized by
-            // what COULD overflow the pass before -- the entities with more tokens than that variant has slots, a static
-            // prefix of the longest-first order -- and the pass is not launched at all when nothing can.
-            const int32_t* list = nullptr;
-            int64_t bound = n_seg;                                   // upper bound of the entities the next pass can receive
-            for (int p = 0; p < n_chain && e == hipSuccess && bound > 0; p++) {
-                SweepLaunch sp = sl;
-                int32_t* out = (p & 1) ? h->d_overflow2 : h->d_overflow;
-                if (p > 0) {
-                    sp.q_list = list; sp.q_list_count = h->d_ovf_meta + ovf_word[p - 1];
-                    sp.q_order = nullptr; sp.q_order_start = 0; sp.q_order_count = 0;
-                    sp.doc_counter = h->d_doc_counter + p;
-                    sp.slot_hist = nullptr;                 // counted in pass 1 already
-                } else {
-                    sp.q_order = h->d_doc_order; sp.q_order_start = seg; sp.q_order_stride = nseg; sp.q_order_count = n_seg;
-                }
-                sp.overflow_list = out; sp.overflow_count = h->d_ovf_meta + ovf_word[p];
-                sp.wave_bytes = fst[p].wave_bytes; sp.waves_per_block = fst[p].wpb;
-                sp.S_cap = std::min(S_cap, 64 * chain[p]);
-                step(mvhdp_launch_sweep_fast(mk, sp, chain[p], blocks_for(bound, fst[p]), debug, s));
-                list = out;
-                // a wide (16-bit count) variant also hands on the entities with a view beyond 65535 tokens
-                const int64_t too_long = (chain[p] >= 8 && mdt > 65535) ? share(longer_than(65535)) : 0;
-                bound = std::max<int64_t>((S_cap > 64 * chain[p]) ? share(longer_than((int64_t)64 * chain[p])) : 0, too_long);
-            }
-            if (e == hipSuccess && bound > 0 && n_chain > 0) {
-                // last pass: topic lists (or views) beyond the register variants, generic LDS kernel
-                SweepLaunch so = sl;
-                so.q_list = list; so.q_list_count = h->d_ovf_meta + ovf_word[n_chain - 1];
-                so.q_order = nullptr; so.q_order_start = 0; so.q_order_count = 0;
-                so.doc_counter = h->d_doc_counter + 4;
-                so.slot_hist = nullptr;
-                so.wave_bytes = gen.wave_bytes; so.waves_per_block = gen.wpb; so.S_cap = S_cap;
-                step(mvhdp_launch_sweep(mk, so, blocks_for(bound, gen), debug, s));
-            }
-        } else {
-            SweepLaunch sg = sl;
-            sg.q_order_start = seg; sg.q_order_stride = nseg; sg.q_order_count = n_seg;
-            sg.wave_bytes = gen.wave_bytes; sg.waves_per_block = gen.wpb;
-            step(mvhdp_launch_sweep(mk, sg, blocks_for(n_seg, gen), debug, s));
+            if (g.fast) step(mvhdp_launch_sweep_fast(mk, sc, g.r, blocks_for(n_c, g), p.debug, st));
+            else step(mvhdp_launch_sweep(mk, sc, blocks_for(n_c, g), p.debug, st));
         }
-        // segmented deferred sweep: the updater catches up before the next segment (counts += delta, delta = 0)
-        if (seg_apply) step(mvhdp_launch_apply_delta(mm, h->d_stats, s));
+        for (int si = 1; si < PLAN_N_STREAMS; si++) if (used_stream[si]) step(hipEventRecord(h->ev_join[si], h->side[si]));
+        for (int si = 1; si < PLAN_N_STREAMS; si++) if (used_stream[si]) step(hipStreamWaitEvent(s, h->ev_join[si], 0));
     }
-    if (live) {
-        if (flags & MVHDP_SWEEP_NO_APPLY) step(mvhdp_launch_live_helper(mm, 1, h->d_stats, s));   // delta = after - before, counts = snapshot
-        else step(mvhdp_launch_live_helper(mm, 2, h->d_stats, s));                                  // UPD:202-215
+    if (p.seg_apply && mm.D > 0) {                               // the last segment's deltas (the trees are rebuilt by whoever needs them next)
+        step(mvhdp_launch_apply_delta(mm, d_stats, s));
+        h->have_trees = false;
     }
-    step(hipEventRecord(h->ev[2], s));
-    unsigned long long hs[ST_COUNT] = {0};
-    long long act = LLONG_MAX;
-    step(hipMemcpyAsync(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost, s));
-    step(hipMemcpyAsync(&act, h->d_act_key, sizeof act, hipMemcpyDeviceToHost, s));
-    step(hipMemcpyAsync(ovf, h->d_ovf_meta, sizeof ovf, hipMemcpyDeviceToHost, s));
-    step(hipStreamSynchronize(s));
-    if (e == hipSuccess && sl.walk) {
-        double all = 0.0;
-        for (int m = 0; m < M; m++) {
-            const double n = (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS];
-            all += n;
-            if (n >= 64) h->walk_f[m] = (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS + 1] / n;
-            else if (nseg == 1) h->walk_f[m] = 1.0;                  // a view with next to no tokens is never steered
-        }
-        for (int b = 0; b < MVHDP_WALK_BINS; b++) {
-            double c = 0.0;
-            for (int m = 0; m < M; m++)
-                if (h->walk_f[m] >= 0.0 && h->walk_f[m] < 0.35) c += (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS + 2 + b];
-            h->walk_hist[b] = all > 0 ? c / all : 0.0;
-        }
+    if (p.live) {
+        if (p.live16 && mm.D > 0) { step(mvhdp_launch_widen_mirror(mm, s)); h->have_trees = false; }   // the 32-bit table is the model again (the mirror is now ahead of the trees)
+        if (flags & MVHDP_SWEEP_NO_APPLY) {
+            step(mvhdp_launch_live_helper(mm, 1, d_stats, s));   // delta = after - before, counts = snapshot
+            if (nseg > 1 && !(flags & MVHDP_SWEEP_REUSE_TREES)) h->have_trees = false;   // the trees of the last segment belong to the live counts, not to the snapshot
+        } else step(mvhdp_launch_live_helper(mm, 2, d_stats, s));                        // UPD:202-215
     }
-    if (e == hipSuccess && mm.D > 0) {
-        // next sweep: the variant that is cheapest for this sweep's topic-list histogram (topic lists change slowly
-        // between sweeps); entities counted twice (overflow re-run) only make the choice more conservative
-        std::copy(ovf + 1, ovf + 1 + MVHDP_HIST_BINS, h->last_hist);
-        h->rmax_hint = rmax_from_hist(ovf + 1);
-        if (h->rmax_hint <= 2) {
-            // 1 round or 2?  The 1-round variant is proposed as soon as half of the tokens sit in lists of at most 64 topics
-            // (the others then run on their own class kernels: classified dispatch below) and kept only if the sweep's clock
-            // agrees (the trial at the end of this function); a failed trial bans it for a while.
-            double tot = 0, beyond = 0;
-            for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)ovf[1 + b]; if (b >= 1) beyond += (double)ovf[1 + b]; }
-            h->rmax_hint = (beyond <= 0.5 * tot && h->sweeps_done >= h->one_round_banned_until) ? 1 : 2;
-        }
-    }
-    if (e != hipSuccess) { cleanup(); HIPC(h, e); }
-    if (getenv("MVHDP_DEBUG")) {
-        fprintf(stderr, "[mvhdp] walk threshold %.2f (base %.2f, phase %d, dir %+d); tree branch %.4f of tokens, walked on demand %.4f; per view (threshold, tree share):",
-                (double)h->walk_probe_i / MVHDP_WALK_BINS, (double)h->walk_i / MVHDP_WALK_BINS, h->walk_phase, h->walk_dir,
-                (double)hs[ST_TREE] / std::max<double>(1.0, (double)hs[ST_TOKENS]), (double)hs[ST_ONDEMAND] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
-        for (int m = 0; m < M; m++) {
-            const double n = std::max<double>(1.0, (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS]);
-            fprintf(stderr, " (%.2f %.3f)", sl.walk_theta[m], hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS + 1] / n);
-        }
-        fprintf(stderr, "\n");
-    }
-    if (getenv("MVHDP_DEBUG") && hs[ST_T_TOTAL])
-        fprintf(stderr, "[mvhdp] wave cycles: queue %.1f%% prologue %.1f%% view setup %.1f%% chunk head %.1f%% tokens %.1f%% chunk end %.1f%% | %.0f cycles per token per wave\n",
-                100.0 * hs[ST_T_QUEUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_PROLOGUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_VIEW] / hs[ST_T_TOTAL],
-                100.0 * hs[ST_T_CHUNK_HEAD] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_TOKENS] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_CHUNK_END] / hs[ST_T_TOTAL],
-                (double)hs[ST_T_TOTAL] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
-    if (hs[ST_MISCLASS]) { cleanup(); FAIL(h, MVHDP_ERR_HIP, "internal: an entity reached a sweep kernel variant that cannot hold its topic list"); }
+    step(hipEventRecord(ev_k1, s));
+    if (e != hipSuccess) HIPC(h, e);
+    return MVHDP_OK;
+}
 
-    if (debug) {
-        for (int m = 0; m < M; m++)
-            if (sl.tok_dbg[m]) step(hipMemcpy(dbg->tok_dbg[m], sl.tok_dbg[m], (size_t)h->N[m] * 4 * sizeof(double), hipMemcpyDeviceToHost));
-        if (sl.n_trace > 0) step(hipMemcpy(dbg->trace_out, sl.trace_out, (size_t)sl.n_trace * (K + 1) * sizeof(double), hipMemcpyDeviceToHost));
-        cleanup();
-        if (e != hipSuccess) HIPC(h, e);
-    }
-
-    mvhdp_sweep_stats st{};
+static void stats_from_counters(const unsigned long long* hs, long long act, mvhdp_sweep_stats& st)
+{
+    st = mvhdp_sweep_stats{};
     st.tokens = (int64_t)hs[ST_TOKENS]; st.changed = (int64_t)hs[ST_CHANGED];
     st.new_mass_cnt = (int64_t)hs[ST_NEW]; st.topic_doc_mass_cnt = (int64_t)hs[ST_DOC];
     st.word_ftree_mass_cnt = (int64_t)hs[ST_TREE]; st.oov_skipped = (int64_t)hs[ST_OOV];
@@ -1182,21 +957,134 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     st.activation_key = act;
     st.activated_topic = -1; st.activated_modality = -1;
     if (act != LLONG_MAX) { st.activated_topic = MVHDP_ACT_KEY_TOPIC(act); st.activated_modality = MVHDP_ACT_KEY_VIEW(act); }
+}
 
+// after the synchronisation: what the sweep(s) left for the next plan, and the walk search
+static void learn_from_sweep(mvhdp_ctx* h, const SweepPlan& p, const unsigned long long* hs, const unsigned long long* meta_hist, double kernel_ms, bool comparable)
+{
+    const MvModel& mm = h->mm;
+    bool any_walk = false;
+    for (int c = 0; c < MVHDP_N_CLASSES; c++) any_walk = any_walk || (p.cls[c].used && p.cls[c].walk);
+    if (any_walk) h->wt.measured(mm.M, p.nseg, hs + ST_VIEW_BASE);
+    if (mm.D > 0) {
+        std::copy(meta_hist, meta_hist + MVHDP_HIST_BINS, h->last_hist);
+        std::copy(meta_hist + MVHDP_HIST_BINS, meta_hist + MVHDP_HIST_BINS + MVHDP_ENT_BINS, h->last_ent);
+        h->nslots_valid = h->last_ent[MVHDP_N_CLASSES] == 0;        // an abandoned entity (Q11): its list is recounted before the next sweep
+    }
+    if (h->dbg_env) {
+        fprintf(stderr, "[mvhdp] walk threshold %.2f (base %.2f, phase %d, dir %+d, group %d); tree branch %.4f of tokens, walked on demand %.4f; per view tree share:",
+                (double)h->wt.walk_probe_i / MVHDP_WALK_BINS, (double)h->wt.walk_i / MVHDP_WALK_BINS, h->wt.walk_phase, h->wt.walk_dir, h->wt.walk_cls,
+                (double)hs[ST_TREE] / std::max<double>(1.0, (double)hs[ST_TOKENS]), (double)hs[ST_ONDEMAND] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
+        for (int m = 0; m < mm.M; m++) {
+            const double n = std::max<double>(1.0, (double)hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS]);
+            fprintf(stderr, " %.3f", hs[ST_VIEW_BASE + m * MVHDP_VIEW_STATS + 1] / n);
+        }
+        fprintf(stderr, "\n");
+        if (hs[ST_T_TOTAL])
+            fprintf(stderr, "[mvhdp] wave cycles: queue %.1f%% prologue %.1f%% view setup %.1f%% chunk head %.1f%% tokens %.1f%% chunk end %.1f%% | %.0f cycles per token per wave\n",
+                    100.0 * hs[ST_T_QUEUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_PROLOGUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_VIEW] / hs[ST_T_TOTAL],
+                    100.0 * hs[ST_T_CHUNK_HEAD] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_TOKENS] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_CHUNK_END] / hs[ST_T_TOTAL],
+                    (double)hs[ST_T_TOTAL] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
+    }
+    const double tokens = (double)hs[ST_TOKENS];
+    h->wt.observe(comparable && tokens > 0, p.walk_cfg, mm.M, tokens > 0 ? kernel_ms * 1e6 / tokens : 0.0);
+}
+
+static void debug_print_plan(const mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx)
+{
+    double tot = 0, b1 = 0, b2 = 0;                           // token share by topic-list size: <= 64, <= 128 slots
+    for (int b = 0; b < MVHDP_HIST_BINS; b++) { tot += (double)h->last_hist[b]; if (b < 1) b1 += (double)h->last_hist[b]; if (b < 2) b2 += (double)h->last_hist[b]; }
+    fprintf(stderr, "[mvhdp] sweep %u: %s primary class %d, routed prefix %lld, S_cap %d, %d segment(s); tokens in lists <=64: %.4f <=128: %.4f; kernels:",
+            sweep_idx, p.fast ? "register-resident" : "generic", p.pc, (long long)p.H, p.S_cap, p.nseg, b1 / std::max(1.0, tot), b2 / std::max(1.0, tot));
+    for (int c = 0; c < MVHDP_N_CLASSES; c++)
+        if (p.cls[c].used)
+            fprintf(stderr, " [class %d %s grid %d wpb %d lds %zu stream %d%s%s theta0 %.2f ents %llu]", c, p.cls[c].fast ? "fast" : "generic", p.cls[c].grid, p.cls[c].wpb, p.cls[c].lds,
+                    p.cls[c].stream, p.cls[c].walk ? " walk" : "", p.cls[c].narrow ? " narrow" : "", p.cls[c].theta[0], (unsigned long long)h->last_ent[c]);
+    fprintf(stderr, "\n");
+}
+
+static int sweep_preconditions(mvhdp_ctx* h, uint32_t flags)
+{
+    int rc = require_corpus(h); if (rc) return rc;
+    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "sweep before set_hyper");
+    if (!h->have_counts) FAIL(h, MVHDP_ERR_STATE, "sweep before build_counts/set_counts");
+    if ((flags & (MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_FROZEN)) && !h->have_trees) FAIL(h, MVHDP_ERR_STATE, "REUSE_TREES / FROZEN without trees");
+    if (h->rows_applied >= 0) FAIL(h, MVHDP_ERR_STATE, "sweep: an mvhdp_apply_delta_begin bracket is open (call mvhdp_apply_delta_end)");
+    if (h->delta_pending && !(flags & MVHDP_SWEEP_FROZEN))
+        FAIL(h, MVHDP_ERR_STATE, "sweep: the previous NO_APPLY sweep's deltas have not been applied (mvhdp_apply_delta)");
+    if (h->counts_stale && !(flags & MVHDP_SWEEP_FROZEN))
+        FAIL(h, MVHDP_ERR_STATE, "sweep: the assignments were replaced after the counts were built (call mvhdp_build_counts, mvhdp_set_counts or mvhdp_counts_written first)");
+    return MVHDP_OK;
+}
+
+static int set_generic_lds(mvhdp_ctx* h, const SweepPlan& p)
+{
+    size_t lds = 0;                                          // the generic kernel may need > 64 KiB of dynamic LDS
+    for (int c = 0; c < MVHDP_N_CLASSES; c++) if (p.cls[c].used && !p.cls[c].fast) lds = std::max(lds, p.cls[c].lds);
+    if (lds > 65536 && lds > h->lds_attr_set) { HIPC(h, mvhdp_sweep_set_max_lds(lds)); h->lds_attr_set = lds; }
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
+                           const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    int rc = sweep_preconditions(h, flags); if (rc) return rc;
+    HIPC(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    rc = ensure_slot_counts(h); if (rc) return rc;
+    const bool debug = dbg != nullptr;
+    PlanIn in; fill_plan_in(h, flags, debug, false, in);
+    SweepPlan p;
+    plan_sweep(in, h->tu, h->wt, p);
+    if (p.err) FAIL(h, p.err, p.msg);
+    rc = set_generic_lds(h, p); if (rc) return rc;
+    if (h->dbg_env) debug_print_plan(h, p, sweep_idx);
+    DebugBufs db;
+    if (debug) { rc = alloc_debug(h, dbg, db); if (rc) return rc; }
+
+    HIPC(h, hipEventRecord(h->ev[0], s));
+    SweepOutcome oc;
+    rc = enqueue_sweep(h, p, sweep_idx, seed, p_override, debug ? &db : nullptr, h->d_stats, h->ev[1], h->ev[2], oc);
+    if (rc) { db.release(); return rc; }
+    unsigned long long ctl[ST_COUNT + 1 + META_WORDS64] = {0};           // counters | activation key | histograms: one copy
+    hipError_t e = hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { db.release(); HIPC(h, e); }
+    const unsigned long long* hs = ctl;
+    const long long act = (long long)ctl[ST_COUNT];
+    const unsigned long long* meta = ctl + ST_COUNT + 1;
+    if (hs[ST_MISCLASS] || meta[META_MISROUTED]) {
+        db.release();
+        h->nslots_valid = false;
+        FAIL(h, MVHDP_ERR_HIP, "internal: an entity reached a sweep kernel variant that cannot hold its topic list");
+    }
+    if (debug) {
+        for (int m = 0; m < mm.M; m++)
+            if (db.tok_dbg[m] && e == hipSuccess) e = hipMemcpy(dbg->tok_dbg[m], db.tok_dbg[m], (size_t)h->N[m] * 4 * sizeof(double), hipMemcpyDeviceToHost);
+        if (db.n_trace > 0 && e == hipSuccess) e = hipMemcpy(dbg->trace_out, db.trace_out, (size_t)db.n_trace * (mm.K + 1) * sizeof(double), hipMemcpyDeviceToHost);
+        db.release();
+        if (e != hipSuccess) HIPC(h, e);
+    }
+
+    mvhdp_sweep_stats st;
+    stats_from_counters(hs, act, st);
+    int n_activations = oc.n_activations;
     int ret = MVHDP_OK;
-    if (flags & MVHDP_SWEEP_FROZEN) {
+    if (p.frozen) {
         // nothing was queued (WRK:587): the delta buffer is untouched
     } else if (flags & MVHDP_SWEEP_NO_APPLY) {
         h->delta_pending = true;
-    } else if (live || seg_apply) {
+    } else if (p.live || p.seg_apply) {
         // the counts are already updated; what is left of the updater's work is the topic activation of the last segment
         h->have_trees = false;
-        if (seg_apply) h->delta_clean = true;                        // apply_delta_kernel zeroed what it added
+        if (p.seg_apply) h->delta_clean = true;                      // apply_delta_kernel zeroed what it added
         ret = apply_activation(h, st.activated_topic, st.activated_modality);
         if (st.activated_topic >= 0) n_activations++;
-        if (first_act != LLONG_MAX) {                                // report the sweep's first activation
-            st.activation_key = first_act;
-            st.activated_topic = MVHDP_ACT_KEY_TOPIC(first_act); st.activated_modality = MVHDP_ACT_KEY_VIEW(first_act);
+        if (oc.first_act != LLONG_MAX) {                             // report the sweep's first activation
+            st.activation_key = oc.first_act;
+            st.activated_topic = MVHDP_ACT_KEY_TOPIC(oc.first_act); st.activated_modality = MVHDP_ACT_KEY_VIEW(oc.first_act);
         }
         if (ret == MVHDP_OK && hs[ST_NEGATIVE]) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
     } else {
@@ -1210,91 +1098,184 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
     st.sweep_kernel_ms = ms_k; st.total_ms = ms_t;
     st.activations = n_activations; st.reserved = 0;
-    // the 1-round trial (see mvhdp_ctx::last_primary): plain full sweeps only, so that the two times are comparable
-    h->sweeps_done++;
-    const bool plain = fast && nseg == 1 && !debug && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) &&
-                       !getenv("MVHDP_FORCE_RMAX") && !getenv("MVHDP_FORCE_MODE") && st.tokens > 0;
-    if (plain) {
-        const double ns = (double)ms_k * 1e6 / (double)st.tokens;    // (a classify pass is inside ms_k)
-        if (rmax == 1 && h->last_primary == 2 && h->last_ns_per_token > 0) h->two_round_ns_per_token = h->last_ns_per_token;
-        if (rmax == 1 && h->two_round_ns_per_token > 0 && ns > 0.995 * h->two_round_ns_per_token) {
-            const int high = MVHDP_WALK_BINS * 4 / 5;
-            if (!h->one_round_retry && !theta_env && walk_any && h->walk_cls == 0 && h->walk_i < high) {
-                // The 1-round variant is the bandwidth-bound one: it gets its edge from a HIGH walk threshold, and the search
-                // has not taken it there yet (it inherits nothing from the wider variants).  One more sweep at 0.8 decides.
-                h->one_round_retry = true;
-                h->walk_i = high; h->walk_phase = 0; h->walk_idle_until = h->sweeps_done + 1;
-            } else {
-                h->one_round_retry = false;
-                if (h->rmax_hint == 1) h->rmax_hint = 2;
-                h->one_round_banned_until = h->sweeps_done + h->one_round_ban;
-                h->one_round_ban = std::min<long long>(32, h->one_round_ban * 2);
-                h->two_round_ns_per_token = 0;
-            }
-        } else if (rmax == 1) {                                      // the trial is over: the 1-round variant stays
-            if (h->two_round_ns_per_token > 0) h->one_round_ban = 4;
-            h->two_round_ns_per_token = 0;
-            h->one_round_retry = false;
-        }
-        h->last_primary = rmax; h->last_ns_per_token = ns;
-    } else h->last_primary = 0;
-    // the walk-threshold search (see mvhdp_ctx::walk_i): among sweeps of one kernel configuration and update mode only
-    const bool comparable = fast && !debug && !theta_env && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN)) && st.tokens > 0;
-    const int walk_cfg = rmax * 2 + (classified ? 1 : 0) + 64 * nseg + (live ? 1 << 16 : 0) + (seg_apply ? 1 << 17 : 0);
-    if (!comparable || h->walk_cfg != walk_cfg) {
-        h->walk_phase = 0;
-        h->walk_cfg = comparable ? walk_cfg : -1;
-        if (comparable) h->walk_ns_a1 = 0.0;
-    }
-    if (comparable && !walk_any) h->walk_phase = 0;
-    if (comparable && walk_any) {
-        const double ns = (double)ms_k * 1e6 / (double)st.tokens;
-        if (h->walk_phase == 0) {
-            h->walk_ns_a1 = ns;
-            if (h->sweeps_done >= h->walk_idle_until) h->walk_phase = 1;
-        } else if (h->walk_phase == 1) {
-            h->walk_ns_b = ns; h->walk_b_i = h->walk_probe_i; h->walk_phase = 2;
-        } else {
-            const double base = 0.5 * (h->walk_ns_a1 + ns);
-            const int step = h->walk_b_i - h->walk_i;
-            const bool far = h->walk_far;
-            h->walk_far = false;
-            // leaving threshold 0 also changes the kernel flavour: ask for more there (no flapping between the two)
-            const double need = h->walk_i == 0 ? 0.005 : 0.0025;
-            if (std::fabs(h->walk_ns_a1 - ns) > 0.025 * base) {          // the A sweeps disagree (a variant change, a jump of the chain): no verdict
-                h->walk_ns_a1 = ns; h->walk_phase = 1; h->walk_far = far;
-            } else if (step != 0 && h->walk_ns_b < base * (1.0 - need)) {
-                h->walk_i = h->walk_b_i;
-                h->walk_ns_a1 = h->walk_ns_b;                            // the B sweep is the first A sweep of the next step
-                h->walk_fails = 0; h->walk_wait = 4; h->walk_phase = 1;
-                if (step > 0) h->walk_maxj = std::min(6, h->walk_maxj * 2);
-                if (step > 0 && h->walk_ns_b < base * (1.0 - 0.008)) h->walk_cap = std::min(0.05, h->walk_cap * 2.0);
-                if (far) h->walk_far = true;                             // half again
-            } else if (step > 1) {                                       // a long step that did not pay: a shorter one, same direction
-                h->walk_ns_a1 = ns;
-                h->walk_maxj = std::max(1, step / 2);
-                h->walk_cap = std::max(0.004, h->walk_cap * 0.5);
-                h->walk_phase = 1;
-            } else if (far) {                                            // half the threshold is no better: back to single steps
-                h->walk_ns_a1 = ns;
-                h->walk_dir = 1;
-                h->walk_phase = 1;
-            } else {
-                h->walk_ns_a1 = ns;
-                h->walk_dir = -h->walk_dir;
-                h->walk_phase = 1;
-                if (++h->walk_fails >= 2) {
-                    h->walk_fails = 0;
-                    h->walk_idle_until = h->sweeps_done + h->walk_wait;
-                    h->walk_wait = std::min(64, h->walk_wait * 2);
-                    h->walk_phase = 0;
-                    h->walk_far = true;
-                }
-            }
-        }
-    }
+    const bool comparable = p.fast && !debug && !h->tu.walk_fixed && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN));
+    learn_from_sweep(h, p, hs, meta + META_HIST, ms_k, comparable);
     if (stats) *stats = st;
     return ret;
+}
+
+// n sweeps (indices first_idx .. first_idx + n - 1) put on the device back to back: ONE plan, no host round trip between the
+// sweeps (the iteration loop PTM:1146-1239 without its per-iteration barrier on the host), the statistics of every sweep
+// collected on the device and read once.  Same integers as n calls of mvhdp_sweep: the plan decides which kernel variant visits
+// an entity and when a word tree is walked, never what is sampled.  Falls back to n single calls where a sweep needs the host in
+// between (inactive topics waiting for activation, view weights or debug output from the host, NO_APPLY).
+extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats)
+{
+    CHECK_H(h);
+    if (n < 0) FAIL(h, MVHDP_ERR_INVALID_ARG, "sweep_many: n < 0");
+    if (n == 0) return MVHDP_OK;
+    MvModel& mm = h->mm;
+    const bool frozen = (flags & MVHDP_SWEEP_FROZEN) != 0;
+    if (n == 1 || mm.first_inactive >= 0 || ((flags & MVHDP_SWEEP_NO_APPLY) && !frozen) || n > 4096) {
+        for (int i = 0; i < n; i++) {
+            const int rc = mvhdp_sweep(h, first_idx + (uint32_t)i, seed, flags, nullptr, nullptr, stats ? stats + i : nullptr);
+            if (rc) return rc;
+        }
+        return MVHDP_OK;
+    }
+    int rc = sweep_preconditions(h, flags); if (rc) return rc;
+    HIPC(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    rc = ensure_slot_counts(h); if (rc) return rc;
+    PlanIn in; fill_plan_in(h, flags, false, true, in);
+    SweepPlan p;
+    plan_sweep(in, h->tu, h->wt, p);
+    if (p.err) FAIL(h, p.err, p.msg);
+    rc = set_generic_lds(h, p); if (rc) return rc;
+    if (h->dbg_env) debug_print_plan(h, p, first_idx);
+    if (h->stats_many_cap < n) {
+        if (h->d_stats_many) { hipFree(h->d_stats_many); h->d_stats_many = nullptr; h->stats_many_cap = 0; }
+        HIPC(h, hipMalloc(&h->d_stats_many, (size_t)n * ST_COUNT * sizeof(unsigned long long)));
+        h->stats_many_cap = n;
+    }
+    while ((int)h->ev_many.size() < 2 * n) { hipEvent_t ev; HIPC(h, hipEventCreate(&ev)); h->ev_many.push_back(ev); }
+    HIPC(h, hipEventRecord(h->ev[0], s));
+    const bool reuse_after_first = false;
+    (void)reuse_after_first;
+    for (int i = 0; i < n; i++) {
+        SweepOutcome oc;
+        unsigned long long* d_st = h->d_stats_many + (size_t)i * ST_COUNT;
+        rc = enqueue_sweep(h, p, first_idx + (uint32_t)i, seed, nullptr, nullptr, d_st, h->ev_many[2 * i], h->ev_many[2 * i + 1], oc);
+        if (rc) return rc;
+        if (!p.frozen && !p.live && !p.seg_apply) {
+            // the updater's pass (UPD:197-218) in stream order; negative counts are counted into this sweep's counters
+            HIPC(h, mvhdp_launch_apply_delta(mm, d_st, s));
+            h->have_trees = false; h->delta_clean = true;
+        } else if (p.live || p.seg_apply) {
+            h->have_trees = false;
+            if (p.seg_apply) h->delta_clean = true;
+        }
+    }
+    HIPC(h, hipEventRecord(h->ev[3], s));
+    std::vector<unsigned long long> hs((size_t)n * ST_COUNT);
+    unsigned long long meta[META_WORDS64] = {0};
+    HIPC(h, hipMemcpyAsync(hs.data(), h->d_stats_many, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPC(h, hipMemcpyAsync(meta, h->d_ovf_meta, sizeof meta, hipMemcpyDeviceToHost, s));
+    HIPC(h, hipStreamSynchronize(s));
+    float ms_t = 0;
+    hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
+    int ret = MVHDP_OK;
+    double ms_sum = 0; unsigned long long tok_sum = 0;
+    for (int i = 0; i < n; i++) {
+        const unsigned long long* hi = hs.data() + (size_t)i * ST_COUNT;
+        mvhdp_sweep_stats st;
+        stats_from_counters(hi, LLONG_MAX, st);
+        float ms_k = 0;
+        hipEventElapsedTime(&ms_k, h->ev_many[2 * i], h->ev_many[2 * i + 1]);
+        st.sweep_kernel_ms = ms_k; st.total_ms = ms_t / n;
+        ms_sum += ms_k; tok_sum += hi[ST_TOKENS];
+        if (stats) stats[i] = st;
+        if (hi[ST_MISCLASS]) { h->nslots_valid = false; FAIL(h, MVHDP_ERR_HIP, "internal: an entity reached a sweep kernel variant that cannot hold its topic list"); }
+        if (hi[ST_NEGATIVE] && ret == MVHDP_OK) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
+    }
+    if (meta[META_MISROUTED]) { h->nslots_valid = false; FAIL(h, MVHDP_ERR_HIP, "internal: an entity could not be routed to a sweep kernel"); }
+    // the batch counts as one observation of the walk search (mean kernel time per token)
+    std::vector<unsigned long long> acc(ST_COUNT, 0);
+    for (int i = 0; i < n; i++) for (int k = 0; k < ST_COUNT; k++) acc[k] += hs[(size_t)i * ST_COUNT + k];
+    const bool comparable = p.fast && !h->tu.walk_fixed && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN));
+    learn_from_sweep(h, p, acc.data(), meta + META_HIST, ms_sum, comparable);
+    (void)tok_sum;
+    return ret;
+}
+
+// ---- tuning: what a host may pin, what the library has learnt (so that a document shard, a resumed chain or another handle on
+// the same corpus does not search again) ----
+extern "C" int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t)
+{
+    CHECK_H(h);
+    if (!t) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_tuning: null");
+    memset(t, 0, sizeof *t);
+    t->force_primary = h->tu.force_primary; t->narrow = h->tu.narrow; t->walk_fixed = h->tu.walk_fixed;
+    t->single_stream = h->tu.single_stream; t->primary_min_share = h->tu.primary_min_share; t->live16 = h->tu.live16;
+    for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) { t->walk_theta[m] = h->tu.walk_theta[m]; t->tree_branch_share[m] = h->wt.walk_f[m]; }
+    for (int g = 0; g < WALK_GROUPS; g++) t->learnt_walk_step[g] = g == h->wt.walk_cls ? h->wt.walk_i : h->wt.walk_i_by[g];
+    t->learnt_walk_step[3] = -1;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t)
+{
+    CHECK_H(h);
+    if (!t) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_tuning: null");
+    const int fp = t->force_primary;
+    if (!(fp == 0 || fp == 1 || fp == 2 || fp == 4 || fp == 8 || fp == 16 || fp == 32)) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_tuning: force_primary must be 0, 1, 2, 4, 8, 16 or 32");
+    if (t->primary_min_share < 0.0 || t->primary_min_share > 1.0) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_tuning: primary_min_share outside [0, 1]");
+    for (int g = 0; g < WALK_GROUPS; g++) if (t->learnt_walk_step[g] < -1 || t->learnt_walk_step[g] > MVHDP_WALK_BINS) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_tuning: learnt_walk_step outside [-1, 20]");
+    h->tu.force_primary = fp; h->tu.narrow = t->narrow; h->tu.walk_fixed = t->walk_fixed ? 1 : 0;
+    h->tu.single_stream = t->single_stream ? 1 : 0;
+    h->tu.live16 = t->live16 < 0 ? -1 : (t->live16 ? 1 : 0);
+    h->tu.primary_min_share = t->primary_min_share > 0.0 ? t->primary_min_share : 0.10;
+    for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) h->tu.walk_theta[m] = t->walk_theta[m];
+    if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) h->wt.restore(t->learnt_walk_step, t->tree_branch_share, h->mm.M);
+    return MVHDP_OK;
+}
+
+// The planner and the walk search without a device (tests/test_plan.py): pure functions of their arguments.
+extern "C" int mvhdp_plan_probe(const mvhdp_plan_input* pi, const mvhdp_tuning* t, mvhdp_plan_output* po)
+{
+    if (!pi || !po) return MVHDP_ERR_INVALID_ARG;
+    PlanIn in;
+    in.K = pi->num_topics; in.M = pi->num_modalities; in.D = pi->num_entities; in.mdt = pi->max_entity_tokens;
+    if (in.K < 1 || in.K > MVHDP_MAX_TOPICS || in.M < 1 || in.M > MVHDP_MAX_MODALITIES || in.D < 0) return MVHDP_ERR_INVALID_ARG;
+    in.have_order = true;
+    for (int c = 0; c < 5; c++) in.n_longer[c] = pi->entities_longer_than[c];
+    for (int b = 0; b < MVHDP_HIST_BINS; b++) in.tok_hist[b] = pi->tokens_by_list_rounds[b];
+    for (int b = 0; b < MVHDP_ENT_BINS; b++) in.ent_hist[b] = pi->entities_by_class[b];
+    in.flags = pi->flags; in.debug = pi->debug != 0; in.batch = pi->batch != 0; in.trees_current = pi->trees_current != 0;
+    in.first_inactive = -1;
+    in.num_cus = pi->num_cus > 0 ? pi->num_cus : 256;
+    for (int c = 0; c < MVHDP_N_CLASSES; c++) for (int f = 0; f < 3; f++) in.regs.regs[c][f] = pi->kernel_registers[c][f];
+    PlanTuning tu;
+    WalkTuner wt;
+    wt.init_defaults(in.K);
+    if (t) {
+        tu.force_primary = t->force_primary; tu.narrow = t->narrow; tu.walk_fixed = t->walk_fixed; tu.single_stream = t->single_stream;
+        tu.live16 = t->live16;
+        if (t->primary_min_share > 0) tu.primary_min_share = t->primary_min_share;
+        for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) tu.walk_theta[m] = t->walk_theta[m];
+        if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) wt.restore(t->learnt_walk_step, t->tree_branch_share, in.M);
+    }
+    SweepPlan p;
+    plan_sweep(in, tu, wt, p);
+    memset(po, 0, sizeof *po);
+    po->status = p.err;
+    if (p.err) return MVHDP_OK;
+    po->segments = p.nseg; po->primary_class = p.pc; po->routed_prefix = p.H; po->register_resident = p.fast ? 1 : 0;
+    po->need_full_trees = p.need_full ? 1 : 0; po->dominant_class = p.dominant;
+    for (int c = 0; c < MVHDP_N_CLASSES; c++) {
+        po->class_used[c] = p.cls[c].used ? 1 : 0; po->class_map[c] = p.class_map[c];
+        po->class_stream[c] = p.cls[c].stream; po->class_grid[c] = p.cls[c].grid; po->class_lds_bytes[c] = (int64_t)p.cls[c].lds;
+        po->class_walk[c] = p.cls[c].walk; po->class_narrow[c] = p.cls[c].narrow; po->class_register_resident[c] = p.cls[c].fast ? 1 : 0;
+        po->class_theta0[c] = p.cls[c].theta[0];
+    }
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_tuner_probe(int32_t num_modalities, const double* tree_branch_share, const double* u1_hist, const double* ns_by_step /*[21]*/,
+                                 int32_t n_sweeps, int32_t group, int32_t* steps_out /*[n_sweeps]*/)
+{
+    if (!tree_branch_share || !ns_by_step || !steps_out || num_modalities < 1 || num_modalities > MVHDP_MAX_MODALITIES || n_sweeps < 0) return MVHDP_ERR_INVALID_ARG;
+    WalkTuner wt;
+    if (group < 0 || group >= WALK_GROUPS) return MVHDP_ERR_INVALID_ARG;
+    for (int m = 0; m < num_modalities; m++) wt.walk_f[m] = tree_branch_share[m];
+    for (int b = 0; b < MVHDP_WALK_BINS; b++) wt.walk_hist[b] = u1_hist ? u1_hist[b] : 0.0;
+    for (int i = 0; i < n_sweeps; i++) {
+        double theta[WALK_GROUPS][MVHDP_MAXM]; bool measure;
+        wt.propose(group, num_modalities, theta, &measure);
+        steps_out[i] = wt.walk_probe_i;
+        wt.observe(true, 1, num_modalities, ns_by_step[std::max(0, std::min(MVHDP_WALK_BINS, wt.walk_probe_i))]);
+    }
+    return MVHDP_OK;
 }
 
 extern "C" int mvhdp_get_view_weights(mvhdp_handle h, double* p)
@@ -1323,7 +1304,7 @@ extern "C" int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** de
 extern "C" int mvhdp_counts_written(mvhdp_handle h)
 {
     CHECK_H(h);
-    h->have_counts = true; h->have_trees = false;
+    h->have_counts = true; h->have_trees = false; h->counts_stale = false;
     return MVHDP_OK;
 }
 

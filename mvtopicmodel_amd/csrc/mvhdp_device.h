@@ -19,10 +19,18 @@ struct MvModel {
     const int64_t* doc_off[MVHDP_MAXM];
     const int32_t* tok[MVHDP_MAXM];
     int32_t* z[MVHDP_MAXM];
+    // [D] distinct topics of each entity's current assignments over all views = the size of its topic list (WRK:376-391) at
+    // the NEXT visit.  Every sweep kernel writes it when it leaves an entity (slot_count_kernel after assignments came from
+    // the host), so the next sweep routes every entity to the narrowest kernel variant that holds it without measuring
+    // anything (route_kernel); 0xFFFF = not known (an abandoned entity, Q11): the host recounts before the next sweep.
+    uint16_t* nslots;
     // model: counts = [sumV*K n_wk | M*K n_k], delta same layout
     int32_t* counts;
     uint16_t* counts16;                // [sumV*K] min(n_wk, 65535): written row by row whenever the row's tree is built (build_trees_kernel),
                                        //   so it is the sweep-start n_wk of every sweep that starts with the trees; read by the NARROW kernel flavour
+    uint8_t* heavy;                    // [sumV] 1: the row's type holds more than 65534 tokens in all: its mirror cells are all 65535 and its
+                                       //   counts live in the 32-bit table only.  A LIGHT row's cells can never reach 65535, so a live sweep may keep
+                                       //   them current IN the mirror (two cells per 32-bit word, +-1 / +-65536 atomics, no carry) -- SweepLaunch::live16
     int32_t* delta;
     double* trees;                     // [sumV][2K]  FTree.tree (FT:21)
     double* root;                      // [sumV]      tree[1]
@@ -54,7 +62,7 @@ struct SweepLaunch {
     unsigned long long* stats;         // [16] device counters
     long long* act_key;                // activation key (atomicMin)
     // Work queue: waves pull entities in batches from one head.  Queue position q maps to an entity through two
-    // segments: first the entities the classify pass listed for this kernel (q_list[0 .. *q_list_count)), then
+    // segments: first the entities the route pass listed for this kernel (q_list[0 .. *q_list_count)), then
     // q_order_count entities of a static order (q_order[q_order_start + i*q_order_stride], or the identity when q_order
     // is null).  The stride cuts the longest-first order into interleaved segments (MVHDP_SWEEP_LIVE): every segment
     // sees the same length distribution, longest first.
@@ -63,15 +71,17 @@ struct SweepLaunch {
     const unsigned int* q_list_count;  // device memory (written by classify_kernel earlier in stream order), or nullptr = 0
     const int32_t* q_order;
     int64_t q_order_start, q_order_count, q_order_stride;
-    int32_t* overflow_list;            // optimistic mode: entities whose topic list exceeds this variant's slots are appended here
-    unsigned int* overflow_count;      //   and re-run by a wider kernel; nullptr in classified mode (an overflow is then an error)
     // Speculative tree walk of the chunk head: a token's word tree is walked up front iff its first uniform u1 >= walk_theta[m]
     // (only a large u1 can reach the tree branch, WRK:529-535); a token that reaches it unwalked walks on demand, same
     // arithmetic, same result.  0 = walk every token.
     double walk_theta[MVHDP_MAXM];
     int32_t walk;                      // 1: launch the kernel flavour that knows about thresholds (and counts the per-view statistics)
-    int32_t narrow;                    // 1: the flavour that gathers n_wk from the 16-bit mirror (1-round walk flavour only; never with LIVE)
-    unsigned long long* slot_hist;     // [17] tokens of the entities with ceil(list size/64) = 1..16, >16 (sizes the next sweep's variant)
+    int32_t narrow;                    // 1: the flavour that gathers n_wk from the 16-bit mirror
+    int32_t live16;                    // 1 (MVHDP_SWEEP_LIVE with narrow): the sweep's n_wk atomics of LIGHT rows go to the mirror itself, which is then the
+                                       //   authoritative copy of those rows until the next tree build / widen pass; heavy rows: the 32-bit table as ever
+    unsigned long long* slot_hist;     // [MVHDP_HIST_BINS] tokens of the entities whose NEW topic list has ceil(size/64) = 1..16, >16, then
+                                       // [MVHDP_ENT_BINS] entities per kernel class 0..5 of that new list ([6]: not known, [7]: spare) --
+                                       // what the next sweep's plan is made from
     // debug
     double* tok_dbg[MVHDP_MAXM];
     int32_t n_trace;
@@ -96,11 +106,18 @@ hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bo
 // the same for the rows [row_begin, row_end) only; apply_first: counts += delta, delta = 0 for those rows before the build
 hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
                                          bool apply_first, unsigned long long* negatives, hipStream_t s);
+// a segment border of a live16 sweep: the light rows are read from the 16-bit mirror (and written through to the 32-bit table), the heavy ones from the table
+hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s);
+// end of a live16 sweep: counts <- mirror for the light rows
+hipError_t mvhdp_launch_widen_mirror(const MvModel& mm, hipStream_t s);
 hipError_t mvhdp_launch_apply_nk(const MvModel& mm, unsigned long long* negatives, hipStream_t s);
 hipError_t mvhdp_launch_init_from_trees(const MvModel& mm, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s);
 hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s);
+// zeroes the given counter arrays (any may be null) and sets *act_key to "none", in one launch
+hipError_t mvhdp_launch_ctl_reset(unsigned long long* stats, int n_stats, long long* act_key, unsigned long long* meta, int n_meta,
+                                  unsigned int* class_counts, unsigned long long* qheads, hipStream_t s);
 // MVHDP_SWEEP_LIVE helpers: 0 = delta <- -counts, 1 = delta <- counts + delta (after - before), counts <- snapshot, 2 = count negatives
 hipError_t mvhdp_launch_live_helper(const MvModel& mm, int which, unsigned long long* stats, hipStream_t s);
 hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, int32_t hist_len,
@@ -112,26 +129,44 @@ hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double
                                unsigned long long* nonzero, hipStream_t s);
 hipError_t mvhdp_launch_gamma_doc_stats(const MvModel& mm, int m, double gamma_m, uint32_t seed_lo, uint32_t seed_hi, uint32_t round,
                                         double* partial, int n_blocks, hipStream_t s);
+// counts every entity's topic list from z: writes MvModel::nslots and the histograms of SweepLaunch::slot_hist
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s);
 struct DocTopicCarry { const int64_t* src[MVHDP_MAXM]; };   // per view [D]: the entity whose counts score entity d (PTM:2873-2886)
 hipError_t mvhdp_launch_doc_topic_prop(const MvModel& mm, const DocTopicCarry& carry, const double* w_dev, int64_t d0, int64_t d1, double* out_dev, hipStream_t s);
 // Classes of the sweep kernels by topic-list size: 0..4 = the register-resident variants with 64 << c slots, 5 = the generic LDS kernel
 #define MVHDP_N_CLASSES 6
 struct ClassifyArgs {
-    const int32_t* order;              // entities to classify: order[start + i*stride], i in [0, n) (nullptr = identity)
+    const int32_t* order;              // entities to route: order[start + i*stride], i in [0, n) (nullptr = identity)
     int64_t n, start, stride;
-    int32_t primary;                   // class of the primary kernel: narrower entities are listed there too
+    int32_t class_map[MVHDP_N_CLASSES]; // class of a topic list -> the launched kernel class that takes it (the primary for narrower lists, the
+                                       // next wider launched class where a class has no kernel of its own); -1: nobody (an error, counted)
+    int32_t check_views;               // 1: some entity has a view beyond 65535 tokens (then the views' lengths are looked at)
     int32_t* lists[MVHDP_N_CLASSES];   // per class, capacity n
     unsigned int* counts;              // [MVHDP_N_CLASSES]
+    unsigned long long* misrouted;     // counts entities whose list size is not known (the host should have recounted)
 };
 hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipStream_t s);
 size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax);
 hipError_t mvhdp_launch_sweep_fast(const MvModel& mm, const SweepLaunch& sl, int rmax, int grid_blocks, bool debug, hipStream_t s);
 int mvhdp_sweep_fast_occupancy(int rmax, bool debug, bool walk, int block_threads, size_t lds_bytes);
 int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_bytes);
+// VGPRs of the compiled sweep kernel of class c (0..4 register-resident, 5 generic); flavour 0: plain, 1: walk, 2: debug
+int mvhdp_sweep_kernel_regs(int cls, int flavour);
+int mvhdp_sweep_generic_regs(bool debug);
 
 #define MVHDP_DOC_BATCH 2
 #define MVHDP_HIST_BINS 17
+#define MVHDP_ENT_BINS 8
+#define MVHDP_NSLOTS_UNKNOWN 0xFFFFu
+
+// kernel class of a topic list of n slots (0..4: the register-resident variants with 64 << c slots, 5: the generic LDS kernel);
+// the 8- and 16-round variants count tokens per slot in 16 bits, so an entity with a view beyond 65535 tokens is generic too
+__host__ __device__ __forceinline__ int mvhdp_class_of(int n, bool view_beyond_16_bits)
+{
+    int c = (n <= 64) ? 0 : (n <= 128) ? 1 : (n <= 256) ? 2 : (n <= 512) ? 3 : (n <= 1024) ? 4 : 5;
+    if (c >= 3 && view_beyond_16_bits) c = 5;
+    return c;
+}
 
 // FTree.sample (FT:111-136) through the descent table (MvModel::dtab), one lane per token: the same reads, comparisons and
 // subtractions as the literal descent over FTree.tree, three levels per 64-byte block (see the chunk head of the

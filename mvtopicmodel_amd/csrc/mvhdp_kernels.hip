@@ -69,8 +69,13 @@ hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens,
 // apply_first: the multi-GPU pipeline's form (mvhdp_apply_delta_rows): the row's all-reduced deltas are added to the
 // counts (UPD:197-207) on the way in -- counts += delta, delta = 0 -- and the tree is built from the updated row; the
 // tokensPerTopic part has been applied before (mvhdp_apply_delta_begin), every tree needs all of it.
+// The 16-bit mirror of the row (MvModel::counts16) is written here too, and with it the row's weight class (MvModel::heavy): a row
+// whose type holds more than 65534 tokens in all is HEAVY -- every mirror cell 65535 = "look in the 32-bit table" --, any other row is
+// LIGHT and its mirror cells are its counts (none can ever reach 65535, however the tokens move between topics).
+// from_mirror (a segment border of a live16 sweep, where the light rows' atomics went to the mirror): light rows are READ from the
+// mirror and written through to the 32-bit table; the flags and the mirror stay as they are.
 __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
-                                                         bool apply_first, unsigned long long* negatives)
+                                                         bool apply_first, unsigned long long* negatives, bool from_mirror)
 {
     extern __shared__ double t[];                  // 2K doubles
     const int K = mm.K, lane = threadIdx.x;
@@ -85,14 +90,32 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         const int32_t* nk = nk_all + (int64_t)m * K;
         const double* al = mm.alpha + (int64_t)m * (K + 1);
         const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
-        uint16_t* c16 = mm.counts16 ? mm.counts16 + row * K : nullptr;
-        for (int k = lane; k < K; k += WAVE) {
-            int c = cnt[k];
-            if (apply_first) {
-                const int d = dl[k];
-                if (d) { c += d; cnt[k] = c; dl[k] = 0; neg += c < 0; }    // UPD:202-215 logs a negative count; here it is reported
+        uint16_t* c16 = mm.counts16 + row * K;
+        const bool light_src = from_mirror && !mm.heavy[row];
+        bool hv = false;
+        // first pass over the row: the updater's catch-up (apply_first), the row's weight class, the mirror
+        if (!from_mirror) {
+            long long sum = 0;
+            for (int k = lane; k < K; k += WAVE) {
+                int c = cnt[k];
+                if (apply_first) {
+                    const int d = dl[k];
+                    if (d) { c += d; cnt[k] = c; dl[k] = 0; neg += c < 0; }    // UPD:202-215 logs a negative count; here it is reported
+                }
+                sum += c < 0 ? 70000 : c;                                  // (a negative count is an error reported elsewhere: keep the row out of the mirror)
             }
-            if (c16) c16[k] = (uint16_t)(c < 0 ? 0 : c > 65535 ? 65535 : c);   // the 16-bit mirror: 65535 = "look in the 32-bit table"
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, WAVE);
+            hv = sum > 65534;
+            if (lane == 0) mm.heavy[row] = hv ? 1 : 0;
+        }
+        for (int k = lane; k < K; k += WAVE) {
+            int c;
+            if (light_src) { c = (int)c16[k]; cnt[k] = c; }                // the mirror is the authority for this row: write it through
+            else {
+                c = cnt[k];
+                if (!from_mirror) c16[k] = hv ? (uint16_t)65535 : (uint16_t)c;
+            }
             double leaf;
             if (inference_leaves) {                                // INF:576: p_wt alone
                 leaf = ((double)c + beta) / ((double)nk[k] + beta_sum);
@@ -157,7 +180,41 @@ hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leave
     if (nrows <= 0) return hipSuccess;
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
-                       row_begin, row_end, apply_first, negatives);
+                       row_begin, row_end, apply_first, negatives, false);
+    return hipGetLastError();
+}
+
+hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s)
+{
+    const int64_t nrows = mm.rowbase[mm.M];
+    if (nrows <= 0) return hipSuccess;
+    int grid = (int)(nrows < 65536 ? nrows : 65536);
+    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, write_full,
+                       (int64_t)0, nrows, false, (unsigned long long*)nullptr, true);
+    return hipGetLastError();
+}
+
+// counts <- mirror for the light rows (the end of a live16 sweep: the 32-bit table is the model again)
+__global__ __launch_bounds__(256) void widen_mirror_kernel(MvModel mm)
+{
+    const int K = mm.K;
+    const int64_t nrows = mm.rowbase[mm.M];
+    const int lane = threadIdx.x & 63;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nrows; row += wstride) {
+        if (mm.heavy[row]) continue;
+        const uint16_t* c16 = mm.counts16 + row * K;
+        int32_t* cnt = mm.counts + row * K;
+        for (int k = lane; k < K; k += WAVE) cnt[k] = (int)c16[k];
+    }
+}
+
+hipError_t mvhdp_launch_widen_mirror(const MvModel& mm, hipStream_t s)
+{
+    const int64_t nrows = mm.rowbase[mm.M];
+    if (nrows <= 0) return hipSuccess;
+    int64_t blocks = (nrows + 3) / 4;
+    hipLaunchKernelGGL(widen_mirror_kernel, dim3((unsigned int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, mm);
     return hipGetLastError();
 }
 
@@ -285,7 +342,7 @@ hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t s
 // ---------------------------------------------------------------------------
 size_t mvhdp_sweep_wave_bytes(int M, int S_cap)
 {
-    size_t b = 64 * 4 /*bitmap*/ + 64 * 4 /*prefix*/ + 16 * 4 /*wlen + pad*/;
+    size_t b = 64 * 4 /*bitmap*/ + 64 * 4 /*prefix*/ + 64 * 4 /*bitmap of the new assignments*/ + 16 * 4 /*wlen + pad*/;
     b += (size_t)S_cap * 4;             // sk
     b += (size_t)M * S_cap * 4;         // sn
     b = (b + 7) & ~(size_t)7;
@@ -308,17 +365,19 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     const int nkd_len = sl.nk_global ? 0 : M * K;
     int* nkd = (int*)smem;
     unsigned int* hist_s = (unsigned int*)(nkd + nkd_len);
-    for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS; i += blockDim.x) nkd[i] = 0;
+    unsigned int* ent_s = hist_s + MVHDP_HIST_BINS;         // [MVHDP_ENT_BINS] entities by the kernel class of their NEW topic list
+    for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS + MVHDP_ENT_BINS; i += blockDim.x) nkd[i] = 0;
     int32_t* const dnk_g = mm.delta + mm.rowbase[M] * K;    // n_k part of the delta buffer
     __syncthreads();
 
     unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
     uint32_t* bitmap = (uint32_t*)wb;
     uint32_t* prefix = bitmap + 64;
-    int* wlen = (int*)(prefix + 64);                        // [8] + pad
+    uint32_t* bitmap2 = prefix + 64;                        // topics of the entity's NEW assignments (MvModel::nslots)
+    int* wlen = (int*)(bitmap2 + 64);                       // [8] + pad
     int* sk = wlen + 16;
     int* sn = sk + S;
-    size_t off = (size_t)(64 + 64 + 16 + S + M * S) * 4;
+    size_t off = (size_t)(64 + 64 + 64 + 16 + S + M * S) * 4;
     off = (off + 7) & ~(size_t)7;
     double* soth = (double*)(wb + off);
     double* sden = soth + S;
@@ -334,12 +393,17 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
     const long long q_n1 = sl.q_list_count ? (long long)*sl.q_list_count : 0;
     const long long q_total = q_n1 + sl.q_order_count;
+    // (the last pulls of the queue take one entity at a time: the launch ends within one entity's time of its last pull)
+    const long long q_single = q_total - 2LL * gridDim.x * (blockDim.x >> 6);
+    long long q_seen = 0;
     for (;;) {
+      const long long batch = (q_seen >= q_single) ? 1 : MVHDP_DOC_BATCH;
       long long q0 = 0;
-      if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)MVHDP_DOC_BATCH);
+      if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)batch);
       q0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)q0);
       if (q0 >= q_total) break;
-      const long long q1 = (q0 + MVHDP_DOC_BATCH < q_total) ? q0 + MVHDP_DOC_BATCH : q_total;
+      q_seen = q0;
+      const long long q1 = (q0 + batch < q_total) ? q0 + batch : q_total;
       for (long long q = q0; q < q1; q++) {
         int64_t d;
         if (q < q_n1) d = (int64_t)sl.q_list[q];
@@ -347,12 +411,14 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
         const int64_t dg = mm.doc_id_base + d;
 
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
-        if (lane < 64) { bitmap[lane] = 0; }
+        bitmap[lane] = 0;
+        bitmap2[lane] = 0;
         LDS_FENCE();
-        int doc_tokens = 0;
+        int doc_tokens = 0, longest_view = 0;
         for (int m = 0; m < M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
             doc_tokens += (int)(e - b);
+            longest_view = max(longest_view, (int)(e - b));
             if (lane == 0) wlen[m] = (int)(e - b);
             for (int64_t i = b + lane; i < e; i += WAVE) {
                 int zz = mm.z[m][i];
@@ -368,7 +434,6 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
             prefix[lane] = (uint32_t)(incl - cnt);
             S_used = bcast_i(incl, 63);
         }
-        if (sl.slot_hist && lane == 0 && S_used > 0) atomicAdd(&hist_s[min((S_used + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);
         LDS_FENCE();
         for (int k0 = 0; k0 < K; k0 += WAVE) {
             int k = k0 + lane;
@@ -626,9 +691,23 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                     }
                 }
                 if (tvalid) mm.z[m][base + ti] = znew_l;                     // coalesced write-back of the chunk
+                if (tvalid && znew_l >= 0) atomicOr(&bitmap2[znew_l >> 5], 1u << (znew_l & 31));
             }
         }
         if (aborted) n_abort++;
+        LDS_FENCE();
+        {   // the entity's topic list at its NEXT visit: distinct topics of the assignments just written
+            int c2 = __popc(lane < NW ? bitmap2[lane] : 0u);
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) c2 += __shfl_xor(c2, sft, WAVE);
+            if (lane == 0) {
+                mm.nslots[d] = aborted ? (uint16_t)MVHDP_NSLOTS_UNKNOWN : (uint16_t)c2;
+                if (sl.slot_hist) {
+                    if (c2 > 0) atomicAdd(&hist_s[min((c2 + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);
+                    atomicAdd(&ent_s[aborted ? MVHDP_N_CLASSES : mvhdp_class_of(c2, longest_view > 65535)], 1u);
+                }
+            }
+        }
         LDS_FENCE();
       }
     }
@@ -636,7 +715,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
     __syncthreads();
     for (int i = threadIdx.x; i < nkd_len; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk_g[i], nkd[i]);
-    if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
+    if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS + MVHDP_ENT_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
     if (lane == 0) {
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
@@ -673,6 +752,14 @@ int mvhdp_sweep_generic_occupancy(bool debug, int block_threads, size_t lds_byte
     return b < 1 ? 1 : b;
 }
 
+int mvhdp_sweep_generic_regs(bool debug)
+{
+    hipFuncAttributes a;
+    const void* f = debug ? (const void*)sweep_kernel<true> : (const void*)sweep_kernel<false>;
+    if (hipFuncGetAttributes(&a, f) != hipSuccess) return 128;
+    return a.numRegs;
+}
+
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s)
 {
     size_t lds = sl.block_shared_bytes + (size_t)sl.waves_per_block * sl.wave_bytes;
@@ -700,6 +787,25 @@ __global__ __launch_bounds__(256) void apply_delta_kernel(int32_t* counts, int32
         }
     }
     if (neg) atomicAdd(&stats[ST_NEGATIVE], (unsigned long long)neg);
+}
+
+// One launch instead of a handful of fills: the counters a sweep (n_stats words), or a segment of one, starts from.
+__global__ __launch_bounds__(256) void ctl_reset_kernel(unsigned long long* stats, int n_stats, long long* act_key, unsigned long long* meta, int n_meta,
+                                                        unsigned int* class_counts, unsigned long long* qheads)
+{
+    const int t = threadIdx.x;
+    if (stats) for (int i = t; i < n_stats; i += blockDim.x) stats[i] = 0ull;
+    if (meta) for (int i = t; i < n_meta; i += blockDim.x) meta[i] = 0ull;
+    if (class_counts && t < MVHDP_N_CLASSES) class_counts[t] = 0u;
+    if (qheads && t < 8) qheads[t] = 0ull;
+    if (act_key && t == 0) *act_key = 0x7fffffffffffffffLL;      // MVHDP_ACT_KEY_NONE
+}
+
+hipError_t mvhdp_launch_ctl_reset(unsigned long long* stats, int n_stats, long long* act_key, unsigned long long* meta, int n_meta,
+                                  unsigned int* class_counts, unsigned long long* qheads, hipStream_t s)
+{
+    hipLaunchKernelGGL(ctl_reset_kernel, dim3(1), dim3(256), 0, s, stats, n_stats, act_key, meta, n_meta, class_counts, qheads);
+    return hipGetLastError();
 }
 
 hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s)
@@ -863,17 +969,18 @@ __global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned lon
 {
     __shared__ uint32_t bm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ unsigned int hs[MVHDP_HIST_BINS];
-    if (threadIdx.x < MVHDP_HIST_BINS) hs[threadIdx.x] = 0;
+    __shared__ unsigned int hs[MVHDP_HIST_BINS + MVHDP_ENT_BINS];
+    if (threadIdx.x < MVHDP_HIST_BINS + MVHDP_ENT_BINS) hs[threadIdx.x] = 0;
     __syncthreads();
     const int64_t wstride = (int64_t)gridDim.x * 4;
     for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < mm.D; d += wstride) {
         bm[wave][lane] = 0;
         LDS_FENCE();
-        int doc_tokens = 0;
+        int doc_tokens = 0, longest_view = 0;
         for (int m = 0; m < mm.M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
             doc_tokens += (int)(e - b);
+            longest_view = max(longest_view, (int)(e - b));
             for (int64_t i = b + lane; i < e; i += WAVE) {
                 int zz = mm.z[m][i];
                 if (zz >= 0) atomicOr(&bm[wave][zz >> 5], 1u << (zz & 31));
@@ -883,11 +990,15 @@ __global__ __launch_bounds__(256) void slot_hist_kernel(MvModel mm, unsigned lon
         int cnt = __popc(bm[wave][lane]);
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, WAVE);
-        if (lane == 0 && cnt > 0) atomicAdd(&hs[min((cnt + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);   // weighted by tokens
+        if (lane == 0) {
+            mm.nslots[d] = (uint16_t)cnt;
+            if (cnt > 0) atomicAdd(&hs[min((cnt + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);   // weighted by tokens
+            atomicAdd(&hs[MVHDP_HIST_BINS + mvhdp_class_of(cnt, longest_view > 65535)], 1u);
+        }
         LDS_FENCE();
     }
     __syncthreads();
-    if (threadIdx.x < MVHDP_HIST_BINS && hs[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)hs[threadIdx.x]);
+    if (threadIdx.x < MVHDP_HIST_BINS + MVHDP_ENT_BINS && hs[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)hs[threadIdx.x]);
 }
 
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s)
@@ -900,70 +1011,45 @@ hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, h
 }
 
 // ---------------------------------------------------------------------------
-// classify: before a sweep, the entities that MAY hold more topics than the primary kernel variant
-// has slots (those with more tokens than slots: a static prefix of the longest-first order) are
-// measured -- the same bitmap count the sweep kernels start every entity with -- and listed for the
-// narrowest kernel that holds them.  The sweep kernels of all classes then run side by side, the
-// widest (longest entities) first, instead of one after another.
+// route: before a sweep (or a segment of one), the entities that MAY hold more topics than the primary kernel
+// variant has slots (those with more tokens than slots: a static prefix of the longest-first order) are listed for
+// the narrowest kernel variant that holds their topic list.  The list sizes are known: every sweep kernel leaves
+// MvModel::nslots behind for the entities it visited, so this is one 2-byte read per entity, no pass over z.
+// The sweep kernels of all classes then run side by side, the widest (longest entities) first.
+// One thread per entity; a wave appends its entities of a class with ONE atomic (ballot + rank), so the lists keep
+// the longest-first order up to the interleaving of waves.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void classify_kernel(MvModel mm, ClassifyArgs ca)
+__global__ __launch_bounds__(256) void route_kernel(MvModel mm, ClassifyArgs ca)
 {
-    __shared__ uint32_t bm[4][64];
-    // per wave and class: up to 64 entity ids staged in LDS and appended to the class list with ONE atomic per
-    // 64 entities (a global counter bumped once per entity serialises the whole pass: 10 ms for 0.9 M entities)
-    __shared__ int32_t stage[4][MVHDP_N_CLASSES][64];
-    __shared__ int n_staged[4][MVHDP_N_CLASSES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < MVHDP_N_CLASSES) n_staged[wave][lane] = 0;
-    LDS_FENCE();
-    auto flush = [&](int c) {
-        const int n = n_staged[wave][c];
-        if (n == 0) return;
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&ca.counts[c], (unsigned int)n);
-        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-        if (lane < n) ca.lists[c][base + lane] = stage[wave][c][lane];
-        LDS_FENCE();
-        if (lane == 0) n_staged[wave][c] = 0;
-        LDS_FENCE();
-    };
-    const int64_t wstride = (int64_t)gridDim.x * 4;
-    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < ca.n; q += wstride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = -1;
+    int64_t d = 0;
+    if (q < ca.n) {
         const int64_t oq = ca.start + q * ca.stride;
-        const int64_t d = ca.order ? (int64_t)ca.order[oq] : oq;
-        bm[wave][lane] = 0;
-        LDS_FENCE();
-        int64_t longest = 0;
-        for (int m = 0; m < mm.M; m++) {
-            const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
-            longest = (e - b > longest) ? e - b : longest;
-            for (int64_t i = b + lane; i < e; i += WAVE) {
-                int zz = mm.z[m][i];
-                if (zz >= 0) atomicOr(&bm[wave][zz >> 5], 1u << (zz & 31));
-            }
-        }
-        LDS_FENCE();
-        int cnt = __popc(bm[wave][lane]);
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, WAVE);
-        int c = (cnt <= 64) ? 0 : (cnt <= 128) ? 1 : (cnt <= 256) ? 2 : (cnt <= 512) ? 3 : (cnt <= 1024) ? 4 : 5;
-        if (c < ca.primary) c = ca.primary;
-        if (c >= 3 && longest > 65535) c = 5;                // the 8- and 16-round variants count tokens per slot in 16 bits
-        c = __builtin_amdgcn_readfirstlane(c);
-        const int n = n_staged[wave][c];
-        if (lane == 0) { stage[wave][c][n] = (int32_t)d; n_staged[wave][c] = n + 1; }
-        LDS_FENCE();
-        if (n + 1 == 64) flush(c);
+        d = ca.order ? (int64_t)ca.order[oq] : oq;
+        const unsigned int ns = mm.nslots[d];
+        bool beyond = false;
+        if (ca.check_views)
+            for (int m = 0; m < mm.M; m++) beyond = beyond || (mm.doc_off[m][d + 1] - mm.doc_off[m][d] > 65535);
+        c = (ns == MVHDP_NSLOTS_UNKNOWN) ? -1 : ca.class_map[mvhdp_class_of((int)ns, beyond)];
+        if (c < 0) atomicAdd(ca.misrouted, 1ull);              // size not known (the host recounts first) or no kernel for it: the host fails the sweep
     }
-    for (int c = 0; c < MVHDP_N_CLASSES; c++) flush(c);
+    for (int k = 0; k < MVHDP_N_CLASSES; k++) {
+        const unsigned long long mine = __ballot(c == k);
+        if (!mine) continue;
+        unsigned int base = 0;
+        if (lane == (int)__builtin_ctzll(mine)) base = atomicAdd(&ca.counts[k], (unsigned int)__popcll(mine));
+        base = (unsigned int)__shfl((int)base, (int)__builtin_ctzll(mine), WAVE);
+        if (c == k) ca.lists[k][base + __popcll(mine & ((1ull << lane) - 1ull))] = (int32_t)d;
+    }
 }
 
 hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipStream_t s)
 {
     if (ca.n <= 0) return hipSuccess;
-    int64_t blocks = (ca.n + 3) / 4;
-    int grid = (int)(blocks < 8192 ? blocks : 8192);
-    hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, mm, ca);
+    const int64_t blocks = (ca.n + 255) / 256;
+    hipLaunchKernelGGL(route_kernel, dim3((unsigned int)blocks), dim3(256), 0, s, mm, ca);
     return hipGetLastError();
 }
 

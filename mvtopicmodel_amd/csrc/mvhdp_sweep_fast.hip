@@ -30,7 +30,7 @@
 size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 {
     size_t counts = (size_t)M * S_cap * (rmax >= 8 ? 2 : 4);
-    size_t b = (size_t)(64 + 64 + 16 + S_cap) * 4 + counts;
+    size_t b = (size_t)(64 + 64 + 64 + 16 + S_cap) * 4 + counts;      // bitmap, prefix, bitmap of the new assignments, wlen, sk
     return (b + 15) & ~(size_t)15;
 }
 
@@ -54,11 +54,14 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 // WALK: the flavour with the thresholded tree walk of the chunk head (SweepLaunch::walk_theta), the walk on demand in the token
 // loop and the per-view branch statistics the threshold search feeds on.  Without it every token is walked up front and nothing
 // is counted: where the best threshold is 0 (C2, C3) that code is 2-5 % faster for not carrying the rest.
-// NARROW (1-round walk flavour only): the n_wk gather reads the 16-bit mirror of the counts (MvModel::counts16, written with the
-// trees at the start of the sweep) -- half the lines of the row; a saturated value (65535) sends the lane to the 32-bit table,
-// checked when the value is used, not when the gather is issued (the prefetch for the next token stays asynchronous).
-// Same numbers, so same results; not for MVHDP_SWEEP_LIVE (the mirror is a snapshot).  The 2-round variant is 4 % slower
-// with it (two 2-byte loads per lane cost it more than the lines are worth): 32-bit gathers there.
+// NARROW (walk flavour only): the n_wk gather reads the 16-bit mirror of the counts (MvModel::counts16, written with the trees at
+// the start of the sweep) -- half the lines of the row; a saturated value (65535 = a heavy row, MvModel::heavy) sends the lane to
+// the 32-bit table, checked when the value is used, not when the gather is issued (the prefetch for the next token stays
+// asynchronous).  Same numbers, so same results.  A deferred sweep uses it for the 1-round variant only (the 2-round variant is 4 %
+// slower with it: two 2-byte loads per lane cost it more than the lines are worth).  A live sweep (SweepLaunch::live16) uses it for
+// every variant: there the chunk-end atomics of the light rows land IN the mirror -- two 16-bit cells per 32-bit word, +-1 or +-65536,
+// which cannot carry: a light row's cell stays below 65535 and a decrement only ever takes back a token that was counted -- so the
+// mirror is what every later token of the sweep reads (UPD:197-207 applied while the workers sample), at half the gather traffic.
 template <int RMAX, bool DEBUG, bool WALK, bool NARROW>
 __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : 1))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
@@ -77,15 +80,17 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     const int nkd_len = sl.nk_global ? 0 : M * K;
     int* nkd = (int*)smem;
     unsigned int* hist_s = (unsigned int*)(nkd + nkd_len);
-    unsigned int* vstat_s = hist_s + MVHDP_HIST_BINS;     // [MVHDP_MAXM][MVHDP_VIEW_STATS] per-view branch statistics of this block
-    for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS + (WALK ? MVHDP_MAXM * MVHDP_VIEW_STATS : 0); i += blockDim.x) nkd[i] = 0;
+    unsigned int* ent_s = hist_s + MVHDP_HIST_BINS;       // [MVHDP_ENT_BINS] entities by the kernel class of their NEW topic list
+    unsigned int* vstat_s = ent_s + MVHDP_ENT_BINS;       // [MVHDP_MAXM][MVHDP_VIEW_STATS] per-view branch statistics of this block
+    for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS + MVHDP_ENT_BINS + (WALK ? MVHDP_MAXM * MVHDP_VIEW_STATS : 0); i += blockDim.x) nkd[i] = 0;
     int32_t* const dnk_g = mm.delta + mm.rowbase[M] * K;    // n_k part of the delta buffer
     __syncthreads();
 
     unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
     uint32_t* bitmap = (uint32_t*)wb;
     uint32_t* prefix = bitmap + 64;
-    int* wlen = (int*)(prefix + 64);
+    uint32_t* bitmap2 = prefix + 64;                       // topics of the entity's NEW assignments (MvModel::nslots)
+    int* wlen = (int*)(bitmap2 + 64);
     int* sk = wlen + 16;
     constexpr bool PACK = RMAX >= 8;                       // per-view slot counts as 16-bit values
     int* sn = sk + S;
@@ -113,12 +118,17 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #else
 #define MVHDP_TSEG(acc) do { } while (0)
 #endif
+    // (the last pulls of the queue take one entity at a time: the launch ends within one entity's time of its last pull)
+    const long long q_single = q_total - 2LL * gridDim.x * (blockDim.x >> 6);
+    long long q_seen = 0;
     for (;;) {
+      const long long batch = (q_seen >= q_single) ? 1 : MVHDP_DOC_BATCH;
       long long q0 = 0;
-      if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)MVHDP_DOC_BATCH);
+      if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)batch);
       q0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)q0);
       if (q0 >= q_total) break;
-      const long long q1 = (q0 + MVHDP_DOC_BATCH < q_total) ? q0 + MVHDP_DOC_BATCH : q_total;
+      q_seen = q0;
+      const long long q1 = (q0 + batch < q_total) ? q0 + batch : q_total;
       for (long long q = q0; q < q1; q++) {
         int64_t d;
         if (q < q_n1) d = (int64_t)sl.q_list[q];
@@ -128,11 +138,13 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         MVHDP_TSEG(tq);
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
         bitmap[lane] = 0;
+        bitmap2[lane] = 0;
         LDS_FENCE();
-        int doc_tokens = 0;
+        int doc_tokens = 0, longest_view = 0;
         for (int m = 0; m < M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
             doc_tokens += (int)(e - b);
+            longest_view = max(longest_view, (int)(e - b));
             if (lane == 0) wlen[m] = (int)(e - b);
             for (int64_t i = b + lane; i < e; i += WAVE) {
                 int zz = mm.z[m][i];
@@ -149,16 +161,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             S_used = bcast_i(incl, 63);
         }
         LDS_FENCE();
-        if (sl.slot_hist && lane == 0 && S_used > 0) atomicAdd(&hist_s[min((S_used + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);
         // slots per lane: 1, 2 or 4 consecutive slots (slot i = lane*R_eff + r)
         const int lg = (S_used <= 64) ? 0 : (S_used <= 128) ? 1 : (S_used <= 256) ? 2 : (S_used <= 512) ? 3 : 4;
         const int R_eff = 1 << lg;
-        bool too_long = false;
-        if (PACK) for (int m = 0; m < M; m++) too_long |= wlen[m] > 65535;
-        if (S_used > 1024 || R_eff > RMAX || too_long) {                    // too many topics (or tokens) for this variant
-            if (sl.overflow_list) {                                         // optimistic mode: a wider kernel re-runs it
-                if (lane == 0) sl.overflow_list[atomicAdd(sl.overflow_count, 1u)] = (int32_t)d;
-            } else n_misclass++;                                            // classified mode: cannot happen; the host fails the sweep
+        if (S_used > 1024 || R_eff > RMAX || (PACK && longest_view > 65535)) {   // too many topics (or tokens) for this variant:
+            n_misclass++;                                                        // route_kernel sent it here by mistake; the host fails the sweep
             continue;
         }
         for (int k0 = 0; k0 < K; k0 += WAVE) {
@@ -252,6 +259,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 const bool tvalid = ti < lenm;
                 int w_l = tvalid ? mm.tok[m][base + ti] : -1;
                 int z_l = tvalid ? mm.z[m][base + ti] : -1;
+                // live16: does this token's row keep its counts in the mirror (light) or in the 32-bit table (heavy)?  (loaded here, used at the chunk's end)
+                bool light_l = false;
+                if (NARROW && sl.live16 && w_l >= 0 && w_l < Vm) light_l = mm.heavy[row0 + w_l] == 0;
                 int so_l = -1;
                 if (z_l >= 0) {
                     uint32_t w = bitmap[z_l >> 5];
@@ -366,12 +376,19 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     n_chg += (unsigned int)__popcll(__ballot(chg));
                     if (chg) {
                         const int64_t rowK = (row0 + w_l) * K;
+                        if (NARROW && light_l) {
+                            // a light row of a live16 sweep: its counts live in the mirror, two cells per word
+                            unsigned int* m32 = (unsigned int*)mm.counts16;
+                            if (z_l >= 0) { const int64_t c = rowK + z_l; __hip_atomic_fetch_add(&m32[c >> 1], 0u - (1u << ((c & 1) * 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            { const int64_t c = rowK + znew_l; __hip_atomic_fetch_add(&m32[c >> 1], 1u << ((c & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        } else {
+                            if (z_l >= 0) __hip_atomic_fetch_add(&dnwk[rowK + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(&dnwk[rowK + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         if (z_l >= 0) {
-                            __hip_atomic_fetch_add(&dnwk[rowK + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (sl.nk_global) __hip_atomic_fetch_add(&dnk_g[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             else __hip_atomic_fetch_add(&nkd[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        __hip_atomic_fetch_add(&dnwk[rowK + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (sl.nk_global) __hip_atomic_fetch_add(&dnk_g[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         else __hip_atomic_fetch_add(&nkd[m * K + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (mm.first_inactive >= 0 && mm.inactive[znew_l]) {          // UPD:263
@@ -381,6 +398,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
                 if (tvalid) mm.z[m][base + ti] = znew_l;                     // coalesced write-back of the chunk
+                if (tvalid && znew_l >= 0) atomicOr(&bitmap2[znew_l >> 5], 1u << (znew_l & 31));
                 MVHDP_TSEG(te);
             }
 
@@ -399,13 +417,26 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         }
         if (aborted) n_abort++;
         LDS_FENCE();
+        {   // the entity's topic list at its NEXT visit: distinct topics of the assignments just written
+            int c2 = __popc(lane < NW ? bitmap2[lane] : 0u);
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) c2 += __shfl_xor(c2, sft, WAVE);
+            if (lane == 0) {
+                mm.nslots[d] = aborted ? (uint16_t)MVHDP_NSLOTS_UNKNOWN : (uint16_t)c2;   // (an abandoned entity keeps assignments this wave never saw)
+                if (sl.slot_hist) {
+                    if (c2 > 0) atomicAdd(&hist_s[min((c2 + 63) >> 6, MVHDP_HIST_BINS) - 1], (unsigned int)doc_tokens);
+                    atomicAdd(&ent_s[aborted ? MVHDP_N_CLASSES : mvhdp_class_of(c2, longest_view > 65535)], 1u);
+                }
+            }
+        }
+        LDS_FENCE();
       }
     }
 
     __syncthreads();
     for (int i = threadIdx.x; i < nkd_len; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk_g[i], nkd[i]);
-    if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
+    if (sl.slot_hist && threadIdx.x < MVHDP_HIST_BINS + MVHDP_ENT_BINS && hist_s[threadIdx.x]) atomicAdd(&sl.slot_hist[threadIdx.x], (unsigned long long)hist_s[threadIdx.x]);
     if (WALK && threadIdx.x < MVHDP_MAXM * MVHDP_VIEW_STATS && vstat_s[threadIdx.x])
         atomicAdd(&sl.stats[ST_VIEW_BASE + threadIdx.x], (unsigned long long)vstat_s[threadIdx.x]);
     if (lane == 0) {
@@ -430,12 +461,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #undef sn_get
 #undef sn_set
 
-// debug launches always take the WALK flavour (one instantiation fewer per variant; a threshold of 0 walks every token);
-// the NARROW flavour exists for the 1-round walk kernel only
+// debug launches always take the WALK flavour (one instantiation fewer per variant; a threshold of 0 walks every token)
 template <int RMAX>
 static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow)
 {
-    if (RMAX == 1 && narrow && walk && !debug) return (const void*)sweep_fast_kernel<1, false, true, true>;
+    if (narrow && walk && !debug) return (const void*)sweep_fast_kernel<RMAX, false, true, true>;
     return debug ? (const void*)sweep_fast_kernel<RMAX, true, true, false>
                  : walk ? (const void*)sweep_fast_kernel<RMAX, false, true, false> : (const void*)sweep_fast_kernel<RMAX, false, false, false>;
 }
@@ -445,13 +475,13 @@ static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid
 {
     size_t lds = sl.block_shared_bytes + (size_t)sl.waves_per_block * sl.wave_bytes;
     dim3 block(64 * sl.waves_per_block);
-    const bool narrow = RMAX == 1 && sl.narrow && sl.walk && !debug;
+    const bool narrow = sl.narrow && sl.walk && !debug;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0, narrow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
-    else if (narrow)  hipLaunchKernelGGL((sweep_fast_kernel<1, false, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else if (narrow)  hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
     else if (sl.walk) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
     else              hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, false, false>), dim3(grid_blocks), block, lds, s, mm, sl);
     return hipGetLastError();
@@ -506,5 +536,25 @@ int mvhdp_sweep_fast_occupancy(int rmax, bool debug, bool walk, int block_thread
     case 8: return occ_fast<8>(debug, walk, block_threads, lds_bytes);
     case 16: return occ_fast<16>(debug, walk, block_threads, lds_bytes);
     default: return 0;
+    }
+}
+
+template <int RMAX>
+static int regs_fast(int flavour)
+{
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, fast_kernel_ptr<RMAX>(flavour == 2, flavour >= 1, false)) != hipSuccess) return 128;
+    return a.numRegs;
+}
+
+int mvhdp_sweep_kernel_regs(int cls, int flavour)
+{
+    switch (cls) {
+    case 0: return regs_fast<1>(flavour);
+    case 1: return regs_fast<2>(flavour);
+    case 2: return regs_fast<4>(flavour);
+    case 3: return regs_fast<8>(flavour);
+    case 4: return regs_fast<16>(flavour);
+    default: return mvhdp_sweep_generic_regs(flavour == 2);
     }
 }

@@ -11,7 +11,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from ._lib import (MAX_M, Config, DebugC, HyperC, MvhdpError, SweepStatsC, load_library)
+from ._lib import (MAX_M, Config, DebugC, HyperC, MvhdpError, SweepStatsC, TuningC, load_library)
 
 SWEEP_REUSE_TREES = 0x1
 SWEEP_NO_APPLY = 0x2
@@ -287,6 +287,34 @@ class NativeSampler:
             out.dbg = [a[: self.N[m]] for m, a in enumerate(dbg_arrays)]
         out.trace = tout
         return out
+
+    def sweep_many(self, first_idx, n, seed, flags=0):
+        """n sweeps enqueued back to back, one synchronisation (mvhdp_sweep_many): the list of their statistics."""
+        arr = (SweepStatsC * max(int(n), 1))()
+        self._ck(self.L.mvhdp_sweep_many(self.h, int(first_idx), int(n), int(seed), int(flags), C.cast(arr, C.c_void_p)))
+        return [SweepStats(**{f: getattr(arr[i], f) for f, _ in SweepStatsC._fields_}) for i in range(int(n))]
+
+    # -- tuning (never changes a result) --------------------------------------------
+    def get_tuning(self):
+        t = TuningC()
+        self._ck(self.L.mvhdp_get_tuning(self.h, C.byref(t)))
+        return t
+
+    def set_tuning(self, t=None, **kw):
+        """set_tuning(force_primary=2, walk_theta=[0.5, 0], narrow=0, ...): fields not named keep their value."""
+        if t is None:
+            t = self.get_tuning()
+        for k, v in kw.items():
+            if k in ("walk_theta", "tree_branch_share", "learnt_walk_step"):
+                arr = getattr(t, k)
+                for i, x in enumerate(v):
+                    arr[i] = x
+                if k == "walk_theta":
+                    for i in range(len(v), MAX_M):
+                        arr[i] = 0.0
+            else:
+                setattr(t, k, v)
+        self._ck(self.L.mvhdp_set_tuning(self.h, C.byref(t)))
 
     def apply_delta(self, activated_topic=-1, activated_modality=-1):
         self._ck(self.L.mvhdp_apply_delta(self.h, int(activated_topic), int(activated_modality)))

@@ -43,7 +43,7 @@ def _case(seed):
     flags = int(rng.choice([0, 0, 0, SWEEP_EXACT_CHAIN, SWEEP_GENERIC_KERNEL]))
     # the segmented launch path (interleaved queue segments) under the deferred contract: same integers for any count
     flags |= SWEEP_LIVE_SEGMENTS(int(rng.choice([0, 0, 1, 2, 3, 7, 40])))
-    env = {"MVHDP_FORCE_MODE": str(rng.choice(["", "optimistic", "classified"])),
+    env = {"MVHDP_FORCE_MODE": str(rng.choice(["", "serial", "streams"])),
            "MVHDP_FORCE_RMAX": str(rng.choice(["", "", "1", "2", "4", "8", "16"]))}
     # the walk threshold of the chunk head (when a token's word tree is walked, never what it returns): left to the library's
     # search, or pinned -- 0 = every token up front, > 1 = every tree-branch token on demand, or a random one per view
@@ -151,6 +151,7 @@ def test_random_shapes_live(seed, monkeypatch):
     """MVHDP_SWEEP_LIVE on the same random shapes (variants, dispatch modes, unassigned and out-of-vocabulary tokens,
     inactive topics): whatever the interleaving, the counts are the counts of z and the statistics add up."""
     c, hy, inactive, flags, env, rng = _case(9000 + seed)
+    env["MVHDP_LIVE16"] = str(seed % 2)                   # even: atomics and gathers on the 32-bit table; odd: light rows live in the 16-bit mirror
     for k, v in env.items():
         if v:
             monkeypatch.setenv(k, v)

@@ -33,9 +33,13 @@ def _check_counts_are_counts_of_z(c, s, K):
         assert np.array_equal(nk.astype(np.int64), want[m].sum(axis=0)), f"n_k is not the column sum in view {m}"
 
 
+@pytest.mark.parametrize("live16", ["0", "1"])
 @pytest.mark.parametrize("nseg", [0, 1, 3, 7])
 @pytest.mark.parametrize("K,V,D,lam,cseed", [(20, [300, 40, 50], 200, [30, 4, 6], 31), (200, [3000, 300, 300], 300, [127, 7, 15], 32)])
-def test_live_sweep_invariants(K, V, D, lam, cseed, nseg):
+def test_live_sweep_invariants(K, V, D, lam, cseed, nseg, live16, monkeypatch):
+    """live16 = 1: the sweep's atomics of the light n_wk rows land in the 16-bit mirror (two cells per word), which every kernel of the
+    sweep gathers from; 0: atomics and gathers on the 32-bit table."""
+    monkeypatch.setenv("MVHDP_LIVE16", live16)
     c = small_corpus(K, V, D, lam, cseed)
     hy = Hyper.defaults(K, V)
     o = make_oracle(c, hy)
@@ -49,7 +53,7 @@ def test_live_sweep_invariants(K, V, D, lam, cseed, nseg):
     s.close()
 
 
-@pytest.mark.parametrize("force,mode", [("1", "optimistic"), ("2", "classified"), ("8", "optimistic"), ("", "")])
+@pytest.mark.parametrize("force,mode", [("1", "serial"), ("2", "streams"), ("8", "serial"), ("", "")])
 @pytest.mark.parametrize("nseg", [2, 5])
 def test_deferred_sweep_over_segments_is_bit_exact(nseg, force, mode, monkeypatch):
     """The segmented launch path itself (interleaved queue segments, per-segment classify / overflow chain) under the
@@ -92,6 +96,48 @@ def test_live_no_apply_returns_this_shards_delta_and_restores_the_snapshot():
     s.close()
 
 
+@pytest.mark.parametrize("force", ["", "2", "8"])
+def test_live16_with_heavy_and_light_rows(force, monkeypatch):
+    """A type with more tokens than a 16-bit cell can count is a HEAVY row: its mirror cells all read 65535 and its counts stay in the
+    32-bit table (atomics and gathers); the other rows are light and live in the mirror.  Both kinds in one corpus, every register
+    variant reading and updating the mirror, several segments (tree rebuild FROM the mirror), then a deferred sweep on top."""
+    monkeypatch.setenv("MVHDP_LIVE16", "1")
+    if force:
+        monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
+    from mvtopicmodel_amd.synth import Corpus
+    K, V, D = 24, [40, 7], 2500
+    rng = np.random.RandomState(11)
+    lens0 = np.full(D, 200, dtype=np.int64); lens1 = rng.randint(0, 5, D).astype(np.int64)
+    off = [np.concatenate([[0], np.cumsum(l)]) for l in (lens0, lens1)]
+    t0 = rng.randint(1, 40, off[0][-1]).astype(np.int32)
+    t0[rng.rand(len(t0)) < 0.5] = 0                                   # type 0: 250 k tokens, far beyond 65534
+    c = Corpus(K, V, off, [t0, rng.randint(0, 7, off[1][-1]).astype(np.int32)])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    nwk = s.get_counts(0)[0]
+    assert nwk[0].sum() > 65534 and nwk[1:].sum(axis=1).max() < 65534
+    for it in range(3):
+        st = s.sweep(it, 21, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(3))
+        assert st.tokens == c.total_tokens and 0 < st.changed
+        _check_counts_are_counts_of_z(c, s, K)
+    # the deferred sweep that follows is the oracle's again (the 32-bit table was brought up to date when the live sweep ended)
+    for m in range(c.M):
+        o.set_assignments(m, s.get_assignments(m))
+    o.build_counts()
+    o.sweep(3, 21); s.sweep(3, 21)
+    assert_same_state(o, s, c.M)
+    # document shards: this shard's delta = after - before, the snapshot restored
+    before = [s.get_counts(m) for m in range(c.M)]
+    s.sweep(4, 21, flags=SWEEP_LIVE | SWEEP_NO_APPLY | SWEEP_LIVE_SEGMENTS(2))
+    for m in range(c.M):
+        a, b = s.get_counts(m)
+        assert np.array_equal(a, before[m][0]) and np.array_equal(b, before[m][1])
+    s.apply_delta(-1, -1)
+    _check_counts_are_counts_of_z(c, s, K)
+    s.close()
+
+
 def test_live_flag_errors():
     K, V = 10, [50]
     c = small_corpus(K, V, 20, [8], 35)
@@ -118,6 +164,7 @@ def test_live_inactive_topics_are_activated_at_segment_borders():
     for m in range(c.M):
         z[m][np.isin(z[m], [22, 25, 27, 28])] = 2
     s = make_native(c, hy, z)
+    s.set_tuning(live16=1)
     born, most = 0, 0
     for it in range(4):
         ina_before = s.get_alpha()[1].copy()

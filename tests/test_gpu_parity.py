@@ -282,13 +282,13 @@ def test_overflow_entities_are_rerun_by_the_generic_kernel():
     s.close()
 
 
-@pytest.mark.parametrize("mode", ["optimistic", "classified", ""])
+@pytest.mark.parametrize("mode", ["serial", "streams", ""])
 @pytest.mark.parametrize("force", ["", "1", "2", "4", "8", "16"])
 def test_register_variants_overflow_chain_and_classified_side_streams(force, mode, monkeypatch):
     """Topic lists of ~50 ... ~1500 distinct topics in one corpus: whatever primary variant (64*r slots,
     r = 1..16) the sweep starts with, the entities that do not fit reach a wider variant and, beyond
     1024 slots, the generic LDS kernel -- either one pass after another through overflow lists
-    ("optimistic") or measured up front and run side by side on their own streams ("classified");
+    ("serial") or measured up front and run side by side on their own streams ("streams");
     all inside one mvhdp_sweep call, with identical results."""
     if mode:
         monkeypatch.setenv("MVHDP_FORCE_MODE", mode)
@@ -316,7 +316,7 @@ def test_register_variants_overflow_chain_and_classified_side_streams(force, mod
     s.close()
 
 
-@pytest.mark.parametrize("mode", ["optimistic", "classified"])
+@pytest.mark.parametrize("mode", ["serial", "streams"])
 def test_views_longer_than_16_bit_counts_take_the_generic_kernel(mode, monkeypatch):
     """The 8- and 16-round variants count tokens per slot in 16 bits: an entity with a view of more than 65535 tokens
     is sent to the generic kernel instead (by the overflow chain, or by the classify pass even when this corpus has no
@@ -374,7 +374,7 @@ def test_eight_views():
     s.close()
 
 
-@pytest.mark.parametrize("mode,force", [("optimistic", "1"), ("optimistic", "16"), ("classified", "1"), ("classified", "4"), ("classified", "16")])
+@pytest.mark.parametrize("mode,force", [("serial", "1"), ("serial", "16"), ("streams", "1"), ("streams", "4"), ("streams", "16")])
 def test_inactive_topic_activation_across_kernel_classes(mode, force, monkeypatch):
     """The truncated-HDP branch with entities spread over several kernel classes: the first delta on an inactive
     topic (in entity, view, position order, UPD:263-270) is found by atomicMin over every kernel of the sweep."""

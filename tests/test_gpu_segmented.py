@@ -43,7 +43,7 @@ def oracle_segmented_sweep(o, c, it, seed, nseg):
     return stats, first + (n_act,)
 
 
-@pytest.mark.parametrize("force,mode", [("", ""), ("1", "optimistic"), ("2", "classified"), ("8", "optimistic")])
+@pytest.mark.parametrize("force,mode", [("", ""), ("1", "serial"), ("2", "streams"), ("8", "serial")])
 @pytest.mark.parametrize("nseg", [0, 2, 5])
 def test_segmented_sweep_bit_exact(nseg, force, mode, monkeypatch):
     if force:
