@@ -137,6 +137,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_NARROW")) h->tu.narrow = atoi(f) != 0 ? -1 : 0;
     if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
+    if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_FORCE_MODE")) { if (!strcmp(f, "serial")) h->tu.single_stream = 1; }   // "streams" (default): class kernels side by side
     if (const char* f = getenv("MVHDP_PRIMARY_MIN_SHARE")) { const double v = atof(f); if (v > 0.0 && v <= 1.0) h->tu.primary_min_share = v; }
     if (const char* t = getenv("MVHDP_WALK_THETA")) {

@@ -20,12 +20,13 @@
 
 // Streams of one sweep: the primary variant on the handle's stream, the wider classes beside it (HIP maps streams onto
 // few hardware queues: more than three side streams only serialise behind each other).
-// The WIDEST class of a sweep (its longest entities: the critical path) runs on the handle's own stream, right behind the route pass:
-// its few blocks are resident before anything else; the primary -- a persistent grid that fills the chip -- waits for the fork event
-// on a side stream and takes the rest (measured the other way round, the primary won the race and the wide entities started when
-// its first blocks drained: +0.15 ms per launch).
-enum { PLAN_STREAM_MAIN = 0, PLAN_STREAM_A = 1 /* generic + 16-round */, PLAN_STREAM_B = 2 /* 8-round */, PLAN_STREAM_C = 3 /* 4- and 2-round */,
-       PLAN_STREAM_P = 4 /* the primary, when a wider class runs beside it */, PLAN_N_STREAMS = 5 };
+// Never more than three side streams: the runtime maps streams onto four hardware queues.
+// Measured on C4 (round 3, gpurun_out/r3_m4_*, r3_m5_*): the primary on the handle's stream and the wider classes behind the fork
+// event on side streams is the fastest arrangement (deferred 32.97 ms over sweeps 5-24, segmented 33.9 settled); the widest class on
+// the handle's stream and the primary on a side stream -- so that the long entities are resident first -- loses 1-2 ms per sweep
+// while two classes are populated (34.15 / 34.2: the primary then trickles in behind the wide class's blocks); everything on one
+// stream costs a full kernel boundary per class and segment (32.73 / 35.7).  PlanTuning::widest_on_main / single_stream keep both.
+enum { PLAN_STREAM_MAIN = 0, PLAN_STREAM_A = 1, PLAN_STREAM_B = 2, PLAN_STREAM_C = 3, PLAN_N_STREAMS = 4 };
 
 // Register counts of the compiled kernels (hipFuncGetAttributes at mvhdp_create; typical values in the CPU tests):
 // [class 0..4][0: plain, 1: walk flavour, 2: debug], [5][0/2]: the generic kernel
@@ -121,6 +122,7 @@ struct PlanTuning {
     double walk_theta[MVHDP_MAXM] = {0};
     double primary_min_share = 0.10;            // the narrowest class holding at least this share of the tokens gets its own (primary) kernel
     int single_stream = 0;                      // 1: every class kernel on the handle's stream, one after another (diagnostics)
+    int widest_on_main = 0;                     // 1: the widest class on the handle's stream, the primary on a side stream (diagnostics)
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
 };
 
@@ -412,10 +414,10 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
             for (int m = 0; m < MVHDP_MAXM; m++) g.theta[m] = theta[group_of(c)][m];
             p.cls[c] = g;
         }
-        if (!tu.single_stream) {
-            int widest = -1;
-            for (int c = MVHDP_N_CLASSES - 1; c > pc; c--) if (p.cls[c].used) { widest = c; break; }
-            if (widest >= 0) { p.cls[widest].stream = PLAN_STREAM_MAIN; p.cls[pc].stream = PLAN_STREAM_P; }
+        if (!tu.single_stream && tu.widest_on_main) {
+            // widest first: the handle's stream, then side streams A, B, C in turn (the last one shared by whatever is left)
+            int next = PLAN_STREAM_MAIN;
+            for (int c = MVHDP_N_CLASSES - 1; c >= pc; c--) if (p.cls[c].used) { p.cls[c].stream = next; next = std::min(next + 1, (int)PLAN_STREAM_C); }
         }
         // a list of a class nobody launched goes to the next wider launched class (a wider variant holds narrower lists); the widest
         // reachable class is always launched when the sizes are not all known

@@ -52,7 +52,7 @@ def test_c4_early_chain_two_round_primary_and_a_four_round_class_beside_it():
     assert list(po.class_used) == [0, 1, 1, 0, 0, 0]
     assert list(po.class_map)[:3] == [1, 1, 2]
     assert po.routed_prefix == 900_000                                      # entities with more than 128 tokens
-    assert po.class_stream[2] == 0 and po.class_stream[1] == 4              # the widest class on the handle's stream, the primary behind the fork event
+    assert po.class_stream[1] == 0 and po.class_stream[2] == 3              # primary on the handle's stream, the wider class beside it
     assert po.class_narrow[1] == 0
     assert po.class_grid[1] == 256 * 6                                      # 80 VGPRs: 6 waves per SIMD = 6 blocks of 4 waves per CU
 
@@ -65,7 +65,7 @@ def test_c4_settling_chain_one_round_primary_with_the_mirror():
     assert po.routed_prefix == 1_000_000                                    # every entity has more than 64 tokens
     assert po.class_walk[0] == 1 and po.class_narrow[0] == 1 and po.class_theta0[0] == 0.5
     assert po.class_narrow[1] == 0                                          # the mirror is the 1-round walk flavour's
-    assert po.class_stream[2] == 0 and po.class_stream[1] == 3 and po.class_stream[0] == 4
+    assert po.class_stream[0] == 0 and po.class_stream[1] == 3 and po.class_stream[2] == 3
     assert po.class_grid[0] == 256 * 7                                      # 72 VGPRs: 7 waves per SIMD
     # a live sweep cannot use the snapshot mirror; nor a sweep that re-uses trees which are not current
     po = probe(tok=[80_000_000, 66_000_000], ent=[550_000, 450_000], flags=SWEEP_LIVE, tuning=dict(walk_fixed=1, walk_theta=[0.5], live16=0))
@@ -109,7 +109,7 @@ def test_c5_power_law_every_class_on_its_stream():
                ent=[800_000, 150_000, 40_000, 8_000, 1_500, 0, 0, 0])
     assert po.primary_class == 0
     assert list(po.class_used) == [1, 1, 1, 1, 1, 0]
-    assert [po.class_stream[c] for c in range(5)] == [4, 3, 3, 2, 0]
+    assert [po.class_stream[c] for c in range(5)] == [0, 3, 3, 2, 1]
     assert [probe(K=1000, M=5, mdt=2080, longer=(600_000, 200_000, 60_000, 9_000, 2_000), tok=[50, 30, 10, 6, 2, 2, 1, 1] + [1] * 8,
                   ent=[800, 150, 40, 8, 2, 0, 0, 0], tuning=dict(single_stream=1)).class_stream[c] for c in range(5)] == [0] * 5
     assert po.need_full_trees == 0
