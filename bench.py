@@ -74,8 +74,10 @@ def main():
                          "not bit-reproducible, so not the default")
     ap.add_argument("--live-segments", type=int, default=0, help="F+tree rebuilds per live sweep (0 = library default)")
     ap.add_argument("--live-steps", type=int, default=None,
-                    help="live sweeps timed after the K steps for the 'live' object (default: 5 on one GPU, 0 on several; 0 = none)")
-    ap.add_argument("--plain-exchange", action="store_true", help="N>1: one all-reduce then apply, instead of the chunked pipeline")
+                    help="sweeps of each secondary update mode timed after the K steps, behind 3 warm-up sweeps of that mode "
+                         "(default: 10 on one GPU, 0 on several; 0 = none)")
+    ap.add_argument("--torch-exchange", action="store_true",
+                    help="N>1: the exchange through torch.distributed on host copies (the fallback path) instead of the library's own RCCL group")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks all on cuda:0 with the gloo backend (host-staged all-reduce): exercises the "
                          "sharding logic on a 1-GPU box; not a performance number")
@@ -101,10 +103,10 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from mvtopicmodel_amd import NativeSampler, synth
+    from mvtopicmodel_amd import NativeGroup, NativeSampler, synth
     from mvtopicmodel_amd.dist import GpuShard, build_counts_all_reduce, sweep_all_reduce
     from mvtopicmodel_amd.host import init_assignments
-    from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS
+    from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sweep has no CPU fallback")
@@ -113,11 +115,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
+        # torch.distributed is the launcher's control plane only (gloo on the host: the 128-byte RCCL id, barriers, the max over
+        # ranks of the wall time); the data path -- the all-reduce of the count deltas -- is RCCL inside libmvhdp.so (mvhdp_group_*)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        dist.init_process_group(backend="gloo")
 
     cfg = dict(synth.CONFIGS[args.workload])
     D_total = args.docs or cfg["D"]
@@ -150,11 +151,72 @@ def main():
     sweep_flags = 0
     if args.live:
         sweep_flags = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(args.live_segments)
-    shard = GpuShard(s, device, host_staged=args.rehearse_on_one_gpu)
-    build_counts_all_reduce(shard)
     local_tokens = corpus.total_tokens
     del z0
+
+    def all_ranks_ok(ok):
+        """Every rank learns whether EVERY rank succeeded (a failure on one rank must not leave the others inside a collective)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item()) == 0
+
+    # ---- the exchange step ----
+    #   world == 1            none: one handle, the library applies its own deltas
+    #   world  > 1            mvhdp_group_* (RCCL inside the library), one rank per process
+    #   fallback              the same shards through torch.distributed on host copies (gloo): taken by ALL ranks together when the
+    #                         native group cannot be formed or fails in the warm-up on ANY rank; the model is recounted from z
+    #                         first (mvhdp_build_counts drops pending deltas), so the numbers that follow are of a consistent model
+    group = shard = None
+    exchange = {"kind": "none (one shard)"}
+    if world > 1 and not args.rehearse_on_one_gpu and not args.torch_exchange:
+        err = None
+        try:
+            ids = [NativeGroup.unique_id() if rank == 0 else None]
+        except Exception as e:
+            ids, err = [None], repr(e)
+        dist.broadcast_object_list(ids, src=0)
+        try:
+            if ids[0] is None:
+                raise RuntimeError("rank 0 could not obtain an RCCL id")
+            group = NativeGroup.from_rank(s, ids[0], rank, world)
+            group.build_counts()
+        except Exception as e:
+            err = err or repr(e)
+        if all_ranks_ok(err is None):
+            exchange = {"kind": "native: mvhdp_group_sweep, RCCL all-reduce inside libmvhdp.so, %d row ranges pipelined with apply + tree rebuild" % group.info().exchange_chunks,
+                        "rccl_version": int(group.info().rccl_version)}
+        else:
+            if group is not None:
+                group.close()
+            group = None
+            exchange = {"kind": "fallback", "fallback_reason": err or "another rank failed"}
+    if world > 1 and group is None:
+        shard = GpuShard(s, device, host_staged=True)
+        build_counts_all_reduce(shard)
+        exchange["kind"] = ("fallback -> " if "fallback_reason" in exchange else "") + "torch.distributed (gloo) all-reduce on host copies, then apply"
+    if world == 1:
+        s.build_counts()
     setup_s = time.time() - t_setup
+
+    phases = {}
+
+    def step(idx, flags):
+        t0 = time.perf_counter()
+        if group is not None:
+            st = group.sweep(idx, args.seed, flags)[0]
+        elif shard is not None:
+            st = sweep_all_reduce(shard, idx, args.seed, flags=flags, pipeline=False)
+        else:
+            st = s.sweep(idx, args.seed, flags=flags)
+        phases["step_call_host"] = phases.get("step_call_host", 0.0) + (time.perf_counter() - t0) * 1e3
+        phases["sweep_kernel"] = phases.get("sweep_kernel", 0.0) + st.sweep_kernel_ms
+        phases["sweep_device_total"] = phases.get("sweep_device_total", 0.0) + st.total_ms
+        if group is not None:
+            phases["exchange_device"] = phases.get("exchange_device", 0.0) + group.info().last_exchange_ms
+        phases["n"] = phases.get("n", 0) + 1
+        return st
 
     def barrier():
         torch.cuda.synchronize()
@@ -162,36 +224,40 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # the exchange step: pipelined (chunked all-reduce overlapped with apply + tree rebuild) unless it fails in the warm-up,
-    # in which case every rank falls back to the plain sequence (sweep -> one all-reduce -> apply) and the line says so
-    exchange = {"pipeline": not args.plain_exchange}
-    for w in range(args.warmup):
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # warm-up; a failure of the native exchange here is agreed on by all ranks, the model recounted, and the run continues on the
+    # fallback path with the NEXT sweep index (nothing is re-sampled on top of a half-exchanged state)
+    w = 0
+    while w < args.warmup:
+        err = None
         try:
-            sweep_all_reduce(shard, w, args.seed, flags=sweep_flags, pipeline=exchange["pipeline"])
+            step(w, sweep_flags)
         except Exception as e:
-            if not exchange["pipeline"] or world == 1:
-                raise
-            exchange = {"pipeline": False, "fallback_reason": repr(e)}
-            for cleanup in (lambda: s.apply_delta_end(-1, -1), lambda: s.apply_delta(-1, -1), s.synchronize):
-                try:                                 # close a half-open apply bracket, drop pending deltas
-                    cleanup()
-                except Exception:
-                    pass
-            sweep_all_reduce(shard, w, args.seed, flags=sweep_flags, pipeline=False)
+            err = repr(e)
+        w += 1
+        if not all_ranks_ok(err is None):
+            if group is None:
+                raise SystemExit("sweep failed in the warm-up: %s" % (err or "on another rank"))
+            group.close(); group = None
+            shard = GpuShard(s, device, host_staged=True)
+            build_counts_all_reduce(shard)            # recount from z on every rank + sum: a consistent model again
+            exchange = {"kind": "fallback -> torch.distributed (gloo) all-reduce on host copies, then apply", "fallback_reason": err or "another rank failed"}
+    phases.clear()
     barrier()
     kernel_ms = []
-    phases = {}
     t0 = time.perf_counter()
     last = None
     for k in range(args.steps):
-        last = sweep_all_reduce(shard, args.warmup + k, args.seed, flags=sweep_flags, timings=phases, pipeline=exchange["pipeline"])
+        last = step(args.warmup + k, sweep_flags)
         kernel_ms.append(last.sweep_kernel_ms)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     value = total_tokens * args.steps / dt
     # roofline of the dominant kernel (sweep_fast_kernel<R>) on this rank: algorithmic bytes per launch /
@@ -236,67 +302,71 @@ def main():
                                   "tree": last.word_ftree_mass_cnt / max(1, last.tokens)},
                   "exact_fallbacks": last.exact_fallbacks, "total_ms_last": last.total_ms},
         "setup_s": setup_s,
-        # rank 0's milliseconds per step by phase (mvtopicmodel_amd.dist.sweep_all_reduce): host wall time of the
-        # sweep call (view weights, F+tree rebuild, kernels, statistics read-back), of which device time in the sweep
-        # kernels; the collective (device time by events on the shared stream); apply (waits for the collective)
+        # rank 0's milliseconds per step by phase: host wall time of the step call (plan, launches, one or two synchronisations),
+        # device time of the sweep kernels, device time of the whole sweep, and (several GPUs) of the exchange: collectives + the
+        # update and tree rebuild of the row ranges (mvhdp_group_info.last_exchange_ms)
         "phase_ms": {k: v / max(1, phases.get("n", 1)) for k, v in phases.items() if k != "n"},
-        "exchange": ("none (one shard)" if world == 1 else
-                     ("pipelined: %d row-range all-reduces overlapped with apply + tree rebuild" % 4 if exchange["pipeline"] else
-                      "plain: one all-reduce, then apply" + (" (pipeline failed in warm-up: %s)" % exchange["fallback_reason"] if "fallback_reason" in exchange else ""))),
+        "exchange": exchange,
         "update_mode": ("live, %d tree rebuilds per sweep" % (args.live_segments or 4)) if args.live else "deferred (snapshot sweep, bit-reproducible)",
+        # What a sweep of each update mode is worth, in sweeps of the CPU restatement of the reference's thread topology, from the
+        # log-likelihood curves of profiles/r02_ll_curves.md (C3, same corpus / start / hyper-parameters): GPU sweeps needed to
+        # reach the log-likelihood the reference reaches in one.  Tokens/s of different modes are comparable only after dividing by it.
+        "reference_sweep_equivalent": {
+            "source": "profiles/r02_ll_curves.md",
+            "gpu_sweeps_per_reference_sweep": {"deferred": [1.4, 2.3], "live": [0.92, 1.0], "segmented": [0.94, 1.07]},
+        },
     }
     # order-independent fingerprint of the final global counts: must not depend on the number of shards
     nk_fp = [int(np.asarray(s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]
     out["final_nk_fingerprint"] = nk_fp
+    out["value_in_reference_sweeps"] = {"deferred": [value / 2.3, value / 1.4]} if not args.live else {"live": [value / 1.0, value / 0.92]}
     if args.live_steps is None:
-        args.live_steps = 5 if world == 1 else 0
+        args.live_steps = 10 if world == 1 else 0
+    sec_warm = 3                                    # warm-up sweeps of a secondary mode (its kernels' flavours and thresholds settle)
+    base_idx = args.warmup + args.steps
+
+    def time_mode(flags, first_idx):
+        for k in range(sec_warm):
+            step(first_idx + k, flags)
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(args.live_steps):
+            step(first_idx + sec_warm + k, flags)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t1)
+
     if not args.live and args.live_steps > 0:
-        # The other update mode, timed after (and outside) the K steps above: MVHDP_SWEEP_LIVE, the reference's own
-        # discipline.  profiles/r02_ll_curves.md: a live sweep is worth one sweep of the CPU reference (0.93-1.0 sweeps
-        # needed per reference sweep on C3), a deferred sweep 0.4-0.7 of one -- quote tokens/s with that in mind.
+        # The other update mode, timed after (and outside) the K steps above: MVHDP_SWEEP_LIVE, the reference's own discipline
+        # (atomics on the shared n_wk while the sweep samples, UPD:197-207; on the 16-bit mirror of the light rows where K >= 256)
         lf = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(args.live_segments)
         try:
-            sweep_all_reduce(shard, args.warmup + args.steps, args.seed, flags=lf)
-            barrier()
-            t1 = time.perf_counter()
-            for k in range(args.live_steps):
-                sweep_all_reduce(shard, args.warmup + args.steps + 1 + k, args.seed, flags=lf)
-            barrier()
-            dl = time.perf_counter() - t1
-            if world > 1:
-                tl = torch.tensor([dl], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
-                dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-                dl = float(tl.item())
+            dl = time_mode(lf, base_idx)
+            v = total_tokens * args.live_steps / dl
+            out["live"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm,
+                           "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
+                           "note": "MVHDP_SWEEP_LIVE, timed after the K deferred steps; sweep for sweep equal to the CPU reference "
+                                   "(profiles/r02_ll_curves.md), not bit-reproducible"}
+            out["value_in_reference_sweeps"]["live"] = [v / 1.0, v / 0.92]
         except Exception as e:                      # the secondary measurement must never cost the primary one
             out["live"] = {"error": repr(e)}
-            dl = None
-        if dl is not None:
-            out["live"] = {"value": total_tokens * args.live_steps / dl, "unit": "tokens/s", "steps": args.live_steps,
-                           "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
-                           "note": "MVHDP_SWEEP_LIVE (atomics on the shared n_wk, UPD:197-207), timed after the K deferred steps; "
-                                   "sweep-for-sweep equal to the CPU reference (profiles/r02_ll_curves.md), not bit-reproducible"}
     if world == 1 and not args.live and args.live_steps > 0:
-        # the deterministic middle ground, single GPU only: a deferred sweep in 8 interleaved segments with the deltas
-        # applied in between (MVHDP_SWEEP_SEGMENT_APPLY): bit-exact against the oracle like the plain deferred sweep and
-        # 0.94-1.07 sweeps per sweep of the CPU reference (profiles/r02_ll_curves.md)
+        # the deterministic middle ground, single handle only: a deferred sweep in 8 interleaved segments with the deltas applied
+        # (and the trees rebuilt) in between (MVHDP_SWEEP_SEGMENT_APPLY): bit-exact against the oracle like the plain deferred sweep
         try:
-            from mvtopicmodel_amd.native import SWEEP_SEGMENT_APPLY
             sf = SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(8)
-            base = args.warmup + args.steps + args.live_steps + 1
-            s.sweep(base, args.seed, flags=sf)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for k in range(args.live_steps):
-                s.sweep(base + 1 + k, args.seed, flags=sf)
-            torch.cuda.synchronize()
-            dsg = time.perf_counter() - t1
-            out["segmented"] = {"value": total_tokens * args.live_steps / dsg, "unit": "tokens/s", "steps": args.live_steps,
+            dsg = time_mode(sf, base_idx + sec_warm + args.live_steps)
+            v = total_tokens * args.live_steps / dsg
+            out["segmented"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm,
                                 "ms_per_step": dsg / args.live_steps * 1e3, "segments": 8,
                                 "note": "MVHDP_SWEEP_SEGMENT_APPLY: deferred sweep in 8 segments, deltas applied and trees rebuilt in "
                                         "between; deterministic (oracle-checked), about one reference sweep per sweep"}
+            out["value_in_reference_sweeps"]["segmented"] = [v / 1.07, v / 0.94]
         except Exception as e:
             out["segmented"] = {"error": repr(e)}
-    shard.close()
+    if group is not None:
+        group.close()
+    if shard is not None:
+        shard.close()
     s.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample_docs, D_total), 3, args.seed)

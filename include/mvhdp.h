@@ -291,6 +291,42 @@ int mvhdp_plan_probe(const mvhdp_plan_input* in, const mvhdp_tuning* tuning /* o
 int mvhdp_tuner_probe(int32_t num_modalities, const double* tree_branch_share /*[M]*/, const double* u1_hist /*[20] or NULL*/,
                       const double* ns_by_step /*[21]*/, int32_t n_sweeps, int32_t group, int32_t* steps_out /*[n_sweeps]*/);
 
+/* ---- document shards on several GPUs: the exchange step inside the library ----
+ * What the reference keeps inside its own process -- the nst x nut queue mesh between sampler and updater threads and the
+ * barrier that ends an iteration (PTM:1042-1049, PTM:1232) -- for samplers that are GPUs: every member handle holds a
+ * contiguous range of entities (mvhdp_config.doc_id_base = global id of its first entity) and a full replica of the model.
+ * One mvhdp_group_sweep = every member samples its entities against the same snapshot; the int32 deltas are summed over all
+ * members (on the device where members share a GPU, by RCCL all-reduce over xGMI between GPUs: the only collective of the
+ * path), pipelined in row ranges with the update and F+tree rebuild of the rows that have arrived; with inactive topics the
+ * activation key (MVHDP_ACT_KEY) is MIN-reduced so that every replica activates the same topic (UPD:263-270).  Results are
+ * bit-identical to one handle holding every entity.  RCCL is opened at run time (librccl.so.1, or the file MVHDP_RCCL_LIB
+ * names): a single-GPU host never loads it.  A handle belongs to at most one group; destroy the group before its members. */
+typedef struct mvhdp_group_ctx* mvhdp_group;
+#define MVHDP_UNIQUE_ID_BYTES 128
+typedef struct {
+    int32_t local_members;        /* handles of this process in the group */
+    int32_t local_devices;        /* distinct GPUs among them = RCCL ranks of this process */
+    int32_t ranks, first_rank;    /* RCCL ranks over all processes; rank of this process's first device */
+    int32_t rccl;                 /* 1: the collective is RCCL; 0: one device and no RCCL installed (device-side sum only) */
+    int32_t rccl_version;
+    int32_t exchange_chunks;      /* row ranges per exchange (default 4) */
+    int32_t reserved;
+    double  last_exchange_ms;     /* device time of the last sweep's exchange on this process's first device: collectives + updates + tree rebuilds */
+} mvhdp_group_info;
+/* one process drives n GPUs (the Java host of INTEGRATION.md): ncclCommInitAll over the members' devices */
+int mvhdp_group_create(int32_t n, const mvhdp_handle* members, mvhdp_group* out);
+/* one process per GPU: rank 0 obtains an id, the host's launcher hands it to every rank, every rank calls create_rank (collective) */
+int mvhdp_group_unique_id(uint8_t* id /*[MVHDP_UNIQUE_ID_BYTES]*/);
+int mvhdp_group_create_rank(mvhdp_handle member, const uint8_t* id /*[MVHDP_UNIQUE_ID_BYTES]*/, int32_t rank, int32_t nranks, mvhdp_group* out);
+int mvhdp_group_destroy(mvhdp_group g);
+const char* mvhdp_group_last_error(mvhdp_group g);           /* g may be NULL: last create error */
+int mvhdp_group_get_info(mvhdp_group g, mvhdp_group_info* info);
+int mvhdp_group_set_exchange_chunks(mvhdp_group g, int32_t chunks /* 1..64 */);
+/* buildInitialTypeTopicCounts PTM:600-652 over all shards: every member counts its entities, the counts are summed over the group */
+int mvhdp_group_build_counts(mvhdp_group g);
+/* flags: MVHDP_SWEEP_LIVE (+ LIVE_SEGMENTS), EXACT_CHAIN, GENERIC_KERNEL; stats: one per local member, or NULL */
+int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats);
+
 /* ---- interop for collectives and stream sharing ---- */
 int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** dev_ptr, size_t* bytes);
 /* The caller has written MVHDP_BUF_COUNTS through the device pointer (e.g. the all-reduce of the shards' initial

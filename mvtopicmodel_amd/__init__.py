@@ -10,6 +10,6 @@ There is no CPU fallback: importing works anywhere, but creating a sampler
 without a gfx950 device raises.
 """
 from ._lib import load_library, LIB_PATH, MvhdpError  # noqa: F401
-from .native import NativeSampler, SweepStats, Hyper  # noqa: F401
+from .native import NativeGroup, NativeSampler, SweepStats, Hyper  # noqa: F401
 
-__all__ = ["load_library", "LIB_PATH", "MvhdpError", "NativeSampler", "SweepStats", "Hyper"]
+__all__ = ["load_library", "LIB_PATH", "MvhdpError", "NativeGroup", "NativeSampler", "SweepStats", "Hyper"]

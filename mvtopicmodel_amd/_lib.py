@@ -20,7 +20,11 @@ ABI_SYMBOLS = [
     "mvhdp_apply_delta", "mvhdp_apply_delta_begin", "mvhdp_apply_delta_rows", "mvhdp_apply_delta_end",
     "mvhdp_trees_current", "mvhdp_get_view_weights",
     "mvhdp_device_buffer", "mvhdp_counts_written", "mvhdp_set_stream", "mvhdp_synchronize",
+    "mvhdp_group_create", "mvhdp_group_unique_id", "mvhdp_group_create_rank", "mvhdp_group_destroy", "mvhdp_group_last_error",
+    "mvhdp_group_get_info", "mvhdp_group_set_exchange_chunks", "mvhdp_group_build_counts", "mvhdp_group_sweep",
 ]
+
+UNIQUE_ID_BYTES = 128
 
 
 class MvhdpError(RuntimeError):
@@ -63,6 +67,12 @@ class TuningC(C.Structure):
                 ("live16", C.c_int32), ("reserved", C.c_int32),
                 ("walk_theta", C.c_double * MAX_M), ("primary_min_share", C.c_double),
                 ("learnt_walk_step", C.c_int32 * 4), ("tree_branch_share", C.c_double * MAX_M)]
+
+
+class GroupInfoC(C.Structure):
+    _fields_ = [("local_members", C.c_int32), ("local_devices", C.c_int32), ("ranks", C.c_int32), ("first_rank", C.c_int32),
+                ("rccl", C.c_int32), ("rccl_version", C.c_int32), ("exchange_chunks", C.c_int32), ("reserved", C.c_int32),
+                ("last_exchange_ms", C.c_double)]
 
 
 class PlanInputC(C.Structure):
@@ -205,9 +215,18 @@ def load_library():
     L.mvhdp_counts_written.argtypes = [vp]
     L.mvhdp_set_stream.argtypes = [vp, vp]
     L.mvhdp_synchronize.argtypes = [vp]
+    L.mvhdp_group_create.argtypes = [i32, C.POINTER(vp), C.POINTER(vp)]
+    L.mvhdp_group_unique_id.argtypes = [vp]
+    L.mvhdp_group_create_rank.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.mvhdp_group_destroy.argtypes = [vp]
+    L.mvhdp_group_last_error.argtypes = [vp]; L.mvhdp_group_last_error.restype = C.c_char_p
+    L.mvhdp_group_get_info.argtypes = [vp, C.POINTER(GroupInfoC)]
+    L.mvhdp_group_set_exchange_chunks.argtypes = [vp, i32]
+    L.mvhdp_group_build_counts.argtypes = [vp]
+    L.mvhdp_group_sweep.argtypes = [vp, u32, u64, u32, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)  # raises AttributeError if the symbol is not exported
-        if name not in ("mvhdp_last_error", "mvhdp_version"):
+        if name not in ("mvhdp_last_error", "mvhdp_version", "mvhdp_group_last_error"):
             f.restype = C.c_int
     _lib = L
     return L

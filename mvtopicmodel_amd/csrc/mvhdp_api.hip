@@ -2,82 +2,9 @@
 // Owns the device state of one model shard (one HIP device), launches the
 // kernels of mvhdp_kernels.hip on one stream and copies results back.
 // There is NO CPU fallback: without a gfx950 device mvhdp_create fails.
-#include "mvhdp_device.h"
-#include "../../include/mvhdp.h"
-#include "mvhdp_plan.h"
-
-#include <algorithm>
-#include <functional>
-#include <climits>
-#include <mutex>
-#include <set>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
+#include "mvhdp_ctx.h"
 
 static thread_local std::string g_create_error;
-
-struct mvhdp_ctx {
-    mvhdp_config cfg{};
-    MvModel mm{};
-    int device = 0;
-    int num_cus = 256;
-    size_t max_lds = 65536;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t ev[4]{};
-    std::string err;
-
-    int64_t N[MVHDP_MAXM]{};                 // tokens per view
-    bool have_corpus[MVHDP_MAXM]{};
-    std::vector<int64_t> h_doc_off[MVHDP_MAXM];
-    void* d_doc_off[MVHDP_MAXM]{};
-    void* d_tok[MVHDP_MAXM]{};
-    void* d_z[MVHDP_MAXM]{};
-    int64_t max_doc_tokens = -1;             // over all views, lazily computed
-
-    double* d_alpha = nullptr;
-    uint8_t* d_inactive = nullptr;
-    std::vector<double> h_alpha;
-    std::vector<uint8_t> h_inactive;
-    bool have_hyper = false, have_counts = false, have_trees = false;
-    bool full_trees = false;                 // the FTree.tree arrays are current too (a sweep may refresh only the descent table)
-    bool trees_inference = false;            // leaves of the last build: p_wt alone (INF:576)
-    bool delta_clean = false;                // the delta buffer is known to be all zero
-    bool delta_pending = false;              // a NO_APPLY sweep has left deltas that mvhdp_apply_delta has not consumed yet
-    bool last_need_full = true;              // the last sweep's kernels could reach the generic kernel (needs FTree.tree itself)
-    int64_t rows_applied = -1;               // mvhdp_apply_delta_rows progress of the current begin/end bracket (-1: no bracket open)
-    bool device_released = false;            // release_device_resources has run (mvhdp_destroy, or the exit handler)
-
-    unsigned long long* d_ctl = nullptr;     // ONE block: [ST_COUNT] counters | activation key | META_WORDS64 | 8 work-queue heads (one reset launch, one read-back)
-    unsigned long long* d_stats = nullptr;   //   = d_ctl
-    long long* d_act_key = nullptr;          //   = d_ctl + ST_COUNT
-    unsigned long long* d_doc_counter = nullptr;
-    int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
-    unsigned int* d_ovf_meta = nullptr;      // META_*: the next sweep's histograms (tokens by list size, entities by kernel class), per-class list lengths, misroutes
-    int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
-    uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
-    hipStream_t side[PLAN_N_STREAMS]{};      // side streams of the wider kernel classes (created on first use; [0] unused: the handle's stream)
-    hipEvent_t ev_fork = nullptr, ev_join[PLAN_N_STREAMS]{};
-    std::vector<hipEvent_t> ev_many;         // mvhdp_sweep_many: two events per sweep of the batch
-    unsigned long long* d_stats_many = nullptr;   // mvhdp_sweep_many: [n][ST_COUNT]
-    int stats_many_cap = 0;
-    std::vector<int64_t> tokens_desc;        // entity token counts, descending (the order of d_doc_order)
-    int64_t* d_carry[MVHDP_MAXM]{};          // doc_topic_proportions: per view, the entity whose view-m counts score entity d (lazily built)
-    // what the last sweep (or the recount after new assignments) left behind for the next plan
-    unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class
-    unsigned long long last_ent[MVHDP_ENT_BINS]{};     // entities by kernel class
-    bool nslots_valid = false;               // MvModel::nslots and the two histograms describe the current assignments
-    bool counts_stale = false;               // assignments were replaced (set_assignments / init_from_trees) and the counts not rebuilt since
-    PlanRegs regs{};                         // register counts of the compiled kernels (occupancy)
-    PlanTuning tu;                           // what the host pinned (mvhdp_set_tuning; environment read once at create)
-    WalkTuner wt;                            // the walk-threshold search
-    bool dbg_env = false;                    // MVHDP_DEBUG was set at create
-    size_t lds_attr_set = 0;
-};
 
 // ---- handle registry and process exit ------------------------------------------------------------------
 // Every live handle is listed here.  The first mvhdp_create registers an atexit handler; it is registered AFTER the
@@ -106,26 +33,11 @@ static void register_handle(mvhdp_ctx* h)
     if (!g_atexit_registered) { atexit(mvhdp_at_exit); g_atexit_registered = true; }
 }
 
-static bool is_live(mvhdp_ctx* h)
+bool mvhdp_is_live(mvhdp_ctx* h)
 {
     std::lock_guard<std::mutex> lk(g_reg_mutex);
     return g_live && g_live->count(h) != 0;
 }
-
-#define CHECK_H(h) do { if (!(h) || !is_live(h)) return MVHDP_ERR_INVALID_ARG; \
-                        if ((h)->device_released) return MVHDP_ERR_STATE; /* the process is exiting */ } while (0)
-#define HIPC(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-    (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
-#define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
-
-static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
-
-// d_ovf_meta (u64 words unless said otherwise): [META_HIST .. +MVHDP_HIST_BINS+MVHDP_ENT_BINS) what the sweep kernels leave for the next
-// plan (SweepLaunch::slot_hist); u32 words [META_CLASS_COUNTS .. +MVHDP_N_CLASSES) lengths of the route pass's class lists;
-// [META_MISROUTED] entities the route pass could not place
-enum { META_HIST = 0, META_MISROUTED = 40, META_WORDS64 = 48, META_BYTES = META_WORDS64 * 8, META_CLASS_COUNTS = 64 /* u32 index = byte 256 */ };
-static_assert(MVHDP_HIST_BINS + MVHDP_ENT_BINS <= 32, "histograms overlap the class counts");
-enum { CTL_WORDS = ST_COUNT + 1 + META_WORDS64 + 8 };
 
 // The environment is read ONCE, here (diagnostics; a host uses mvhdp_set_tuning):
 //   MVHDP_FORCE_RMAX=1|2|4|8|16   primary variant          MVHDP_NARROW=0        never the 16-bit mirror
@@ -155,7 +67,7 @@ static void read_environment(mvhdp_ctx* h)
 
 extern "C" const char* mvhdp_version(void) { return "mvhdp 0.1 (gfx950)"; }
 
-extern "C" const char* mvhdp_last_error(mvhdp_handle h) { return (h && is_live(h)) ? h->err.c_str() : g_create_error.c_str(); }
+extern "C" const char* mvhdp_last_error(mvhdp_handle h) { return (h && mvhdp_is_live(h)) ? h->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
 {
@@ -232,6 +144,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     h->d_act_key = (long long*)(h->d_ctl + ST_COUNT);
     h->d_ovf_meta = (unsigned int*)(h->d_ctl + ST_COUNT + 1);
     h->d_doc_counter = h->d_ctl + ST_COUNT + 1 + META_WORDS64;                       // one work-queue head per kernel class
+    CREATE_HIP(hipHostMalloc((void**)&h->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipHostMallocDefault));   // pinned: the read-back never blocks the host
     for (int c = 0; c < MVHDP_N_CLASSES; c++)
         for (int f = 0; f < 3; f++) h->regs.regs[c][f] = mvhdp_sweep_kernel_regs(c, f);
     read_environment(h);
@@ -255,6 +168,7 @@ static void release_device_resources(mvhdp_ctx* h)
     for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); }
     fr(h->mm.counts); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
     fr(h->d_alpha); fr(h->d_inactive); fr(h->d_ctl);
+    if (h->h_ctl) { hipHostFree(h->h_ctl); h->h_ctl = nullptr; }
     h->d_stats = nullptr; h->d_act_key = nullptr; h->d_doc_counter = nullptr; h->d_ovf_meta = nullptr;
     fr(h->d_doc_order); fr(h->d_lists); fr(h->d_nslots); fr(h->d_stats_many);
     for (auto& e : h->ev_many) if (e) { hipEventDestroy(e); e = nullptr; }
@@ -720,16 +634,6 @@ static void fill_plan_in(mvhdp_ctx* h, uint32_t flags, bool debug, bool batch, P
     in.regs = h->regs;
 }
 
-// device-side buffers of the parity tests' debug outputs
-struct DebugBufs {
-    std::vector<void*> to_free;
-    double* tok_dbg[MVHDP_MAXM] = {};
-    int n_trace = 0;
-    const int64_t* trace_doc = nullptr; const int32_t* trace_view = nullptr; const int32_t* trace_pos = nullptr;
-    double* trace_out = nullptr;
-    void release() { for (void* p : to_free) hipFree(p); to_free.clear(); }
-};
-
 static int alloc_debug(mvhdp_ctx* h, const mvhdp_debug* dbg, DebugBufs& db)
 {
     const int K = h->mm.K, M = h->mm.M;
@@ -763,11 +667,6 @@ static int alloc_debug(mvhdp_ctx* h, const mvhdp_debug* dbg, DebugBufs& db)
     }
     return MVHDP_OK;
 }
-
-struct SweepOutcome {                        // what enqueue_sweep learnt on the way (segment-border activations need the host)
-    int n_activations = 0;
-    long long first_act = LLONG_MAX;
-};
 
 // Everything one sweep puts on the device, in stream order; returns without waiting (except at the segment borders of a live /
 // segmented sweep over a model with inactive topics, where the host performs the activation UPD:263-270).
@@ -1026,52 +925,67 @@ static int set_generic_lds(mvhdp_ctx* h, const SweepPlan& p)
     return MVHDP_OK;
 }
 
-extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
-                           const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats)
+int mvhdp_sweep_begin(mvhdp_ctx* h, uint32_t sweep_idx, uint64_t seed, uint32_t flags, const double* p_override, const mvhdp_debug* dbg, PendingSweep& ps)
 {
-    CHECK_H(h);
-    MvModel& mm = h->mm;
     int rc = sweep_preconditions(h, flags); if (rc) return rc;
     HIPC(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     rc = ensure_slot_counts(h); if (rc) return rc;
-    const bool debug = dbg != nullptr;
-    PlanIn in; fill_plan_in(h, flags, debug, false, in);
-    SweepPlan p;
-    plan_sweep(in, h->tu, h->wt, p);
-    if (p.err) FAIL(h, p.err, p.msg);
-    rc = set_generic_lds(h, p); if (rc) return rc;
-    if (h->dbg_env) debug_print_plan(h, p, sweep_idx);
-    DebugBufs db;
-    if (debug) { rc = alloc_debug(h, dbg, db); if (rc) return rc; }
-
+    ps.flags = flags; ps.dbg = dbg; ps.debug = dbg != nullptr; ps.oc = SweepOutcome();
+    PlanIn in; fill_plan_in(h, flags, ps.debug, false, in);
+    plan_sweep(in, h->tu, h->wt, ps.p);
+    if (ps.p.err) FAIL(h, ps.p.err, ps.p.msg);
+    rc = set_generic_lds(h, ps.p); if (rc) return rc;
+    if (h->dbg_env) debug_print_plan(h, ps.p, sweep_idx);
+    if (ps.debug) { rc = alloc_debug(h, dbg, ps.db); if (rc) return rc; }
     HIPC(h, hipEventRecord(h->ev[0], s));
-    SweepOutcome oc;
-    rc = enqueue_sweep(h, p, sweep_idx, seed, p_override, debug ? &db : nullptr, h->d_stats, h->ev[1], h->ev[2], oc);
-    if (rc) { db.release(); return rc; }
-    unsigned long long ctl[ST_COUNT + 1 + META_WORDS64] = {0};           // counters | activation key | histograms: one copy
-    hipError_t e = hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { db.release(); HIPC(h, e); }
-    const unsigned long long* hs = ctl;
-    const long long act = (long long)ctl[ST_COUNT];
-    const unsigned long long* meta = ctl + ST_COUNT + 1;
+    rc = enqueue_sweep(h, ps.p, sweep_idx, seed, p_override, ps.debug ? &ps.db : nullptr, h->d_stats, h->ev[1], h->ev[2], ps.oc);
+    if (rc) { ps.db.release(); return rc; }
+    // counters | activation key | histograms: one copy into the handle's pinned buffer, in stream order behind the kernels
+    hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, (ST_COUNT + 1 + META_WORDS64) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) { ps.db.release(); HIPC(h, e); }
+    ps.open = true;
+    return MVHDP_OK;
+}
+
+int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats)
+{
+    if (!ps.open) FAIL(h, MVHDP_ERR_STATE, "sweep_finish without sweep_begin");
+    ps.open = false;
+    MvModel& mm = h->mm;
+    const SweepPlan& p = ps.p;
+    const uint32_t flags = ps.flags;
+    HIPC(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { ps.db.release(); HIPC(h, e); }
+    const unsigned long long* hs = h->h_ctl;
+    const long long act = (long long)h->h_ctl[ST_COUNT];
+    const unsigned long long* meta = h->h_ctl + ST_COUNT + 1;
     if (hs[ST_MISCLASS] || meta[META_MISROUTED]) {
-        db.release();
+        ps.db.release();
         h->nslots_valid = false;
         FAIL(h, MVHDP_ERR_HIP, "internal: an entity reached a sweep kernel variant that cannot hold its topic list");
     }
-    if (debug) {
+    if (ps.debug) {
+        const mvhdp_debug* dbg = ps.dbg;
         for (int m = 0; m < mm.M; m++)
-            if (db.tok_dbg[m] && e == hipSuccess) e = hipMemcpy(dbg->tok_dbg[m], db.tok_dbg[m], (size_t)h->N[m] * 4 * sizeof(double), hipMemcpyDeviceToHost);
-        if (db.n_trace > 0 && e == hipSuccess) e = hipMemcpy(dbg->trace_out, db.trace_out, (size_t)db.n_trace * (mm.K + 1) * sizeof(double), hipMemcpyDeviceToHost);
-        db.release();
+            if (ps.db.tok_dbg[m] && e == hipSuccess) e = hipMemcpy(dbg->tok_dbg[m], ps.db.tok_dbg[m], (size_t)h->N[m] * 4 * sizeof(double), hipMemcpyDeviceToHost);
+        if (ps.db.n_trace > 0 && e == hipSuccess) e = hipMemcpy(dbg->trace_out, ps.db.trace_out, (size_t)ps.db.n_trace * (mm.K + 1) * sizeof(double), hipMemcpyDeviceToHost);
+        ps.db.release();
         if (e != hipSuccess) HIPC(h, e);
     }
 
     mvhdp_sweep_stats st;
     stats_from_counters(hs, act, st);
-    int n_activations = oc.n_activations;
+    const unsigned long long negatives = hs[ST_NEGATIVE];
+    // (mvhdp_apply_delta below re-uses the pinned buffer's source counters: everything needed from it is copied by now except
+    // the histograms, which learn_from_sweep reads -- keep them)
+    unsigned long long hist_keep[MVHDP_HIST_BINS + MVHDP_ENT_BINS];
+    std::copy(meta + META_HIST, meta + META_HIST + MVHDP_HIST_BINS + MVHDP_ENT_BINS, hist_keep);
+    unsigned long long hs_keep[ST_COUNT];
+    std::copy(hs, hs + ST_COUNT, hs_keep);
+    int n_activations = ps.oc.n_activations;
     int ret = MVHDP_OK;
     if (p.frozen) {
         // nothing was queued (WRK:587): the delta buffer is untouched
@@ -1083,11 +997,11 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
         if (p.seg_apply) h->delta_clean = true;                      // apply_delta_kernel zeroed what it added
         ret = apply_activation(h, st.activated_topic, st.activated_modality);
         if (st.activated_topic >= 0) n_activations++;
-        if (oc.first_act != LLONG_MAX) {                             // report the sweep's first activation
-            st.activation_key = oc.first_act;
-            st.activated_topic = MVHDP_ACT_KEY_TOPIC(oc.first_act); st.activated_modality = MVHDP_ACT_KEY_VIEW(oc.first_act);
+        if (ps.oc.first_act != LLONG_MAX) {                          // report the sweep's first activation
+            st.activation_key = ps.oc.first_act;
+            st.activated_topic = MVHDP_ACT_KEY_TOPIC(ps.oc.first_act); st.activated_modality = MVHDP_ACT_KEY_VIEW(ps.oc.first_act);
         }
-        if (ret == MVHDP_OK && hs[ST_NEGATIVE]) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
+        if (ret == MVHDP_OK && negatives) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
     } else {
         if (st.activated_topic >= 0) n_activations = 1;
         ret = mvhdp_apply_delta(h, st.activated_topic, st.activated_modality);
@@ -1099,10 +1013,20 @@ extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, ui
     hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
     st.sweep_kernel_ms = ms_k; st.total_ms = ms_t;
     st.activations = n_activations; st.reserved = 0;
-    const bool comparable = p.fast && !debug && !h->tu.walk_fixed && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN));
-    learn_from_sweep(h, p, hs, meta + META_HIST, ms_k, comparable);
+    const bool comparable = p.fast && !ps.debug && !h->tu.walk_fixed && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN));
+    learn_from_sweep(h, p, hs_keep, hist_keep, ms_k, comparable);
     if (stats) *stats = st;
     return ret;
+}
+
+extern "C" int mvhdp_sweep(mvhdp_handle h, uint32_t sweep_idx, uint64_t seed, uint32_t flags,
+                           const double* p_override, const mvhdp_debug* dbg, mvhdp_sweep_stats* stats)
+{
+    CHECK_H(h);
+    PendingSweep ps;
+    const int rc = mvhdp_sweep_begin(h, sweep_idx, seed, flags, p_override, dbg, ps);
+    if (rc) return rc;
+    return mvhdp_sweep_finish(h, ps, stats);
 }
 
 // n sweeps (indices first_idx .. first_idx + n - 1) put on the device back to back: ONE plan, no host round trip between the

@@ -1,0 +1,127 @@
+// mvhdp_ctx.h — the state behind an mvhdp_handle and the internal interfaces shared by the host-side sources of libmvhdp.so
+// (mvhdp_api.hip: the C ABI of one handle; mvhdp_group.hip: document shards on several GPUs).  Not installed: include/mvhdp.h is the ABI.
+#pragma once
+#include "mvhdp_device.h"
+#include "../../include/mvhdp.h"
+#include "mvhdp_plan.h"
+
+#include <algorithm>
+#include <functional>
+#include <climits>
+#include <mutex>
+#include <set>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+
+struct mvhdp_ctx {
+    mvhdp_config cfg{};
+    MvModel mm{};
+    int device = 0;
+    int num_cus = 256;
+    size_t max_lds = 65536;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[4]{};
+    std::string err;
+
+    int64_t N[MVHDP_MAXM]{};                 // tokens per view
+    bool have_corpus[MVHDP_MAXM]{};
+    std::vector<int64_t> h_doc_off[MVHDP_MAXM];
+    void* d_doc_off[MVHDP_MAXM]{};
+    void* d_tok[MVHDP_MAXM]{};
+    void* d_z[MVHDP_MAXM]{};
+    int64_t max_doc_tokens = -1;             // over all views, lazily computed
+
+    double* d_alpha = nullptr;
+    uint8_t* d_inactive = nullptr;
+    std::vector<double> h_alpha;
+    std::vector<uint8_t> h_inactive;
+    bool have_hyper = false, have_counts = false, have_trees = false;
+    bool full_trees = false;                 // the FTree.tree arrays are current too (a sweep may refresh only the descent table)
+    bool trees_inference = false;            // leaves of the last build: p_wt alone (INF:576)
+    bool delta_clean = false;                // the delta buffer is known to be all zero
+    bool delta_pending = false;              // a NO_APPLY sweep has left deltas that mvhdp_apply_delta has not consumed yet
+    bool last_need_full = true;              // the last sweep's kernels could reach the generic kernel (needs FTree.tree itself)
+    int64_t rows_applied = -1;               // mvhdp_apply_delta_rows progress of the current begin/end bracket (-1: no bracket open)
+    bool device_released = false;            // release_device_resources has run (mvhdp_destroy, or the exit handler)
+
+    unsigned long long* d_ctl = nullptr;     // ONE block: [ST_COUNT] counters | activation key | META_WORDS64 | 8 work-queue heads (one reset launch, one read-back)
+    unsigned long long* h_ctl = nullptr;     // pinned host copy of the first three parts (a sweep's read-back)
+    unsigned long long* d_stats = nullptr;   //   = d_ctl
+    long long* d_act_key = nullptr;          //   = d_ctl + ST_COUNT
+    unsigned long long* d_doc_counter = nullptr;
+    int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
+    unsigned int* d_ovf_meta = nullptr;      // META_*: the next sweep's histograms (tokens by list size, entities by kernel class), per-class list lengths, misroutes
+    int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
+    uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
+    hipStream_t side[PLAN_N_STREAMS]{};      // side streams of the wider kernel classes (created on first use; [0] unused: the handle's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[PLAN_N_STREAMS]{};
+    std::vector<hipEvent_t> ev_many;         // mvhdp_sweep_many: two events per sweep of the batch
+    unsigned long long* d_stats_many = nullptr;   // mvhdp_sweep_many: [n][ST_COUNT]
+    int stats_many_cap = 0;
+    std::vector<int64_t> tokens_desc;        // entity token counts, descending (the order of d_doc_order)
+    int64_t* d_carry[MVHDP_MAXM]{};          // doc_topic_proportions: per view, the entity whose view-m counts score entity d (lazily built)
+    // what the last sweep (or the recount after new assignments) left behind for the next plan
+    unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class
+    unsigned long long last_ent[MVHDP_ENT_BINS]{};     // entities by kernel class
+    bool nslots_valid = false;               // MvModel::nslots and the two histograms describe the current assignments
+    bool counts_stale = false;               // assignments were replaced (set_assignments / init_from_trees) and the counts not rebuilt since
+    PlanRegs regs{};                         // register counts of the compiled kernels (occupancy)
+    PlanTuning tu;                           // what the host pinned (mvhdp_set_tuning; environment read once at create)
+    WalkTuner wt;                            // the walk-threshold search
+    bool dbg_env = false;                    // MVHDP_DEBUG was set at create
+    size_t lds_attr_set = 0;
+};
+
+
+bool mvhdp_is_live(mvhdp_ctx* h);
+#define CHECK_H(h) do { if (!(h) || !mvhdp_is_live(h)) return MVHDP_ERR_INVALID_ARG; \
+                        if ((h)->device_released) return MVHDP_ERR_STATE; /* the process is exiting */ } while (0)
+#define HIPC(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
+#define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
+
+static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
+
+// d_ovf_meta (u64 words unless said otherwise): [META_HIST .. +MVHDP_HIST_BINS+MVHDP_ENT_BINS) what the sweep kernels leave for the next
+// plan (SweepLaunch::slot_hist); u32 words [META_CLASS_COUNTS .. +MVHDP_N_CLASSES) lengths of the route pass's class lists;
+// [META_MISROUTED] entities the route pass could not place
+enum { META_HIST = 0, META_MISROUTED = 40, META_WORDS64 = 48, META_BYTES = META_WORDS64 * 8, META_CLASS_COUNTS = 64 /* u32 index = byte 256 */ };
+static_assert(MVHDP_HIST_BINS + MVHDP_ENT_BINS <= 32, "histograms overlap the class counts");
+enum { CTL_WORDS = ST_COUNT + 1 + META_WORDS64 + 8 };
+
+
+// device-side buffers of the parity tests' debug outputs
+struct DebugBufs {
+    std::vector<void*> to_free;
+    double* tok_dbg[MVHDP_MAXM] = {};
+    int n_trace = 0;
+    const int64_t* trace_doc = nullptr; const int32_t* trace_view = nullptr; const int32_t* trace_pos = nullptr;
+    double* trace_out = nullptr;
+    void release() { for (void* p : to_free) hipFree(p); to_free.clear(); }
+};
+
+struct SweepOutcome {                        // what enqueue_sweep learnt on the way (segment-border activations need the host)
+    int n_activations = 0;
+    long long first_act = LLONG_MAX;
+};
+
+// A sweep between its two halves: mvhdp_sweep_begin plans it and puts everything on the device without waiting (kernels, the
+// read-back of the counters into the handle's pinned buffer); mvhdp_sweep_finish waits, applies (unless NO_APPLY / FROZEN / live),
+// reports and learns.  mvhdp_sweep = begin + finish; a group begins the sweeps of all its members before it finishes any.
+struct PendingSweep {
+    SweepPlan p;
+    SweepOutcome oc;
+    uint32_t flags = 0;
+    bool debug = false;
+    const mvhdp_debug* dbg = nullptr;
+    DebugBufs db;
+    bool open = false;
+};
+int mvhdp_sweep_begin(mvhdp_ctx* h, uint32_t sweep_idx, uint64_t seed, uint32_t flags, const double* p_override, const mvhdp_debug* dbg, PendingSweep& ps);
+int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats);

@@ -1,0 +1,462 @@
+// mvhdp_group.hip — document shards on several GPUs inside the library (include/mvhdp.h "document shards").
+//
+// Replaces, for a host in ANY language, what the reference keeps inside its own process: the nst x nut queue mesh between
+// sampler and updater threads and the barrier at the end of an iteration (PTM:1042-1049, PTM:1232).  Here the samplers are
+// GPUs: every member handle holds a contiguous range of entities and a full replica of n_wk / n_k; one sweep of the group =
+//   every member samples its entities against the same snapshot (MVHDP_SWEEP_NO_APPLY)            WRK:186-233 x members
+//   the int32 deltas of all members are summed: device-side over members that share a GPU, RCCL all-reduce over xGMI between GPUs
+//   every replica applies the same sum row range by row range, rebuilding the F+trees of a range while the next is on the wire
+//   (when inActiveTopicIndex is non-empty) the activation key is MIN-reduced so that every replica activates the same topic UPD:263-270
+// Two ways to form a group: one process driving all its GPUs (mvhdp_group_create: ncclCommInitAll over the members' devices), or one
+// process per GPU (mvhdp_group_create_rank: ncclCommInitRank with an id the host's launcher passes around).
+//
+// RCCL is opened at run time (dlopen by soname; MVHDP_RCCL_LIB names another file): libmvhdp.so itself does not need it, a
+// single-GPU host never loads it, and a process that already has a copy mapped (PyTorch) shares that copy.
+#include "mvhdp_ctx.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <map>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    std::string path, why;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+
+// opens RCCL once per process; returns nullptr (and says why in g_rccl.why) when it cannot
+Rccl* rccl()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    if (g_rccl.lib) return &g_rccl;
+    if (!g_rccl.why.empty()) return nullptr;
+    std::vector<std::string> names;
+    names.push_back("librccl.so.1");                          // a copy that is mapped already (same soname) is re-used
+    if (const char* e = getenv("MVHDP_RCCL_LIB")) names.push_back(e);
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    std::string errs;
+    for (const std::string& n : names) {
+        void* l = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!l) { errs += std::string(dlerror() ? dlerror() : "?") + "; "; continue; }
+        g_rccl.lib = l; g_rccl.path = n;
+        break;
+    }
+    if (!g_rccl.lib) { g_rccl.why = "RCCL could not be opened: " + errs; return nullptr; }
+#define SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(g_rccl.lib, name); \
+        if (!g_rccl.field) { g_rccl.why = std::string("RCCL lacks ") + name; dlclose(g_rccl.lib); g_rccl.lib = nullptr; return nullptr; } } while (0)
+    SYM(GetVersion, "ncclGetVersion"); SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(AllReduce, "ncclAllReduce");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return &g_rccl;
+}
+
+__global__ __launch_bounds__(256) void add_into_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+hipError_t launch_add_into(int32_t* dst, const int32_t* src, int64_t n, hipStream_t s)
+{
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 8192);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(add_into_kernel, dim3(grid), dim3(256), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+struct mvhdp_group_ctx {
+    std::vector<mvhdp_ctx*> members;          // local members, in the caller's order
+    std::vector<int> leader_of;               // per member: index of the first member on the same device (its delta buffer takes the device's sum)
+    std::vector<int> leaders;                 // member indices that are leaders, one per distinct device: the RCCL ranks of this process
+    std::vector<ncclComm_t> comms;            // one communicator per leader (empty: no RCCL, a single device)
+    std::vector<hipEvent_t> ev_swept;         // per member: its sweep (or count build) is on its stream
+    std::vector<hipEvent_t> ev_reduced;       // per leader: the reduced buffer is complete
+    std::vector<long long*> d_key;            // per leader: 8 bytes for the MIN-reduce of the activation key
+    hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;   // around the exchange on leader 0's stream
+    int nranks = 1, rank0 = 0;                // ranks over all processes, rank of this process's first leader
+    bool multi_process = false;
+    bool rccl_used = false;
+    int rccl_version = 0;
+    int chunks = 4;                           // row ranges of one exchange: the apply + tree rebuild of range i runs while range i+1 is on the wire
+    double last_exchange_ms = 0.0;
+    long long sweeps = 0;
+    std::string err;
+};
+
+static std::mutex g_group_mutex;
+static std::set<mvhdp_group_ctx*>* g_groups = nullptr;
+static thread_local std::string g_group_create_error;
+
+static bool group_live(mvhdp_group_ctx* g)
+{
+    std::lock_guard<std::mutex> lk(g_group_mutex);
+    return g_groups && g_groups->count(g) != 0;
+}
+
+#define CHECK_G(g) do { if (!(g) || !group_live(g)) return MVHDP_ERR_INVALID_ARG; } while (0)
+#define GFAIL(g, code, msg) do { (g)->err = (msg); return (code); } while (0)
+#define GHIP(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
+#define GNCCL(g, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    (g)->err = std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error"); return MVHDP_ERR_HIP; } } while (0)
+#define GMEM(g, i, call) do { int rc_ = (call); if (rc_ != MVHDP_OK) { \
+    (g)->err = "member " + std::to_string(i) + ": " + (g)->members[i]->err; return rc_; } } while (0)
+
+extern "C" const char* mvhdp_group_last_error(mvhdp_group g)
+{
+    return (g && group_live(g)) ? g->err.c_str() : g_group_create_error.c_str();
+}
+
+static int64_t counts_len_of(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
+
+static int validate_members(int32_t n, const mvhdp_handle* members)
+{
+    if (n < 1 || !members) { g_group_create_error = "group_create: no members"; return MVHDP_ERR_INVALID_ARG; }
+    for (int i = 0; i < n; i++) {
+        mvhdp_ctx* h = members[i];
+        if (!h || !mvhdp_is_live(h) || h->device_released) { g_group_create_error = "group_create: member " + std::to_string(i) + " is not a live handle"; return MVHDP_ERR_INVALID_ARG; }
+        for (int j = 0; j < i; j++) if (members[j] == h) { g_group_create_error = "group_create: a handle is listed twice"; return MVHDP_ERR_INVALID_ARG; }
+        const MvModel &a = members[0]->mm, &b = h->mm;
+        bool same = a.K == b.K && a.M == b.M;
+        for (int m = 0; same && m < a.M; m++) same = a.V[m] == b.V[m];
+        if (!same) { g_group_create_error = "group_create: every member must hold the same model shape (topics, views, alphabet sizes)"; return MVHDP_ERR_INVALID_ARG; }
+    }
+    return MVHDP_OK;
+}
+
+static int group_common_init(mvhdp_group_ctx* g, int32_t n, const mvhdp_handle* members)
+{
+    std::map<int, int> first_on_device;
+    for (int i = 0; i < n; i++) {
+        mvhdp_ctx* h = members[i];
+        g->members.push_back(h);
+        auto it = first_on_device.find(h->device);
+        if (it == first_on_device.end()) { first_on_device[h->device] = i; g->leader_of.push_back(i); g->leaders.push_back(i); }
+        else g->leader_of.push_back(it->second);
+    }
+    for (int i = 0; i < n; i++) {
+        hipEvent_t ev;
+        GHIP(g, hipSetDevice(g->members[i]->device));
+        GHIP(g, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g->ev_swept.push_back(ev);
+    }
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        hipEvent_t ev; long long* k = nullptr;
+        GHIP(g, hipSetDevice(g->members[g->leaders[l]]->device));
+        GHIP(g, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g->ev_reduced.push_back(ev);
+        GHIP(g, hipMalloc(&k, sizeof(long long)));
+        g->d_key.push_back(k);
+    }
+    GHIP(g, hipSetDevice(g->members[g->leaders[0]]->device));
+    GHIP(g, hipEventCreate(&g->ev_x0));
+    GHIP(g, hipEventCreate(&g->ev_x1));
+    return MVHDP_OK;
+}
+
+static void group_register(mvhdp_group_ctx* g)
+{
+    std::lock_guard<std::mutex> lk(g_group_mutex);
+    if (!g_groups) g_groups = new std::set<mvhdp_group_ctx*>();
+    g_groups->insert(g);
+}
+
+static void group_release(mvhdp_group_ctx* g)
+{
+    Rccl* r = g_rccl.lib ? &g_rccl : nullptr;
+    for (size_t l = 0; l < g->comms.size(); l++) if (g->comms[l] && r) r->CommDestroy(g->comms[l]);
+    g->comms.clear();
+    for (size_t i = 0; i < g->ev_swept.size(); i++) if (g->ev_swept[i]) hipEventDestroy(g->ev_swept[i]);
+    for (size_t l = 0; l < g->ev_reduced.size(); l++) if (g->ev_reduced[l]) hipEventDestroy(g->ev_reduced[l]);
+    for (size_t l = 0; l < g->d_key.size(); l++) if (g->d_key[l]) hipFree(g->d_key[l]);
+    if (g->ev_x0) hipEventDestroy(g->ev_x0);
+    if (g->ev_x1) hipEventDestroy(g->ev_x1);
+}
+
+// One process, n handles: ncclCommInitAll over the distinct devices of the members.  Members that share a device (a test
+// arrangement: several document shards on one GPU) are summed on that device and enter the collective as one rank.
+extern "C" int mvhdp_group_create(int32_t n, const mvhdp_handle* members, mvhdp_group* out)
+{
+    if (!out) { g_group_create_error = "group_create: null"; return MVHDP_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int rc = validate_members(n, members); if (rc) return rc;
+    mvhdp_group_ctx* g = new mvhdp_group_ctx();
+    rc = group_common_init(g, n, members);
+    if (rc) { g_group_create_error = g->err; group_release(g); delete g; return rc; }
+    g->nranks = (int)g->leaders.size(); g->rank0 = 0; g->multi_process = false;
+    Rccl* r = rccl();
+    if (!r) {
+        if (g->leaders.size() > 1) { g_group_create_error = "group_create: " + g_rccl.why; group_release(g); delete g; return MVHDP_ERR_UNSUPPORTED; }
+        // one device and no RCCL in this installation: the exchange is the device-side sum alone (mvhdp_group_info says so)
+    } else {
+        std::vector<int> devs;
+        for (int l : g->leaders) devs.push_back(g->members[l]->device);
+        g->comms.assign(devs.size(), nullptr);
+        ncclResult_t nr = r->CommInitAll(g->comms.data(), (int)devs.size(), devs.data());
+        if (nr != ncclSuccess) {
+            g_group_create_error = std::string("ncclCommInitAll: ") + r->GetErrorString(nr);
+            g->comms.clear(); group_release(g); delete g; return MVHDP_ERR_HIP;
+        }
+        g->rccl_used = true;
+        r->GetVersion(&g->rccl_version);
+    }
+    group_register(g);
+    *out = g;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_group_unique_id(uint8_t* id)
+{
+    if (!id) { g_group_create_error = "group_unique_id: null"; return MVHDP_ERR_INVALID_ARG; }
+    Rccl* r = rccl();
+    if (!r) { g_group_create_error = "group_unique_id: " + g_rccl.why; return MVHDP_ERR_UNSUPPORTED; }
+    static_assert(MVHDP_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    ncclResult_t nr = r->GetUniqueId(&u);
+    if (nr != ncclSuccess) { g_group_create_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(nr); return MVHDP_ERR_HIP; }
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return MVHDP_OK;
+}
+
+// One process per GPU: this process's handle is rank `rank` of `nranks`; `id` comes from mvhdp_group_unique_id on one rank and
+// reaches the others through the host's launcher (a file, a socket, MPI, torch.distributed's store: 128 bytes).  Collective: every
+// rank must call it.
+extern "C" int mvhdp_group_create_rank(mvhdp_handle member, const uint8_t* id, int32_t rank, int32_t nranks, mvhdp_group* out)
+{
+    if (!out || !id) { g_group_create_error = "group_create_rank: null"; return MVHDP_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) { g_group_create_error = "group_create_rank: bad rank"; return MVHDP_ERR_INVALID_ARG; }
+    int rc = validate_members(1, &member); if (rc) return rc;
+    Rccl* r = rccl();
+    if (!r) { g_group_create_error = "group_create_rank: " + g_rccl.why; return MVHDP_ERR_UNSUPPORTED; }
+    mvhdp_group_ctx* g = new mvhdp_group_ctx();
+    rc = group_common_init(g, 1, &member);
+    if (rc) { g_group_create_error = g->err; group_release(g); delete g; return rc; }
+    g->nranks = nranks; g->rank0 = rank; g->multi_process = true;
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    g->comms.assign(1, nullptr);
+    hipSetDevice(member->device);
+    ncclResult_t nr = r->CommInitRank(&g->comms[0], nranks, u, rank);
+    if (nr != ncclSuccess) {
+        g_group_create_error = std::string("ncclCommInitRank: ") + r->GetErrorString(nr);
+        g->comms.clear(); group_release(g); delete g; return MVHDP_ERR_HIP;
+    }
+    g->rccl_used = true;
+    r->GetVersion(&g->rccl_version);
+    group_register(g);
+    *out = g;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_group_destroy(mvhdp_group g)
+{
+    if (!g) return MVHDP_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_group_mutex);
+        if (!g_groups || g_groups->erase(g) == 0) return MVHDP_ERR_INVALID_ARG;
+    }
+    for (mvhdp_ctx* h : g->members) if (mvhdp_is_live(h) && !h->device_released) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
+    group_release(g);
+    delete g;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_group_get_info(mvhdp_group g, mvhdp_group_info* info)
+{
+    CHECK_G(g);
+    if (!info) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_get_info: null");
+    memset(info, 0, sizeof *info);
+    info->local_members = (int32_t)g->members.size();
+    info->local_devices = (int32_t)g->leaders.size();
+    info->ranks = g->nranks; info->first_rank = g->rank0;
+    info->rccl = g->rccl_used ? 1 : 0; info->rccl_version = g->rccl_version;
+    info->exchange_chunks = g->chunks;
+    info->last_exchange_ms = g->last_exchange_ms;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_group_set_exchange_chunks(mvhdp_group g, int32_t chunks)
+{
+    CHECK_G(g);
+    if (chunks < 1 || chunks > 64) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_set_exchange_chunks: 1..64");
+    g->chunks = chunks;
+    return MVHDP_OK;
+}
+
+// ---- the exchange: buffer `which` of every member becomes the sum over ALL members of all ranks ----
+// Stream order throughout, no host wait: co-located members are added into their device's leader, the leaders all-reduce the
+// element range [e0, e1) (RCCL, in place, on the leader's stream), and ev_reduced[l] marks the range complete on leader l.
+static int reduce_local(mvhdp_group_ctx* g, bool counts)
+{
+    // members that share a device: delta_leader += delta_member, in stream order behind both sweeps
+    const int n = (int)g->members.size();
+    for (int i = 0; i < n; i++) {
+        const int li = g->leader_of[i];
+        if (li == i) continue;
+        mvhdp_ctx *h = g->members[i], *L = g->members[li];
+        GHIP(g, hipSetDevice(L->device));
+        GHIP(g, hipStreamWaitEvent(L->stream, g->ev_swept[i], 0));
+        GHIP(g, launch_add_into(counts ? L->mm.counts : L->mm.delta, counts ? h->mm.counts : h->mm.delta, counts_len_of(L), L->stream));
+    }
+    return MVHDP_OK;
+}
+
+static int allreduce_range(mvhdp_group_ctx* g, bool counts, int64_t e0, int64_t e1)
+{
+    if (e1 <= e0 || g->comms.empty()) return MVHDP_OK;
+    Rccl* r = &g_rccl;
+    if (g->comms.size() > 1) GNCCL(g, r->GroupStart());
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        mvhdp_ctx* L = g->members[g->leaders[l]];
+        GHIP(g, hipSetDevice(L->device));
+        int32_t* buf = (counts ? L->mm.counts : L->mm.delta) + e0;
+        GNCCL(g, r->AllReduce(buf, buf, (size_t)(e1 - e0), ncclInt32, ncclSum, g->comms[l], L->stream));
+    }
+    if (g->comms.size() > 1) GNCCL(g, r->GroupEnd());
+    return MVHDP_OK;
+}
+
+// the co-located members of a device take the reduced range from their leader
+static int fan_out_range(mvhdp_group_ctx* g, bool counts, int64_t e0, int64_t e1)
+{
+    if (e1 <= e0 || g->members.size() == g->leaders.size()) return MVHDP_OK;
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        mvhdp_ctx* L = g->members[g->leaders[l]];
+        GHIP(g, hipSetDevice(L->device));
+        GHIP(g, hipEventRecord(g->ev_reduced[l], L->stream));
+        for (size_t i = 0; i < g->members.size(); i++) {
+            if (g->leader_of[i] != g->leaders[l] || (int)i == g->leaders[l]) continue;
+            mvhdp_ctx* h = g->members[i];
+            GHIP(g, hipStreamWaitEvent(h->stream, g->ev_reduced[l], 0));
+            const int32_t* src = (counts ? L->mm.counts : L->mm.delta) + e0;
+            int32_t* dst = (counts ? h->mm.counts : h->mm.delta) + e0;
+            GHIP(g, hipMemcpyAsync(dst, src, (size_t)(e1 - e0) * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    return MVHDP_OK;
+}
+
+// buildInitialTypeTopicCounts PTM:600-652 over every shard: local counts, then the sum over all members of all ranks.
+extern "C" int mvhdp_group_build_counts(mvhdp_group g)
+{
+    CHECK_G(g);
+    const int n = (int)g->members.size();
+    for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_build_counts(g->members[i]));
+    for (int i = 0; i < n; i++) { GHIP(g, hipSetDevice(g->members[i]->device)); GHIP(g, hipEventRecord(g->ev_swept[i], g->members[i]->stream)); }
+    int rc = reduce_local(g, true); if (rc) return rc;
+    const int64_t len = counts_len_of(g->members[0]);
+    rc = allreduce_range(g, true, 0, len); if (rc) return rc;
+    rc = fan_out_range(g, true, 0, len); if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        GHIP(g, hipSetDevice(g->members[i]->device));
+        GHIP(g, hipStreamSynchronize(g->members[i]->stream));
+        GMEM(g, i, mvhdp_counts_written(g->members[i]));
+    }
+    return MVHDP_OK;
+}
+
+// One Gibbs sweep of the whole model (see the head of this file).  flags: MVHDP_SWEEP_EXACT_CHAIN, MVHDP_SWEEP_LIVE (+ segments: each
+// replica is live for its own entities and one sweep stale for the others', AD-LDA), MVHDP_SWEEP_GENERIC_KERNEL; NO_APPLY and
+// REUSE_TREES are the group's own business.  stats: one entry per local member, or NULL.  Bit-identical to the sweep of one handle
+// holding all entities (deferred mode): entities are independent under the snapshot and integer sums do not depend on the order.
+extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats)
+{
+    CHECK_G(g);
+    if (flags & (MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_SEGMENT_APPLY))
+        GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: NO_APPLY / REUSE_TREES are set by the group itself; FROZEN and SEGMENT_APPLY are single-handle modes");
+    const int n = (int)g->members.size();
+    const bool live = (flags & MVHDP_SWEEP_LIVE) != 0;
+    std::vector<PendingSweep> ps((size_t)n);
+    std::vector<mvhdp_sweep_stats> st((size_t)n);
+    // 1. every member's sweep goes on its device before any is waited for
+    for (int i = 0; i < n; i++) {
+        mvhdp_ctx* h = g->members[i];
+        // the trees a pipelined apply left behind are those of the counts this sweep starts from (a live sweep rebuilds per segment itself)
+        const uint32_t reuse = (h->have_trees && !live) ? MVHDP_SWEEP_REUSE_TREES : 0u;
+        GMEM(g, i, mvhdp_sweep_begin(h, sweep_idx, seed, flags | MVHDP_SWEEP_NO_APPLY | reuse, nullptr, nullptr, ps[i]));
+    }
+    int first_err = MVHDP_OK;
+    for (int i = 0; i < n; i++) {
+        const int rc = mvhdp_sweep_finish(g->members[i], ps[i], &st[i]);
+        if (rc != MVHDP_OK && first_err == MVHDP_OK) { first_err = rc; g->err = "member " + std::to_string(i) + ": " + g->members[i]->err; }
+    }
+    if (first_err != MVHDP_OK) return first_err;
+    for (int i = 0; i < n; i++) { GHIP(g, hipSetDevice(g->members[i]->device)); GHIP(g, hipEventRecord(g->ev_swept[i], g->members[i]->stream)); }
+    // 2. the exchange, as a pipeline in stream order: the tokensPerTopic part first (every tree needs all of it), then the n_wk rows in
+    //    `chunks` ranges -- while range i+1 is on the wire, range i is applied and its F+trees rebuilt (mvhdp_apply_delta_rows)
+    mvhdp_ctx* L0 = g->members[g->leaders[0]];
+    GHIP(g, hipSetDevice(L0->device));
+    GHIP(g, hipEventRecord(g->ev_x0, L0->stream));
+    int rc = reduce_local(g, false); if (rc) return rc;
+    const MvModel& mm = g->members[0]->mm;
+    const int64_t rows = mm.rowbase[mm.M], K = mm.K, nk_off = rows * K, len = counts_len_of(g->members[0]);
+    rc = allreduce_range(g, false, nk_off, len); if (rc) return rc;
+    rc = fan_out_range(g, false, nk_off, len); if (rc) return rc;
+    for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_apply_delta_begin(g->members[i]));
+    const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(g->chunks, rows));
+    for (int c = 0; c < nch; c++) {
+        const int64_t r0 = rows * c / nch, r1 = rows * (c + 1) / nch;
+        if (r1 <= r0) continue;
+        rc = allreduce_range(g, false, r0 * K, r1 * K); if (rc) return rc;
+        rc = fan_out_range(g, false, r0 * K, r1 * K); if (rc) return rc;
+        for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_apply_delta_rows(g->members[i], r0, r1));
+    }
+    // 3. UPD:263-270 across shards: the first activating delta in (entity, view, position) order wins on every replica alike
+    long long key = LLONG_MAX;
+    const bool has_inactive = g->members[0]->mm.first_inactive >= 0;       // the hyper-parameters are replicated: every rank answers alike
+    if (has_inactive) {
+        for (int i = 0; i < n; i++) key = std::min<long long>(key, (long long)st[i].activation_key);
+        if (!g->comms.empty() && g->nranks > 1) {
+            Rccl* r = &g_rccl;
+            for (size_t l = 0; l < g->leaders.size(); l++) {
+                mvhdp_ctx* L = g->members[g->leaders[l]];
+                GHIP(g, hipSetDevice(L->device));
+                GHIP(g, hipMemcpyAsync(g->d_key[l], &key, sizeof key, hipMemcpyHostToDevice, L->stream));
+            }
+            if (g->comms.size() > 1) GNCCL(g, r->GroupStart());
+            for (size_t l = 0; l < g->leaders.size(); l++) {
+                mvhdp_ctx* L = g->members[g->leaders[l]];
+                GHIP(g, hipSetDevice(L->device));
+                GNCCL(g, r->AllReduce(g->d_key[l], g->d_key[l], 1, ncclInt64, ncclMin, g->comms[l], L->stream));
+            }
+            if (g->comms.size() > 1) GNCCL(g, r->GroupEnd());
+            GHIP(g, hipSetDevice(L0->device));
+            GHIP(g, hipMemcpyAsync(&key, g->d_key[0], sizeof key, hipMemcpyDeviceToHost, L0->stream));
+            GHIP(g, hipStreamSynchronize(L0->stream));
+        }
+    }
+    GHIP(g, hipSetDevice(L0->device));
+    GHIP(g, hipEventRecord(g->ev_x1, L0->stream));
+    const int32_t topic = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_TOPIC(key), view = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_VIEW(key);
+    first_err = MVHDP_OK;
+    for (int i = 0; i < n; i++) {
+        const int rc2 = mvhdp_apply_delta_end(g->members[i], topic, view);
+        if (rc2 != MVHDP_OK && first_err == MVHDP_OK) { first_err = rc2; g->err = "member " + std::to_string(i) + ": " + g->members[i]->err; }
+        st[i].activation_key = key; st[i].activated_topic = topic; st[i].activated_modality = view;
+        st[i].activations = topic >= 0 ? 1 : 0;
+    }
+    float ms = 0;
+    hipSetDevice(L0->device);
+    if (hipEventElapsedTime(&ms, g->ev_x0, g->ev_x1) == hipSuccess) g->last_exchange_ms = ms;
+    g->sweeps++;
+    if (stats) for (int i = 0; i < n; i++) stats[i] = st[i];
+    return first_err;
+}

@@ -11,7 +11,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from ._lib import (MAX_M, Config, DebugC, HyperC, MvhdpError, SweepStatsC, TuningC, load_library)
+from ._lib import (MAX_M, UNIQUE_ID_BYTES, Config, DebugC, GroupInfoC, HyperC, MvhdpError, SweepStatsC, TuningC, load_library)
 
 SWEEP_REUSE_TREES = 0x1
 SWEEP_NO_APPLY = 0x2
@@ -354,3 +354,79 @@ class NativeSampler:
 
     def synchronize(self):
         self._ck(self.L.mvhdp_synchronize(self.h))
+
+
+class NativeGroup:
+    """Document shards on several GPUs, exchange step inside the library (include/mvhdp.h mvhdp_group_*): Python mirror of what
+    the Java host of INTEGRATION.md calls.  Two ways to form one:
+
+      NativeGroup(samplers)                            one process, one NativeSampler per GPU (or several on one GPU: tests)
+      NativeGroup.from_rank(sampler, id, rank, n)      one process per GPU; `id` = NativeGroup.unique_id() of one rank, handed to
+                                                       the others by the launcher (torch.distributed's store in bench.py)
+    """
+
+    def __init__(self, samplers=None, _handle=None, _members=None):
+        self.L = load_library()
+        if _handle is not None:
+            self.g, self.members = _handle, list(_members)
+            return
+        self.members = list(samplers)
+        arr = (C.c_void_p * len(self.members))(*[s.h for s in self.members])
+        self.g = C.c_void_p()
+        rc = self.L.mvhdp_group_create(len(self.members), arr, C.byref(self.g))
+        if rc != 0:
+            self.g = None
+            raise MvhdpError(rc, self.L.mvhdp_group_last_error(None).decode())
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        rc = L.mvhdp_group_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise MvhdpError(rc, L.mvhdp_group_last_error(None).decode())
+        return bytes(buf)
+
+    @classmethod
+    def from_rank(cls, sampler, unique_id, rank, nranks):
+        L = load_library()
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        g = C.c_void_p()
+        rc = L.mvhdp_group_create_rank(sampler.h, C.cast(buf, C.c_void_p), int(rank), int(nranks), C.byref(g))
+        if rc != 0:
+            raise MvhdpError(rc, L.mvhdp_group_last_error(None).decode())
+        return cls(_handle=g, _members=[sampler])
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MvhdpError(rc, self.L.mvhdp_group_last_error(self.g).decode())
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.mvhdp_group_destroy(self.g)
+            self.g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        t = GroupInfoC()
+        self._ck(self.L.mvhdp_group_get_info(self.g, C.byref(t)))
+        return t
+
+    def set_exchange_chunks(self, n):
+        self._ck(self.L.mvhdp_group_set_exchange_chunks(self.g, int(n)))
+
+    def build_counts(self):
+        self._ck(self.L.mvhdp_group_build_counts(self.g))
+
+    def sweep(self, sweep_idx, seed, flags=0):
+        """One sweep of the whole model; the list of the local members' statistics."""
+        n = len(self.members)
+        arr = (SweepStatsC * n)()
+        self._ck(self.L.mvhdp_group_sweep(self.g, int(sweep_idx), int(seed), int(flags), C.cast(arr, C.c_void_p)))
+        return [SweepStats(**{f: getattr(arr[i], f) for f, _ in SweepStatsC._fields_}) for i in range(n)]

@@ -1,0 +1,147 @@
+"""mvhdp_group_*: document shards with the exchange step inside the library (the counterpart of the reference's
+in-process queue mesh + barrier, PTM:1042-1049, PTM:1232).  One GPU here: a one-member group goes through the real RCCL
+collective (one rank); several members on the one device exercise the sharding itself (their deltas are summed on the device
+and enter the collective as one rank) -- both must give the oracle's integers.  The driver runs 2 / 4 / 8 GPUs."""
+import numpy as np
+import pytest
+
+from mvtopicmodel_amd import NativeGroup, synth
+from mvtopicmodel_amd._lib import MvhdpError
+from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_NO_APPLY
+from tests.helpers import assert_same_state, make_native, make_oracle, small_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _shards(c, hy, z, n):
+    """n NativeSamplers over contiguous entity ranges balanced by token count (synth.shard_bounds), global entity ids kept."""
+    tot = sum(np.diff(c.doc_off[m]) for m in range(c.M))
+    out = []
+    for lo, hi in synth.shard_bounds(tot, n):
+        sub = c.slice_docs(lo, hi)
+        zs = [z[m][c.doc_off[m][lo]:c.doc_off[m][hi]] for m in range(c.M)]
+        out.append(make_native(sub, hy, zs, doc_id_base=lo))
+    return out
+
+
+def _assert_group_equals_oracle(o, shards, c):
+    for m in range(c.M):
+        assert np.array_equal(np.concatenate([s.get_assignments(m) for s in shards]), o.get_assignments(m)), f"z differs in view {m}"
+        nwk, nk = o.get_counts(m)
+        for s in shards:
+            a, b = s.get_counts(m)
+            assert np.array_equal(a, nwk) and np.array_equal(b, nk), f"a replica's counts differ in view {m}"
+
+
+def test_one_member_group_goes_through_rccl_and_equals_the_plain_sweep():
+    K, V = 50, [600, 80]
+    c = small_corpus(K, V, 120, [40, 6], 91)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    with NativeGroup([s]) as g:
+        info = g.info()
+        assert (info.local_members, info.local_devices, info.ranks, info.rccl) == (1, 1, 1, 1) and info.rccl_version > 0
+        g.build_counts()
+        for it in range(4):
+            ro = o.sweep(it, 5)
+            st = g.sweep(it, 5)[0]
+            assert st.tokens == c.total_tokens and st.changed == ro["stats"]["changed"]
+            assert_same_state(o, s, 2)
+            assert s.trees_current()                                       # rebuilt row range by row range behind the collective
+            o.build_trees()
+            for m, w in [(0, 3), (1, 79)]:
+                assert np.array_equal(o.get_tree(m, w), s.get_tree(m, w))
+        assert g.info().last_exchange_ms > 0
+        with pytest.raises(MvhdpError):
+            g.sweep(9, 5, flags=SWEEP_NO_APPLY)                            # the group sets that itself
+    # the same through the one-process-per-GPU entry: an id, one rank
+    uid = NativeGroup.unique_id()
+    assert len(uid) == 128
+    with NativeGroup.from_rank(s, uid, 0, 1) as g:
+        assert g.info().rccl == 1 and g.info().ranks == 1
+        for it in range(4, 6):
+            o.sweep(it, 5); g.sweep(it, 5)
+            assert_same_state(o, s, 2)
+    s.close()
+
+
+@pytest.mark.parametrize("n,chunks", [(2, 4), (4, 1), (4, 7)])
+def test_members_on_one_device_equal_the_single_handle(n, chunks):
+    """n document shards (global entity ids, full model replicas) + the in-library exchange == one handle over all entities == the
+    oracle, including the topic the sweep activates (the first delta in entity order wins on every replica, UPD:263-270)."""
+    K, V = 60, [700, 90, 70]
+    c = small_corpus(K, V, 150, [40, 5, 6], 92)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[52, 57]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive); hy.alpha[:, K] = 25.0
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(3)]
+    for m in range(3):
+        z[m][np.isin(z[m], [52, 57])] = 1
+        o.set_assignments(m, z[m])
+    o.build_counts()
+    shards = _shards(c, hy, z, n)
+    with NativeGroup(shards) as g:
+        info = g.info()
+        assert (info.local_members, info.local_devices, info.ranks) == (n, 1, 1)
+        g.set_exchange_chunks(chunks)
+        g.build_counts()                                                    # local counts summed over the members
+        _assert_group_equals_oracle(o, shards, c)
+        acts = 0
+        for it in range(4):
+            ro = o.sweep(it, 11)
+            sts = g.sweep(it, 11)
+            assert sum(st.tokens for st in sts) == c.total_tokens
+            assert all(st.activated_topic == ro["stats"]["activated_topic"] and st.activated_modality == ro["stats"]["activated_modality"] for st in sts)
+            acts += ro["stats"]["activated_topic"] >= 0
+            _assert_group_equals_oracle(o, shards, c)
+            for s in shards:
+                a, ina = s.get_alpha()
+                assert np.array_equal(a, o.get_alpha()) and np.array_equal(ina, o.get_inactive())
+        assert acts >= 1
+    for s in shards:
+        s.close()
+
+
+def test_live_sweeps_of_a_group_keep_the_counts_consistent():
+    """MVHDP_SWEEP_LIVE across shards (each replica live for its own entities, one sweep stale for the others': AD-LDA): the global
+    counts are exactly the counts of the concatenated assignments, on every replica."""
+    K, V = 40, [500, 60]
+    c = small_corpus(K, V, 160, [50, 6], 93)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(2)]
+    shards = _shards(c, hy, z, 3)
+    for s in shards:
+        s.set_tuning(live16=1)
+    with NativeGroup(shards) as g:
+        g.build_counts()
+        for it in range(3):
+            sts = g.sweep(it, 3, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2))
+            assert sum(st.tokens for st in sts) == c.total_tokens
+            for m in range(2):
+                zc = np.concatenate([s.get_assignments(m) for s in shards])
+                ref = np.zeros((V[m], K), dtype=np.int32); np.add.at(ref, (c.tokens[m], zc), 1)
+                for s in shards:
+                    a, b = s.get_counts(m)
+                    assert a.min() >= 0 and np.array_equal(a, ref) and np.array_equal(b, ref.sum(axis=0))
+    for s in shards:
+        s.close()
+
+
+def test_group_create_errors():
+    K, V = 10, [50]
+    c = small_corpus(K, V, 20, [8], 35)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    a = make_native(c, hy, [o.get_assignments(0)])
+    c2 = small_corpus(12, V, 20, [8], 35)
+    o2 = make_oracle(c2, Hyper.defaults(12, V))
+    b = make_native(c2, Hyper.defaults(12, V), [o2.get_assignments(0)])
+    with pytest.raises(MvhdpError):
+        NativeGroup([a, b])                                                 # different model shapes
+    with pytest.raises(MvhdpError):
+        NativeGroup([a, a])                                                 # a handle listed twice
+    with pytest.raises(MvhdpError):
+        NativeGroup([])
+    a.close(); b.close()
