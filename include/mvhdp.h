@@ -148,6 +148,13 @@ typedef struct {
  * entities ordered by decreasing token count (ties by entity index). */
 #define MVHDP_SWEEP_SEGMENT_APPLY 0x40u
 
+/* Only segment s (0-based) of the MVHDP_SWEEP_LIVE_SEGMENTS(n) interleaved segments is swept: the entities at positions s, s+n,
+ * s+2n, ... of the longest-first order; the statistics cover those entities.  With it a HOST drives a segmented sweep and can put
+ * anything between two segments -- an all-reduce over document shards, a look at the counts (tests/test_gpu_full_size.py checks
+ * every segment of a full-size segmented sweep against the oracle this way).  n calls with s = 0..n-1 of a deferred sweep (each
+ * applying its deltas) give the integers of one MVHDP_SWEEP_SEGMENT_APPLY call with n segments.  Not with LIVE or SEGMENT_APPLY. */
+#define MVHDP_SWEEP_ONLY_SEGMENT(s) ((((uint32_t)(s) + 1u) & 0xffu) << 24)
+
 /* device buffers a host may hand to a collective (RCCL through torch.distributed or directly) */
 typedef enum {
     MVHDP_BUF_COUNTS = 0,  /* int32 [sumV*K + M*K]: n_wk rows of every view, then n_k */

@@ -735,11 +735,12 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         const int64_t need = (n + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
         return (int)std::max<int64_t>(1, std::min<int64_t>(need, g.grid));
     };
-    for (int seg = 0; seg < nseg && e == hipSuccess && mm.D > 0; seg++) {
+    const int seg_lo = p.only_seg >= 0 ? p.only_seg : 0, seg_hi = p.only_seg >= 0 ? p.only_seg + 1 : nseg;
+    for (int seg = seg_lo; seg < seg_hi && e == hipSuccess && mm.D > 0; seg++) {
         // segment seg = positions seg, seg + nseg, ... of the order; a prefix [0, P) of the order holds share(P) of them
         auto share = [&](int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
         const int64_t n_seg = share(mm.D);
-        if (seg > 0) {
+        if (seg > seg_lo) {
             // UPD:263-270 acts as soon as a delta lands on an inactive topic, and the samplers then draw the NEXT inactive
             // index (WRK:523-526): a sweep whose counts are kept current does the same at every segment border -- the
             // segment's first such delta (by entity, view, position) activates its topic before the next segment starts.
@@ -866,7 +867,11 @@ static void learn_from_sweep(mvhdp_ctx* h, const SweepPlan& p, const unsigned lo
     bool any_walk = false;
     for (int c = 0; c < MVHDP_N_CLASSES; c++) any_walk = any_walk || (p.cls[c].used && p.cls[c].walk);
     if (any_walk) h->wt.measured(mm.M, p.nseg, hs + ST_VIEW_BASE);
-    if (mm.D > 0) {
+    if (mm.D > 0 && p.only_seg >= 0) {
+        // a single segment was swept: its histograms describe a part of the entities only -- the earlier ones stay (every plan of
+        // a single-segment sweep launches whatever is reachable), only an abandoned entity asks for a recount
+        if (meta_hist[MVHDP_HIST_BINS + MVHDP_N_CLASSES] != 0) h->nslots_valid = false;
+    } else if (mm.D > 0) {
         std::copy(meta_hist, meta_hist + MVHDP_HIST_BINS, h->last_hist);
         std::copy(meta_hist + MVHDP_HIST_BINS, meta_hist + MVHDP_HIST_BINS + MVHDP_ENT_BINS, h->last_ent);
         h->nslots_valid = h->last_ent[MVHDP_N_CLASSES] == 0;        // an abandoned entity (Q11): its list is recounted before the next sweep

@@ -349,6 +349,9 @@ static int fan_out_range(mvhdp_group_ctx* g, bool counts, int64_t e0, int64_t e1
             const int32_t* src = (counts ? L->mm.counts : L->mm.delta) + e0;
             int32_t* dst = (counts ? h->mm.counts : h->mm.delta) + e0;
             GHIP(g, hipMemcpyAsync(dst, src, (size_t)(e1 - e0) * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+            // the leader's own update of this range zeroes its delta rows: not before this copy has read them
+            GHIP(g, hipEventRecord(g->ev_swept[i], h->stream));
+            GHIP(g, hipStreamWaitEvent(L->stream, g->ev_swept[i], 0));
         }
     }
     return MVHDP_OK;
@@ -373,19 +376,13 @@ extern "C" int mvhdp_group_build_counts(mvhdp_group g)
     return MVHDP_OK;
 }
 
-// One Gibbs sweep of the whole model (see the head of this file).  flags: MVHDP_SWEEP_EXACT_CHAIN, MVHDP_SWEEP_LIVE (+ segments: each
-// replica is live for its own entities and one sweep stale for the others', AD-LDA), MVHDP_SWEEP_GENERIC_KERNEL; NO_APPLY and
-// REUSE_TREES are the group's own business.  stats: one entry per local member, or NULL.  Bit-identical to the sweep of one handle
-// holding all entities (deferred mode): entities are independent under the snapshot and integer sums do not depend on the order.
-extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats)
+// One exchange-terminated step: every member sweeps (all of its entities, or one segment of them) with NO_APPLY, the deltas are
+// summed over the group and applied by every replica.  st: per-member statistics of this step.
+static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, std::vector<mvhdp_sweep_stats>& st)
 {
-    CHECK_G(g);
-    if (flags & (MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_SEGMENT_APPLY))
-        GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: NO_APPLY / REUSE_TREES are set by the group itself; FROZEN and SEGMENT_APPLY are single-handle modes");
     const int n = (int)g->members.size();
     const bool live = (flags & MVHDP_SWEEP_LIVE) != 0;
     std::vector<PendingSweep> ps((size_t)n);
-    std::vector<mvhdp_sweep_stats> st((size_t)n);
     // 1. every member's sweep goes on its device before any is waited for
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = g->members[i];
@@ -455,8 +452,51 @@ extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t see
     }
     float ms = 0;
     hipSetDevice(L0->device);
-    if (hipEventElapsedTime(&ms, g->ev_x0, g->ev_x1) == hipSuccess) g->last_exchange_ms = ms;
-    g->sweeps++;
-    if (stats) for (int i = 0; i < n; i++) stats[i] = st[i];
+    if (hipEventElapsedTime(&ms, g->ev_x0, g->ev_x1) == hipSuccess) g->last_exchange_ms += ms;
     return first_err;
+}
+
+// One Gibbs sweep of the whole model (see the head of this file).  flags: MVHDP_SWEEP_EXACT_CHAIN, MVHDP_SWEEP_GENERIC_KERNEL,
+// MVHDP_SWEEP_LIVE (+ LIVE_SEGMENTS: each replica is live for its own entities and one sweep stale for the others', AD-LDA), or
+// MVHDP_SWEEP_SEGMENT_APPLY (+ LIVE_SEGMENTS(n)): the deterministic segmented sweep ACROSS the shards -- every member sweeps its
+// segment s, the deltas are exchanged and applied, then segment s+1: n exchanges per sweep, a token sees counts at most one segment
+// old on every replica.  NO_APPLY and REUSE_TREES are the group's own business.  stats: one entry per local member, or NULL.
+// Deferred and segmented modes are bit-identical to the same sweep of one handle holding all entities when the segments are cut the
+// same way; a group cuts them per member (each member's own longest-first order), so the segmented sweep of a group is its own
+// deterministic chain, reproducible for a given sharding.
+extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats)
+{
+    CHECK_G(g);
+    if (flags & (MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_FROZEN | 0xff000000u))
+        GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: NO_APPLY, REUSE_TREES and ONLY_SEGMENT are set by the group itself; FROZEN is a single-handle mode");
+    if ((flags & MVHDP_SWEEP_SEGMENT_APPLY) && (flags & MVHDP_SWEEP_LIVE)) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: SEGMENT_APPLY excludes LIVE");
+    const int n = (int)g->members.size();
+    std::vector<mvhdp_sweep_stats> total((size_t)n), st((size_t)n);
+    g->last_exchange_ms = 0.0;
+    int ret = MVHDP_OK;
+    if (flags & MVHDP_SWEEP_SEGMENT_APPLY) {
+        int nseg = (int)((flags >> 16) & 0xffu);
+        if (nseg == 0) nseg = 4;
+        for (int i = 0; i < n; i++) nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, g->members[i]->mm.D));   // (every member must have every segment)
+        const uint32_t base = (flags & ~(MVHDP_SWEEP_SEGMENT_APPLY | MVHDP_SWEEP_LIVE_SEGMENTS(0xff))) | MVHDP_SWEEP_LIVE_SEGMENTS(nseg);
+        for (int s = 0; s < nseg && ret == MVHDP_OK; s++) {
+            ret = group_step(g, sweep_idx, seed, base | MVHDP_SWEEP_ONLY_SEGMENT(s), st);
+            for (int i = 0; i < n; i++) {
+                if (s == 0) { total[i] = st[i]; continue; }
+                total[i].tokens += st[i].tokens; total[i].changed += st[i].changed; total[i].new_mass_cnt += st[i].new_mass_cnt;
+                total[i].topic_doc_mass_cnt += st[i].topic_doc_mass_cnt; total[i].word_ftree_mass_cnt += st[i].word_ftree_mass_cnt;
+                total[i].oov_skipped += st[i].oov_skipped; total[i].aborted_docs += st[i].aborted_docs; total[i].exact_fallbacks += st[i].exact_fallbacks;
+                total[i].sweep_kernel_ms += st[i].sweep_kernel_ms; total[i].total_ms += st[i].total_ms;
+                if (total[i].activated_topic < 0 && st[i].activated_topic >= 0) {
+                    total[i].activated_topic = st[i].activated_topic; total[i].activated_modality = st[i].activated_modality; total[i].activation_key = st[i].activation_key;
+                }
+                total[i].activations += st[i].activations;
+            }
+        }
+    } else {
+        ret = group_step(g, sweep_idx, seed, flags, total);
+    }
+    g->sweeps++;
+    if (stats) for (int i = 0; i < n; i++) stats[i] = total[i];
+    return ret;
 }

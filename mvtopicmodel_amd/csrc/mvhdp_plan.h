@@ -70,6 +70,7 @@ struct SweepPlan {
     uint32_t flags = 0;
     bool live = false, seg_apply = false, frozen = false, debug = false;
     int nseg = 1;
+    int only_seg = -1;                          // >= 0: only this segment is swept (MVHDP_SWEEP_ONLY_SEGMENT)
     int S_cap = 0;
     bool fast = false;                          // register-resident variants in use
     int pc = 0;                                 // class of the primary variant
@@ -293,7 +294,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     uint32_t flags = in.flags;
     if (flags & MVHDP_SWEEP_FROZEN) flags |= MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY;   // nut == 0: the model is read-only
     if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL | MVHDP_SWEEP_FROZEN |
-                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff) | MVHDP_SWEEP_SEGMENT_APPLY)) return fail(MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff) | MVHDP_SWEEP_SEGMENT_APPLY | 0xff000000u)) return fail(MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
     p.flags = flags;
     p.live = (flags & MVHDP_SWEEP_LIVE) != 0;
     p.seg_apply = (flags & MVHDP_SWEEP_SEGMENT_APPLY) != 0;
@@ -308,6 +309,11 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     if (nseg == 0) nseg = (p.live || p.seg_apply) ? 4 : 1;
     if ((int64_t)nseg > in.D) nseg = (int)std::max<int64_t>(1, in.D);
     p.nseg = nseg;
+    p.only_seg = (int)(flags >> 24) - 1;                  // MVHDP_SWEEP_ONLY_SEGMENT(s): -1 = every segment
+    if (p.only_seg >= 0) {
+        if (p.live || p.seg_apply) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT excludes LIVE and SEGMENT_APPLY");
+        if (p.only_seg >= nseg) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT beyond the segment count");
+    }
     const int K = in.K, M = in.M;
     int S_cap = (int)std::min<int64_t>(K, std::max<int64_t>(in.mdt, 1));
     S_cap = (S_cap + 63) / 64 * 64;
@@ -322,7 +328,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // ---- which classes hold entities (this sweep's topic lists), and the primary variant ----
     double tok[MVHDP_N_CLASSES], tot = 0;
     for (int c = 0; c < MVHDP_N_CLASSES; c++) { tok[c] = plan_class_tokens(in.tok_hist, c); tot += tok[c]; }
-    const bool unknown = in.ent_hist[MVHDP_N_CLASSES] != 0 || tot == 0 || in.batch;   // the lists are not all known (or will move): launch whatever is reachable
+    const bool unknown = in.ent_hist[MVHDP_N_CLASSES] != 0 || tot == 0 || in.batch || p.only_seg >= 0;   // the lists are not all known (or will move): launch whatever is reachable
     // widest class any entity can reach: a list is no longer than the entity (tokens) nor than K
     int c_max = 0;
     while (c_max < 5 && S_cap > (64 << c_max)) c_max++;

@@ -25,6 +25,10 @@ SWEEP_SEGMENT_APPLY = 0x40
 def SWEEP_LIVE_SEGMENTS(n):
     return (int(n) & 0xFF) << 16
 
+def SWEEP_ONLY_SEGMENT(s):
+    return ((int(s) + 1) & 0xFF) << 24
+
+
 BUF_COUNTS = 0
 BUF_DELTA = 1
 

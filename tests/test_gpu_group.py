@@ -129,6 +129,53 @@ def test_live_sweeps_of_a_group_keep_the_counts_consistent():
         s.close()
 
 
+def test_segmented_sweep_across_shards_follows_the_oracle():
+    """MVHDP_SWEEP_SEGMENT_APPLY on a group: segment s of EVERY member is swept against the same snapshot, the deltas are exchanged
+    and applied, then segment s+1 (n exchanges per sweep).  The oracle follows it: segment s = the union of the members' segments
+    (each member cuts its own longest-first order), swept with NO_APPLY, applied, activated -- every integer must agree."""
+    from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY
+    from mvtopicmodel_amd.native import SWEEP_SEGMENT_APPLY
+    K, V = 60, [700, 90, 70]
+    c = small_corpus(K, V, 150, [40, 5, 6], 94)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[50, 55, 58]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive); hy.alpha[:, K] = 25.0
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(3)]
+    for m in range(3):
+        z[m][np.isin(z[m], [50, 55, 58])] = 1
+        o.set_assignments(m, z[m])
+    o.build_counts()
+    n, nseg = 3, 4
+    tot = sum(np.diff(c.doc_off[m]) for m in range(c.M))
+    bounds = synth.shard_bounds(tot, n)
+    shards = _shards(c, hy, z, n)
+    seg_docs = [[] for _ in range(nseg)]
+    for lo, hi in bounds:                                                   # each member's own longest-first order, cut into nseg interleaved segments
+        order = lo + np.argsort(-tot[lo:hi], kind="stable")
+        for sidx in range(nseg):
+            seg_docs[sidx].append(order[sidx::nseg])
+    with NativeGroup(shards) as g:
+        g.build_counts()
+        births = 0
+        for it in range(3):
+            acts = 0
+            for sidx in range(nseg):
+                r = o.sweep_list(it, 17, np.sort(np.concatenate(seg_docs[sidx])), flags=ORC_NO_APPLY, want_delta=True)
+                o.apply_delta(r["delta_nwk"], r["delta_nk"], r["stats"]["activated_topic"], r["stats"]["activated_modality"])
+                acts += r["stats"]["activated_topic"] >= 0
+            sts = g.sweep(it, 17, flags=SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(nseg))
+            assert sum(st.tokens for st in sts) == c.total_tokens
+            assert all(st.activations == acts for st in sts)
+            births += acts
+            _assert_group_equals_oracle(o, shards, c)
+            for sh in shards:
+                a, ina = sh.get_alpha()
+                assert np.array_equal(a, o.get_alpha()) and np.array_equal(ina, o.get_inactive())
+        assert births >= 2
+    for sh in shards:
+        sh.close()
+
+
 def test_group_create_errors():
     K, V = 10, [50]
     c = small_corpus(K, V, 20, [8], 35)
