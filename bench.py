@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--live-steps", type=int, default=None,
                     help="sweeps of each secondary update mode timed after the K steps, behind 3 warm-up sweeps of that mode "
                          "(default: 10 on one GPU, 0 on several; 0 = none)")
+    ap.add_argument("--batch", action="store_true",
+                    help="one GPU: the K timed steps as ONE mvhdp_sweep_many call (no host round trip between sweeps): what a host "
+                         "does when nothing needs the counts in between; same integers")
     ap.add_argument("--torch-exchange", action="store_true",
                     help="N>1: the exchange through torch.distributed on host copies (the fallback path) instead of the library's own RCCL group")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -253,9 +256,15 @@ def main():
     kernel_ms = []
     t0 = time.perf_counter()
     last = None
-    for k in range(args.steps):
-        last = step(args.warmup + k, sweep_flags)
-        kernel_ms.append(last.sweep_kernel_ms)
+    if args.batch and world == 1:
+        sts = s.sweep_many(args.warmup, args.steps, args.seed, flags=sweep_flags)
+        kernel_ms = [st.sweep_kernel_ms for st in sts]
+        last = sts[-1]
+        phases.update(step_call_host=(time.perf_counter() - t0) * 1e3, sweep_kernel=sum(kernel_ms), sweep_device_total=sum(st.total_ms for st in sts), n=args.steps)
+    else:
+        for k in range(args.steps):
+            last = step(args.warmup + k, sweep_flags)
+            kernel_ms.append(last.sweep_kernel_ms)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
 
@@ -308,6 +317,7 @@ def main():
         "phase_ms": {k: v / max(1, phases.get("n", 1)) for k, v in phases.items() if k != "n"},
         "exchange": exchange,
         "update_mode": ("live, %d tree rebuilds per sweep" % (args.live_segments or 4)) if args.live else "deferred (snapshot sweep, bit-reproducible)",
+        "step_calls": "one mvhdp_sweep_many call for the K steps" if (args.batch and world == 1) else "one call per step",
         # What a sweep of each update mode is worth, in sweeps of the CPU restatement of the reference's thread topology, from the
         # log-likelihood curves of profiles/r02_ll_curves.md (C3, same corpus / start / hyper-parameters): GPU sweeps needed to
         # reach the log-likelihood the reference reaches in one.  Tokens/s of different modes are comparable only after dividing by it.

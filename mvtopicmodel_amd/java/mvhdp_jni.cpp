@@ -14,6 +14,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "mvhdp.h"
@@ -28,7 +30,27 @@ struct Shard {                       // what the jlong handle points to: the lib
     jlong N[MVHDP_MAX_MODALITIES] = {};
 };
 
-inline Shard* S(jlong p) { return reinterpret_cast<Shard*>(p); }
+// Every Shard (and group) the shim has handed to Java is listed here; a jlong that is not listed -- closed already, e.g. by a
+// finalizer racing an explicit close() -- is refused instead of dereferenced.
+std::mutex g_reg_mutex;
+std::set<void*> g_shards, g_groups;
+
+inline Shard* S(jlong p)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    return g_shards.count(reinterpret_cast<void*>(p)) ? reinterpret_cast<Shard*>(p) : nullptr;
+}
+
+struct Group {                        // an mvhdp_group and how many members it has in this process
+    mvhdp_group g = nullptr;
+    int members = 0;
+};
+
+inline Group* G(jlong p)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    return g_groups.count(reinterpret_cast<void*>(p)) ? reinterpret_cast<Group*>(p) : nullptr;
+}
 
 void throw_msg(JNIEnv* env, const char* cls, const char* msg)
 {
@@ -94,15 +116,23 @@ JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nCreate(JNIEn
     if (rc != MVHDP_OK) { delete s; throw_rt(env, nullptr, rc, "mvhdp_create"); return 0; }
     s->K = K; s->M = M;
     for (int m = 0; m < M; m++) s->V[m] = cfg.num_types[m];
+    { std::lock_guard<std::mutex> lk(g_reg_mutex); g_shards.insert(s); }
     return reinterpret_cast<jlong>(s);
 }
 
 // Safe at any time, including from a finalizer or shutdown hook after the HIP runtime is gone (mvhdp_destroy then
-// releases host memory only) and when called twice (the second call is refused by the library, nothing is dereferenced).
+// releases host memory only) and when called twice: the handle leaves the registry under the lock, a second call finds
+// nothing and touches nothing.
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nDestroy(JNIEnv*, jclass, jlong p)
 {
-    Shard* s = S(p);
-    if (!s) return;
+    Shard* s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        auto it = g_shards.find(reinterpret_cast<void*>(p));
+        if (it == g_shards.end()) return;
+        s = reinterpret_cast<Shard*>(*it);
+        g_shards.erase(it);
+    }
     mvhdp_destroy(s->h);
     delete s;
 }
@@ -110,6 +140,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nDestroy(JNIEn
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetCorpus(JNIEnv* env, jclass, jlong p, jint m, jlongArray docOff, jintArray tokens)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M || !docOff || env->GetArrayLength(docOff) < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "setCorpus: bad view or docOff"); return; }
     const jsize D = env->GetArrayLength(docOff) - 1;
     int rc;
@@ -130,6 +161,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetCorpus(JNI
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetAssignments(JNIEnv* env, jclass, jlong p, jint m, jintArray z)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "setAssignments: bad view"); return; }
     if (s->N[m] > 0 && bad_len(env, z, s->N[m], "setAssignments")) return;
     int rc;
@@ -141,6 +173,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetAssignment
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAssignments(JNIEnv* env, jclass, jlong p, jint m, jintArray z)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "getAssignments: bad view"); return; }
     if (s->N[m] == 0) return;
     if (bad_len(env, z, s->N[m], "getAssignments")) return;
@@ -153,6 +186,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetHyper(JNIE
         jdoubleArray beta, jdoubleArray betaSum, jdoubleArray gamma, jobjectArray p_a, jobjectArray p_b, jbooleanArray inactive)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     const jsize M = s->M, K1 = s->K + 1;
     if (bad_len(env, alpha, M, "setHyper alpha") || bad_len(env, p_a, M, "setHyper p_a") || bad_len(env, p_b, M, "setHyper p_b") ||
         bad_len(env, alphaSum, M, "setHyper alphaSum") || bad_len(env, beta, M, "setHyper beta") ||
@@ -187,14 +221,17 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetHyper(JNIE
 }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildCounts(JNIEnv* env, jclass, jlong p)
-{ int rc = mvhdp_build_counts(S(p)->h); if (rc) throw_rt(env, S(p)->h, rc, "mvhdp_build_counts"); }
+{ Shard* s = S(p); if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+  int rc = mvhdp_build_counts(s->h); if (rc) throw_rt(env, s->h, rc, "mvhdp_build_counts"); }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildTrees(JNIEnv* env, jclass, jlong p)
-{ int rc = mvhdp_build_trees(S(p)->h); if (rc) throw_rt(env, S(p)->h, rc, "mvhdp_build_trees"); }
+{ Shard* s = S(p); if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+  int rc = mvhdp_build_trees(s->h); if (rc) throw_rt(env, s->h, rc, "mvhdp_build_trees"); }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetCounts(JNIEnv* env, jclass, jlong p, jint m, jintArray nwk, jintArray nk)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "getCounts: bad view"); return; }
     if ((nwk && bad_len(env, nwk, (jlong)s->V[m] * s->K, "getCounts typeTopicCounts")) || (nk && bad_len(env, nk, s->K, "getCounts tokensPerTopic"))) return;
     int rc;
@@ -206,6 +243,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetCounts(JNI
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetDocTopicHist(JNIEnv* env, jclass, jlong p, jint m, jintArray hist, jint histLen, jintArray lens)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M || histLen < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "getDocTopicHist: bad view or length"); return; }
     if (hist && bad_len(env, hist, (jlong)s->K * histLen, "getDocTopicHist hist")) return;
     int rc;
@@ -217,6 +255,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetDocTopicHi
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAlpha(JNIEnv* env, jclass, jlong p, jdoubleArray alphaFlat, jbooleanArray inactive)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (bad_len(env, alphaFlat, (jlong)s->M * (s->K + 1), "getAlpha alpha") || bad_len(env, inactive, s->K, "getAlpha inactive")) return;
     std::vector<double> a(static_cast<size_t>(s->M) * (s->K + 1));
     std::vector<uint8_t> ina(static_cast<size_t>(s->K));
@@ -229,6 +268,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAlpha(JNIE
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv* env, jclass, jlong p, jint sweepIdx, jlong seed, jint flags, jdoubleArray pOverride, jobject out)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (pOverride && bad_len(env, pOverride, s->D * s->M * s->M, "sweep pOverride [D][M][M]")) return;
     mvhdp_sweep_stats st;
     int rc;
@@ -253,16 +293,174 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv*
 }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nApplyDelta(JNIEnv* env, jclass, jlong p, jint topic, jint modality)
-{ int rc = mvhdp_apply_delta(S(p)->h, topic, modality); if (rc) throw_rt(env, S(p)->h, rc, "mvhdp_apply_delta"); }
+{ Shard* s = S(p); if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+  int rc = mvhdp_apply_delta(s->h, topic, modality); if (rc) throw_rt(env, s->h, rc, "mvhdp_apply_delta"); }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nModelLogLikelihood(JNIEnv* env, jclass, jlong p, jdoubleArray out)
 {
     Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (bad_len(env, out, s->M, "modelLogLikelihood")) return;
     double ll[MVHDP_MAX_MODALITIES];
     int rc = mvhdp_model_log_likelihood(s->h, ll);
     if (rc) { throw_rt(env, s->h, rc, "mvhdp_model_log_likelihood"); return; }
     env->SetDoubleArrayRegion(out, 0, s->M, ll);
+}
+
+// statistics of n sweeps as a flat long array, 8 per sweep: tokens, changed, newMassCnt, topicDocMassCnt, wordFTreeMassCnt,
+// oovSkipped, abortedDocs, exactFallbacks
+static void stats_to_longs(const mvhdp_sweep_stats& st, jlong* o)
+{
+    o[0] = st.tokens; o[1] = st.changed; o[2] = st.new_mass_cnt; o[3] = st.topic_doc_mass_cnt;
+    o[4] = st.word_ftree_mass_cnt; o[5] = st.oov_skipped; o[6] = st.aborted_docs; o[7] = st.exact_fallbacks;
+}
+
+// the iteration loop PTM:1146-1239 without a host round trip per iteration (mvhdp_sweep_many)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweepMany(JNIEnv* env, jclass, jlong p, jint firstIdx, jint n, jlong seed, jint flags, jlongArray statsFlat)
+{
+    Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (n < 0 || (statsFlat && bad_len(env, statsFlat, (jlong)n * 8, "sweepMany stats [n][8]"))) return;
+    std::vector<mvhdp_sweep_stats> st(static_cast<size_t>(n > 0 ? n : 1));
+    int rc = mvhdp_sweep_many(s->h, static_cast<uint32_t>(firstIdx), n, static_cast<uint64_t>(seed), static_cast<uint32_t>(flags), st.data());
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_sweep_many"); return; }
+    if (statsFlat) {
+        std::vector<jlong> flat(static_cast<size_t>(n) * 8);
+        for (int i = 0; i < n; i++) stats_to_longs(st[i], flat.data() + (size_t)i * 8);
+        env->SetLongArrayRegion(statsFlat, 0, (jsize)flat.size(), flat.data());
+    }
+}
+
+// tuning block (mvhdp_tuning): ints = {forcePrimary, narrow, walkFixed, singleStream, live16, learntStep0, learntStep1, learntStep2},
+// doubles = {primaryMinShare, walkTheta[8], treeBranchShare[8]}
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetTuning(JNIEnv* env, jclass, jlong p, jintArray ints, jdoubleArray doubles)
+{
+    Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (bad_len(env, ints, 8, "getTuning ints") || bad_len(env, doubles, 17, "getTuning doubles")) return;
+    mvhdp_tuning t;
+    int rc = mvhdp_get_tuning(s->h, &t);
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_get_tuning"); return; }
+    const jint iv[8] = {t.force_primary, t.narrow, t.walk_fixed, t.single_stream, t.live16, t.learnt_walk_step[0], t.learnt_walk_step[1], t.learnt_walk_step[2]};
+    jdouble dv[17];
+    dv[0] = t.primary_min_share;
+    for (int m = 0; m < 8; m++) { dv[1 + m] = t.walk_theta[m]; dv[9 + m] = t.tree_branch_share[m]; }
+    env->SetIntArrayRegion(ints, 0, 8, iv);
+    env->SetDoubleArrayRegion(doubles, 0, 17, dv);
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetTuning(JNIEnv* env, jclass, jlong p, jintArray ints, jdoubleArray doubles)
+{
+    Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (bad_len(env, ints, 8, "setTuning ints") || bad_len(env, doubles, 17, "setTuning doubles")) return;
+    jint iv[8]; jdouble dv[17];
+    env->GetIntArrayRegion(ints, 0, 8, iv);
+    env->GetDoubleArrayRegion(doubles, 0, 17, dv);
+    mvhdp_tuning t;
+    std::memset(&t, 0, sizeof t);
+    t.force_primary = iv[0]; t.narrow = iv[1]; t.walk_fixed = iv[2]; t.single_stream = iv[3]; t.live16 = iv[4];
+    t.learnt_walk_step[0] = iv[5]; t.learnt_walk_step[1] = iv[6]; t.learnt_walk_step[2] = iv[7]; t.learnt_walk_step[3] = -1;
+    t.primary_min_share = dv[0];
+    for (int m = 0; m < 8; m++) { t.walk_theta[m] = dv[1 + m]; t.tree_branch_share[m] = dv[9 + m]; }
+    int rc = mvhdp_set_tuning(s->h, &t);
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_set_tuning");
+}
+
+// ---- document shards on several GPUs: mvhdp_group_* (the reference's queue mesh + barrier, PTM:1042-1049, PTM:1232) ----
+static void throw_group(JNIEnv* env, mvhdp_group g, int rc, const char* what)
+{
+    char msg[640];
+    snprintf(msg, sizeof msg, "%s failed (%d): %s", what, rc, mvhdp_group_last_error(g));
+    throw_msg(env, "java/lang/RuntimeException", msg);
+}
+
+// one JVM drives all its GPUs: one NativeSampler per device
+JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupCreate(JNIEnv* env, jclass, jlongArray handles)
+{
+    const jsize n = handles ? env->GetArrayLength(handles) : 0;
+    if (n < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "groupCreate: no members"); return 0; }
+    std::vector<jlong> hp(static_cast<size_t>(n));
+    env->GetLongArrayRegion(handles, 0, n, hp.data());
+    std::vector<mvhdp_handle> hs;
+    for (jsize i = 0; i < n; i++) {
+        Shard* s = S(hp[i]);
+        if (!s) { throw_msg(env, "java/lang/IllegalStateException", "groupCreate: a member is closed"); return 0; }
+        hs.push_back(s->h);
+    }
+    Group* gr = new Group();
+    int rc = mvhdp_group_create(n, hs.data(), &gr->g);
+    if (rc != MVHDP_OK) { delete gr; throw_group(env, nullptr, rc, "mvhdp_group_create"); return 0; }
+    gr->members = n;
+    { std::lock_guard<std::mutex> lk(g_reg_mutex); g_groups.insert(gr); }
+    return reinterpret_cast<jlong>(gr);
+}
+
+// one JVM per GPU: rank 0 makes the 128-byte id, the launcher hands it to the other ranks
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupUniqueId(JNIEnv* env, jclass, jbyteArray id)
+{
+    if (bad_len(env, id, MVHDP_UNIQUE_ID_BYTES, "groupUniqueId")) return;
+    uint8_t buf[MVHDP_UNIQUE_ID_BYTES];
+    int rc = mvhdp_group_unique_id(buf);
+    if (rc) { throw_group(env, nullptr, rc, "mvhdp_group_unique_id"); return; }
+    env->SetByteArrayRegion(id, 0, MVHDP_UNIQUE_ID_BYTES, reinterpret_cast<const jbyte*>(buf));
+}
+
+JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupCreateRank(JNIEnv* env, jclass, jlong p, jbyteArray id, jint rank, jint nranks)
+{
+    Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return 0; }
+    if (bad_len(env, id, MVHDP_UNIQUE_ID_BYTES, "groupCreateRank id")) return 0;
+    uint8_t buf[MVHDP_UNIQUE_ID_BYTES];
+    env->GetByteArrayRegion(id, 0, MVHDP_UNIQUE_ID_BYTES, reinterpret_cast<jbyte*>(buf));
+    Group* gr = new Group();
+    int rc = mvhdp_group_create_rank(s->h, buf, rank, nranks, &gr->g);
+    if (rc != MVHDP_OK) { delete gr; throw_group(env, nullptr, rc, "mvhdp_group_create_rank"); return 0; }
+    gr->members = 1;
+    { std::lock_guard<std::mutex> lk(g_reg_mutex); g_groups.insert(gr); }
+    return reinterpret_cast<jlong>(gr);
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupDestroy(JNIEnv*, jclass, jlong p)
+{
+    Group* gr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        auto it = g_groups.find(reinterpret_cast<void*>(p));
+        if (it == g_groups.end()) return;
+        gr = reinterpret_cast<Group*>(*it);
+        g_groups.erase(it);
+    }
+    mvhdp_group_destroy(gr->g);
+    delete gr;
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupBuildCounts(JNIEnv* env, jclass, jlong p)
+{
+    Group* gr = G(p);
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    int rc = mvhdp_group_build_counts(gr->g);
+    if (rc) throw_group(env, gr->g, rc, "mvhdp_group_build_counts");
+}
+
+// statsFlat: [members][8] as nSweepMany; act: {activatedTopic, activatedModality, activations} of the sweep (the same on every replica);
+// returns the device milliseconds of the exchange (collectives + updates + tree rebuilds)
+JNIEXPORT jdouble JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupSweep(JNIEnv* env, jclass, jlong p, jint sweepIdx, jlong seed, jint flags, jlongArray statsFlat, jintArray act)
+{
+    Group* gr = G(p);
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return 0.0; }
+    if ((statsFlat && bad_len(env, statsFlat, (jlong)gr->members * 8, "groupSweep stats [members][8]")) || (act && bad_len(env, act, 3, "groupSweep act"))) return 0.0;
+    std::vector<mvhdp_sweep_stats> st(static_cast<size_t>(gr->members));
+    int rc = mvhdp_group_sweep(gr->g, static_cast<uint32_t>(sweepIdx), static_cast<uint64_t>(seed), static_cast<uint32_t>(flags), st.data());
+    if (rc) { throw_group(env, gr->g, rc, "mvhdp_group_sweep"); return 0.0; }
+    if (statsFlat) {
+        std::vector<jlong> flat(static_cast<size_t>(gr->members) * 8);
+        for (int i = 0; i < gr->members; i++) stats_to_longs(st[i], flat.data() + (size_t)i * 8);
+        env->SetLongArrayRegion(statsFlat, 0, (jsize)flat.size(), flat.data());
+    }
+    if (act) { const jint a[3] = {st[0].activated_topic, st[0].activated_modality, st[0].activations}; env->SetIntArrayRegion(act, 0, 3, a); }
+    mvhdp_group_info info;
+    return mvhdp_group_get_info(gr->g, &info) == MVHDP_OK ? info.last_exchange_ms : 0.0;
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@ public final class NativeSampler implements AutoCloseable {
     public static final int SWEEP_LIVE = 0x20;         // the updater threads' own discipline: atomics on the shared counts
     public static final int SWEEP_SEGMENT_APPLY = 0x40; // deterministic: segments sampled one after the other, deltas applied in between
     public static int sweepLiveSegments(int n) { return (n & 0xff) << 16; }
+    public static int sweepOnlySegment(int s) { return ((s + 1) & 0xff) << 24; }   // only segment s of the n segments
 
     /** What one sweep reports: the three branch counters of the worker plus bookkeeping. */
     public static final class SweepStats {
@@ -66,10 +67,110 @@ public final class NativeSampler implements AutoCloseable {
     public void applyDelta(int activatedTopic, int activatedModality) { nApplyDelta(handle, activatedTopic, activatedModality); }
     public double[] modelLogLikelihood(int numModalities) { double[] ll = new double[numModalities]; nModelLogLikelihood(handle, ll); return ll; }
 
-    /** Safe from a finalizer or a shutdown hook: after the HIP runtime has gone the library frees host memory only. */
+    /**
+     * n sweeps (indices firstIdx .. firstIdx+n-1) enqueued back to back, one synchronisation at the end: the iteration loop
+     * of estimate() (lines 1146-1239) without a host round trip per iteration.  Same integers as n calls of sweep().
+     */
+    public SweepStats[] sweepMany(int firstIdx, int n, long seed, int flags) {
+        long[] flat = new long[n * 8];
+        nSweepMany(handle, firstIdx, n, seed, flags, flat);
+        SweepStats[] out = new SweepStats[n];
+        for (int i = 0; i < n; i++) out[i] = statsFromFlat(flat, i);
+        return out;
+    }
+
+    static SweepStats statsFromFlat(long[] flat, int i) {
+        SweepStats st = new SweepStats();
+        st.tokens = flat[8 * i]; st.changed = flat[8 * i + 1]; st.newMassCnt = flat[8 * i + 2]; st.topicDocMassCnt = flat[8 * i + 3];
+        st.wordFTreeMassCnt = flat[8 * i + 4]; st.oovSkipped = flat[8 * i + 5]; st.abortedDocs = flat[8 * i + 6]; st.exactFallbacks = flat[8 * i + 7];
+        return st;
+    }
+
+    /**
+     * The sweep's own choices (mvhdp_tuning): none of them changes a result.  learntWalkStep / treeBranchShare are what the
+     * library's walk-threshold search has found -- read them from one sampler and hand them to another (a document shard, a
+     * resumed chain) and it does not search again.
+     */
+    public static final class Tuning {
+        public int forcePrimary, narrow = -1, walkFixed, singleStream, live16 = -1;
+        public int[] learntWalkStep = {-1, -1, -1};
+        public double primaryMinShare;
+        public double[] walkTheta = new double[8], treeBranchShare = new double[8];
+    }
+
+    public Tuning getTuning() {
+        int[] iv = new int[8]; double[] dv = new double[17];
+        nGetTuning(handle, iv, dv);
+        Tuning t = new Tuning();
+        t.forcePrimary = iv[0]; t.narrow = iv[1]; t.walkFixed = iv[2]; t.singleStream = iv[3]; t.live16 = iv[4];
+        t.learntWalkStep = new int[] {iv[5], iv[6], iv[7]};
+        t.primaryMinShare = dv[0];
+        System.arraycopy(dv, 1, t.walkTheta, 0, 8); System.arraycopy(dv, 9, t.treeBranchShare, 0, 8);
+        return t;
+    }
+
+    public void setTuning(Tuning t) {
+        int[] iv = {t.forcePrimary, t.narrow, t.walkFixed, t.singleStream, t.live16, t.learntWalkStep[0], t.learntWalkStep[1], t.learntWalkStep[2]};
+        double[] dv = new double[17];
+        dv[0] = t.primaryMinShare;
+        System.arraycopy(t.walkTheta, 0, dv, 1, 8); System.arraycopy(t.treeBranchShare, 0, dv, 9, 8);
+        nSetTuning(handle, iv, dv);
+    }
+
+    /**
+     * Document shards on several GPUs with the exchange step inside the library (mvhdp_group_*): what the queue mesh between
+     * sampler and updater threads and the CyclicBarrier do inside the reference's one JVM (lines 1042-1049, 1232).  Every member
+     * holds a contiguous range of entities (docIdBase = global index of its first entity) and a full replica of the model.
+     */
+    public static final class Group implements AutoCloseable {
+        private long g;
+        private final int members;
+
+        /** One JVM drives all its GPUs: one NativeSampler per device. */
+        public Group(NativeSampler[] samplers) {
+            long[] hs = new long[samplers.length];
+            for (int i = 0; i < hs.length; i++) hs[i] = samplers[i].handle;
+            g = nGroupCreate(hs);
+            members = hs.length;
+        }
+
+        private Group(long g) { this.g = g; this.members = 1; }
+
+        /** One JVM per GPU: rank 0 calls uniqueId(), the launcher hands the 128 bytes to every rank, every rank calls this. */
+        public static Group ofRank(NativeSampler sampler, byte[] id, int rank, int nranks) {
+            return new Group(nGroupCreateRank(sampler.handle, id, rank, nranks));
+        }
+
+        public static byte[] uniqueId() { byte[] id = new byte[128]; nGroupUniqueId(id); return id; }
+
+        /** buildInitialTypeTopicCounts (lines 600-652) over all shards. */
+        public void buildCounts() { nGroupBuildCounts(g); }
+
+        /** One sweep of the whole model; flags: SWEEP_LIVE / SWEEP_SEGMENT_APPLY (+ sweepLiveSegments), SWEEP_EXACT_CHAIN. */
+        public SweepStats[] sweep(int sweepIdx, long seed, int flags) {
+            long[] flat = new long[members * 8];
+            int[] act = new int[3];
+            double exchangeMs = nGroupSweep(g, sweepIdx, seed, flags, flat, act);
+            SweepStats[] out = new SweepStats[members];
+            for (int i = 0; i < members; i++) {
+                out[i] = statsFromFlat(flat, i);
+                out[i].activatedTopic = act[0]; out[i].activatedModality = act[1]; out[i].activations = act[2];
+                out[i].totalMs = exchangeMs;
+            }
+            return out;
+        }
+
+        @Override
+        public void close() { if (g != 0) { nGroupDestroy(g); g = 0; } }
+    }
+
+    /**
+     * Safe from a finalizer or a shutdown hook (after the HIP runtime has gone the library frees host memory only) and when it
+     * races a second close: the native side drops the handle from its registry under a lock and ignores a handle it does not know.
+     */
     @Override
-    public void close() {
-        if (handle != 0) { nDestroy(handle); handle = 0; }
+    public synchronized void close() {
+        if (handle != 0) { long h = handle; handle = 0; nDestroy(h); }
     }
 
     private static native long nCreate(int numTopics, int[] numTypes, int device, long docIdBase);
@@ -87,4 +188,13 @@ public final class NativeSampler implements AutoCloseable {
     private static native void nSweep(long h, int sweepIdx, long seed, int flags, double[] pOverride, SweepStats out);
     private static native void nApplyDelta(long h, int topic, int modality);
     private static native void nModelLogLikelihood(long h, double[] out);
+    private static native void nSweepMany(long h, int firstIdx, int n, long seed, int flags, long[] statsFlat);
+    private static native void nGetTuning(long h, int[] ints, double[] doubles);
+    private static native void nSetTuning(long h, int[] ints, double[] doubles);
+    private static native long nGroupCreate(long[] handles);
+    private static native void nGroupUniqueId(byte[] id);
+    private static native long nGroupCreateRank(long h, byte[] id, int rank, int nranks);
+    private static native void nGroupDestroy(long g);
+    private static native void nGroupBuildCounts(long g);
+    private static native double nGroupSweep(long g, int sweepIdx, long seed, int flags, long[] statsFlat, int[] act);
 }

@@ -8,12 +8,13 @@
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
-typedef int32_t jint; typedef int64_t jlong; typedef double jdouble; typedef uint8_t jboolean; typedef jint jsize;
+typedef int32_t jint; typedef int64_t jlong; typedef double jdouble; typedef uint8_t jboolean; typedef int8_t jbyte; typedef jint jsize;
 class _jobject {}; class _jclass : public _jobject {}; class _jarray : public _jobject {};
 class _jintArray : public _jarray {}; class _jlongArray : public _jarray {}; class _jdoubleArray : public _jarray {};
-class _jbooleanArray : public _jarray {}; class _jobjectArray : public _jarray {};
+class _jbooleanArray : public _jarray {}; class _jobjectArray : public _jarray {}; class _jbyteArray : public _jarray {};
 typedef _jobject* jobject; typedef _jclass* jclass; typedef _jarray* jarray; typedef _jintArray* jintArray;
 typedef _jlongArray* jlongArray; typedef _jdoubleArray* jdoubleArray; typedef _jbooleanArray* jbooleanArray; typedef _jobjectArray* jobjectArray;
+typedef _jbyteArray* jbyteArray;
 struct _jfieldID; typedef _jfieldID* jfieldID;
 struct JNIEnv {
     jclass FindClass(const char*); jint ThrowNew(jclass, const char*); jsize GetArrayLength(jarray);
@@ -26,5 +27,8 @@ struct JNIEnv {
     void GetIntArrayRegion(jintArray, jsize, jsize, jint*); void GetDoubleArrayRegion(jdoubleArray, jsize, jsize, jdouble*);
     void GetBooleanArrayRegion(jbooleanArray, jsize, jsize, jboolean*);
     void SetDoubleArrayRegion(jdoubleArray, jsize, jsize, const jdouble*); void SetBooleanArrayRegion(jbooleanArray, jsize, jsize, const jboolean*);
+    void GetLongArrayRegion(jlongArray, jsize, jsize, jlong*); void SetLongArrayRegion(jlongArray, jsize, jsize, const jlong*);
+    void SetIntArrayRegion(jintArray, jsize, jsize, const jint*);
+    void GetByteArrayRegion(jbyteArray, jsize, jsize, jbyte*); void SetByteArrayRegion(jbyteArray, jsize, jsize, const jbyte*);
 };
 #endif

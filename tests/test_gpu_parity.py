@@ -422,3 +422,58 @@ def test_no_entities_and_a_view_without_tokens():
     for it in range(2):
         o.sweep(it, 2); s.sweep(it, 2); assert_same_state(o, s, 2)
     s.close()
+
+
+@pytest.mark.parametrize("flags_name", ["deferred", "live", "segmented", "frozen"])
+def test_sweep_many_equals_single_sweeps(flags_name):
+    """mvhdp_sweep_many: n sweeps enqueued back to back under ONE plan, no host round trip in between -- the integers of n single
+    calls (and so the oracle's), statistics per sweep included.  With inactive topics it falls back to single calls (the activation
+    needs the host): same results again."""
+    from mvtopicmodel_amd.native import SWEEP_FROZEN, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
+    from tests.test_gpu_segmented import oracle_segmented_sweep
+    K, V = 90, [900, 120, 100]
+    c = small_corpus(K, V, 260, [70, 6, 8], 71)
+    for inactive in (None, np.eye(1, K, 83, dtype=np.uint8)[0]):
+        hy = Hyper.defaults(K, V, inactive=inactive)
+        if inactive is not None:
+            hy.alpha[:, K] = 20.0
+        o = make_oracle(c, hy)
+        z0 = [o.get_assignments(m) for m in range(3)]
+        for m in range(3):
+            z0[m][z0[m] == 83] = 1
+            o.set_assignments(m, z0[m])
+        o.build_counts()
+        s = make_native(c, hy, z0)
+        n = 6
+        if flags_name == "deferred":
+            sts = s.sweep_many(3, n, 99)
+            for i in range(n):
+                ro = o.sweep(3 + i, 99)
+                assert (sts[i].tokens, sts[i].changed, sts[i].word_ftree_mass_cnt) == (ro["stats"]["tokens"], ro["stats"]["changed"], ro["stats"]["word_ftree_mass_cnt"])
+                if inactive is not None:
+                    assert sts[i].activated_topic == ro["stats"]["activated_topic"]
+            assert_same_state(o, s, 3)
+        elif flags_name == "segmented":
+            sts = s.sweep_many(3, n, 99, flags=SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(3))
+            for i in range(n):
+                so, _ = oracle_segmented_sweep(o, c, 3 + i, 99, 3)
+                assert (sts[i].tokens, sts[i].changed) == (so["tokens"], so["changed"])
+            assert_same_state(o, s, 3)
+        elif flags_name == "frozen":
+            s.build_trees(); o.build_trees()
+            before = [s.get_counts(m) for m in range(3)]
+            from oracle.binding import SWEEP_FROZEN as ORC_FROZEN
+            sts = s.sweep_many(3, n, 99, flags=SWEEP_FROZEN)
+            for i in range(n):
+                o.sweep(3 + i, 99, flags=ORC_FROZEN)
+            for m in range(3):
+                assert np.array_equal(o.get_assignments(m), s.get_assignments(m))
+                assert np.array_equal(before[m][0], s.get_counts(m)[0])           # the model is untouched
+        else:
+            sts = s.sweep_many(3, n, 99, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2))
+            assert all(st.tokens == c.total_tokens for st in sts)
+            for m in range(3):
+                z = s.get_assignments(m); nwk, nk = s.get_counts(m)
+                ref = np.zeros_like(nwk); np.add.at(ref, (c.tokens[m], z), 1)
+                assert nwk.min() >= 0 and np.array_equal(ref, nwk) and np.array_equal(ref.sum(axis=0), nk)
+        s.close()
