@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "../../../include/mvhdp.h"
+#include "../include/mvhdp.h"
 #include "java_random.h"
 #include "knowceans_samplers.h"
 

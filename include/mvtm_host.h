@@ -1,6 +1,6 @@
 /*
  * mvtm_host.h — extern "C" hooks around the C++ host-side mirror of
- * FastQMVWVParallelTopicModel (mvtopicmodel_amd/csrc/host/).  These exist so
+ * FastQMVWVParallelTopicModel (hostmirror/).  These exist so
  * that a harness without a C++ compiler (the Python tests, bench.py) can drive
  * the host class the way a MALLET client drives the reference:
  *   new FastQMVWVParallelTopicModel(K, M, alpha, beta)   PTM:183
@@ -9,7 +9,7 @@
  *   estimate()                                            PTM:1033
  * Entity names (Instance.getName(), PTM:437) cross as int64 ids.
  * The drop-in boundary itself is include/mvhdp.h (libmvhdp.so: kernels + C ABI only).  This host mirror is a
- * SEPARATE library, libmvtm_host.so, built from mvtopicmodel_amd/csrc/host/ and linked against libmvhdp.so: it
+ * SEPARATE library, libmvtm_host.so, built from hostmirror/ and linked against libmvhdp.so: it
  * stands in for the Java host that cannot be compiled here, it is not part of the product library.
  */
 #ifndef MVTM_HOST_H

@@ -1,5 +1,5 @@
 """ctypes view of the C++ host mirror of FastQMVWVParallelTopicModel / FastQMVWVTopicInferencer
-(csrc/host/, hooks declared in include/mvtm_host.h).  The mirror is its own library, lib/libmvtm_host.so: it stands in
+(hostmirror/, hooks declared in include/mvtm_host.h).  The mirror is its own library, hostmirror/lib/libmvtm_host.so: it stands in
 for the Java host classes that cannot be compiled in this image and calls the product (libmvhdp.so) through the C ABI."""
 import atexit
 import ctypes as C
@@ -24,7 +24,7 @@ HOST_SYMBOLS = [
     "mvtm_inferencer_doc_topics", "mvtm_inferencer_print_document_topics", "mvtm_inferencer_get_stats",
 ]
 
-HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvtm_host.so")
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hostmirror", "lib", "libmvtm_host.so")
 _host = None
 
 _ready = False
@@ -45,7 +45,7 @@ def _lib():
     if _host is None:
         load_library()                       # the product library first: fails loudly when it has not been built
         if not os.path.exists(HOST_LIB_PATH):
-            raise ImportError(f"{HOST_LIB_PATH} is missing: build it with `make -C mvtopicmodel_amd/csrc`")
+            raise ImportError(f"{HOST_LIB_PATH} is missing: build it with `make -C hostmirror`")
         _host = C.CDLL(HOST_LIB_PATH)
     L = _host
     if not _ready:

@@ -1,5 +1,5 @@
 """Host-side samplers of optimizeDP (PTM:2440-2591) and optimizeGamma (PTM:2369-2438): the C++ host
-mirror's restatement (csrc/host/knowceans_samplers.h, java_random.h) against the pure-Python oracle
+mirror's restatement (hostmirror/knowceans_samplers.h, java_random.h) against the pure-Python oracle
 (oracle/dp_samplers.py), plus anchors that do not depend on either: numpy's MT19937 for the Cokus
 stream, exact Antoniak probabilities, and Gamma/Beta moments."""
 import math

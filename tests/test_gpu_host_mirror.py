@@ -1,9 +1,10 @@
-"""The C++ host-side mirror of FastQMVWVParallelTopicModel (csrc/host/), driven the way a MALLET
+"""The C++ host-side mirror of FastQMVWVParallelTopicModel (hostmirror/), driven the way a MALLET
 client drives the reference: new ...(K, M, alpha, beta); set*; addInstances(InstanceList[]); estimate()."""
 import numpy as np
 import pytest
 
 from mvtopicmodel_amd.native import Hyper
+from tests.helpers import small_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -261,6 +262,51 @@ def test_print_state_format(tmp_path):
     assert java_double_to_string(1e-4) == "1.0E-4" and java_double_to_string(0.001) == "0.001"
     assert java_double_to_string(1e7) == "1.0E7" and java_double_to_string(9999999.0) == "9999999.0"
     model.close()
+
+
+def test_print_state_round_trip(tmp_path):
+    """write -> read -> the same model without a JVM.  The state a chain wrote (host mirror printState, gzip) is read
+    back by mvtopicmodel_amd.state_io (the reference's commented-out initializeFromState, PTM:534-573): identical assignments,
+    the header's gamma*alpha, and -- pushed through the C ABI into a fresh handle -- identical counts and the same next sweep."""
+    from mvtopicmodel_amd import NativeSampler
+    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from mvtopicmodel_amd.state_io import read_state
+    K, V, D = 12, [80, 20, 15], 40
+    c = small_corpus(K, V, D, [18, 3, 4], 77)
+    views = []
+    for m in range(3):
+        off = c.doc_off[m].copy()
+        if m > 0:                                                           # printState needs every view present (PTM:3291): give empty views one token
+            lens = np.maximum(np.diff(off), 1)
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        rng = np.random.RandomState(70 + m)
+        tok = rng.randint(0, V[m], off[-1]).astype(np.int32)
+        views.append((np.arange(D, dtype=np.int64), off, tok, V[m]))
+    model = FastQMVWVParallelTopicModel(K, 3, 0.1, 0.01)
+    model.setNumIterations(6); model.setRandomSeed(5)
+    model.addInstances(views)
+    model.estimate()
+    path = tmp_path / "state.gz"
+    model.printState(path)
+    st = read_state(path, [v[1] for v in views], [v[2] for v in views])
+    for m in range(3):
+        assert np.array_equal(st["z"][m], model.get_view(m)[3])
+    assert st["beta0"] == 0.01 and st["gamma_alpha"].shape == (3, K)
+    # a fresh handle from the file alone
+    s = NativeSampler(K, V)
+    for m in range(3):
+        s.set_corpus(m, views[m][1], views[m][2]); s.set_assignments(m, st["z"][m])
+    hy = Hyper.defaults(K, V)
+    s.set_hyper(hy); s.build_counts()
+    for m in range(3):
+        nwk, nk = s.get_counts(m)
+        ref = np.zeros((V[m], K), dtype=np.int32); np.add.at(ref, (views[m][2], st["z"][m]), 1)
+        assert np.array_equal(nwk, ref) and np.array_equal(nk, ref.sum(axis=0))
+    # a corpus that does not match is refused, like the reference's reader (PTM:557-559)
+    bad = [v[2].copy() for v in views]; bad[0][5] = (bad[0][5] + 1) % V[0]
+    with pytest.raises(ValueError):
+        read_state(path, [v[1] for v in views], bad)
+    s.close(); model.close()
 
 
 def test_number_format_and_display_top_words():

@@ -33,17 +33,22 @@ def main():
         s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z0[m])
     s.set_hyper(Hyper.defaults(c.K, c.V, inactive=inactive)); s.build_counts()
     it = 0
-    os.environ["MVHDP_WALK_THETA"] = "0"
+
+    def fix(theta):                                  # thresholds through the tuning block (the library reads the environment once, at create)
+        if theta == "auto":
+            s.set_tuning(walk_fixed=0)
+        else:
+            th = [float(x) for x in theta.split(",")] if "," in theta else [float(theta)] + [0.0] * (c.M - 1)
+            s.set_tuning(walk_fixed=1, walk_theta=th)
+
+    fix("0")
     for _ in range(a.burn):
         s.sweep(it, 1); it += 1
     times = {t: [] for t in a.thetas}
     for r in range(a.rounds):
         order = a.thetas if r % 2 == 0 else a.thetas[::-1]           # forwards and backwards: the chain's drift cancels
         for t in order:
-            if t == "auto":
-                os.environ.pop("MVHDP_WALK_THETA", None)
-            else:
-                os.environ["MVHDP_WALK_THETA"] = t if "," in t else ",".join([t] + ["0"] * (c.M - 1))
+            fix(t)
             st = s.sweep(it, 1); it += 1
             times[t].append(st.sweep_kernel_ms)
     base = sum(times[a.thetas[0]]) / len(times[a.thetas[0]])
