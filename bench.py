@@ -274,21 +274,22 @@ def main():
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     bpt = algorithmic_bytes_per_token(K)
     achieved = local_tokens * bpt / avg_kernel_s / 1e9
-    # HBM-side traffic of the same kernels from the committed PMC passes (profiles/pmc_r02b.sh: separate FETCH_SIZE /
-    # TCC_EA0_RDREQ / WRITE_SIZE runs of this very command); bytes per token there x tokens per launch here.
+    # HBM-side traffic of the same kernels from the committed PMC passes (profiles/profile_r03.sh: separate FETCH_SIZE /
+    # TCC_EA0_RDREQ / WRITE_SIZE runs of this very command, this build); bytes per token there x tokens per launch here.  Counters
+    # cannot be read inside an un-profiled run, so the per-token figure is the profiled window's, the rate is this run's.
     traffic = None
     traffic_note = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02b_c4_pmc_summary.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_c4_pmc_summary.json")))
         if args.workload == "C4":
             bpt_meas = pm["fetch_bytes_per_token"] + pm["write_bytes_per_token"]
             traffic = local_tokens * bpt_meas / avg_kernel_s / 1e9
             traffic_note = (f"{bpt_meas:.0f} B/token = TCC_EA0_RDREQ x 128 B (= 2 x FETCH_SIZE: the gfx950 correction, calibrated "
                             "on this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits "
-                            "included; PMC passes of profiles/pmc_r02b.sh over the 20 timed sweeps of `--steps 20 --warmup 5` "
-                            "(a rocprofv3 run of its own; the walk threshold of the chunk head moves during those sweeps and the "
-                            "1-round kernel with its 16-bit mirror of the counts takes over at sweep 13, so the per-token figure "
-                            "belongs to that window and is BELOW the algorithmic 4K+8 bytes, which assume 4-byte counts), the rate is this run's")
+                            "included; PMC passes of profiles/profile_r03.sh over the 20 timed sweeps of `--steps 20 --warmup 5` "
+                            "(a rocprofv3 run of its own, same build; the 1-round kernel on the 16-bit mirror of the counts takes the "
+                            "entities with short topic lists from sweep 2 on, so the per-token figure is BELOW the algorithmic 4K+8 "
+                            "bytes, which assume 4-byte counts), the rate is this run's")
     except Exception:
         pass
     out = {

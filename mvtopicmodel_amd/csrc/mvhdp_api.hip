@@ -50,6 +50,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_FORK_DELAY_US")) h->tu.fork_delay_us = std::max(0, std::min(1000, atoi(f)));
     if (const char* f = getenv("MVHDP_FORCE_MODE")) { if (!strcmp(f, "serial")) h->tu.single_stream = 1; }   // "streams" (default): class kernels side by side
     if (const char* f = getenv("MVHDP_PRIMARY_MIN_SHARE")) { const double v = atof(f); if (v > 0.0 && v <= 1.0) h->tu.primary_min_share = v; }
     if (const char* t = getenv("MVHDP_WALK_THETA")) {
@@ -802,6 +803,12 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
                 if (!used_stream[si]) step(hipStreamWaitEvent(h->side[si], h->ev_fork, 0));
                 used_stream[si] = true;
                 st = h->side[si];
+            }
+            // the side streams' kernels first: hold this stream for a moment before the primary takes the chip (mvhdp_launch_delay)
+            if (c == p.pc && st == s) {
+                bool side = false;
+                for (int si = 1; si < PLAN_N_STREAMS; si++) side = side || used_stream[si];
+                if (side) step(mvhdp_launch_delay(h->tu.fork_delay_us, s));
             }
             SweepLaunch sc = sl;
             sc.doc_counter = h->d_doc_counter + c;

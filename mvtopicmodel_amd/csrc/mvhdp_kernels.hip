@@ -145,9 +145,14 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         // the same numbers once more, grouped for the descent (see MvModel::dtab)
         double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
         for (int x = lane; x < mm.dt_nblk; x += WAVE) {
-            int bd = 0;
-            while (bd + 1 < mm.dt_nbd && x >= mm.dt_base[bd + 1]) bd++;
-            const int b = (1 << mm.dt_depth[bd]) + (x - mm.dt_base[bd]);
+            // block x of the row: block 0 is rooted at depth 0, then 2^dep blocks for dep = dt_f, dt_f+3, ... (arithmetic, not the
+            // dt_base / dt_depth arrays: a lane-varying index into a kernel-argument array would go through scratch memory)
+            int base = 0, dep = 0;
+            if (x >= 1) {
+                base = 1; dep = mm.dt_f;
+                while (x >= base + (1 << dep)) { base += 1 << dep; dep += 3; }
+            }
+            const int b = (1 << dep) + (x - base);
             double v[8];
 #pragma unroll
             for (int q = 0; q < 7; q++) {
@@ -805,6 +810,24 @@ hipError_t mvhdp_launch_ctl_reset(unsigned long long* stats, int n_stats, long l
                                   unsigned int* class_counts, unsigned long long* qheads, hipStream_t s)
 {
     hipLaunchKernelGGL(ctl_reset_kernel, dim3(1), dim3(256), 0, s, stats, n_stats, act_key, meta, n_meta, class_counts, qheads);
+    return hipGetLastError();
+}
+
+// Holds a stream for about `microseconds` (one wave, s_sleep against the constant 100 MHz counter; always terminates).  An experiment
+// (PlanTuning::fork_delay_us, off by default): put between the fork event and the primary kernel it lets the wider class kernels --
+// which wait for that event on side streams, ~16 us longer than the next launch on the same stream takes -- become resident first
+// instead of when the primary's first blocks drain.  In the kernel trace the segment shortens by 0.14 ms; un-profiled the sweep does
+// not (segmented 34.76 vs 34.66 ms) and a deferred sweep whose wider class is still populous loses 1.5 ms (gpurun_out/r3_m6_*).
+__global__ __launch_bounds__(64) void delay_kernel(unsigned int ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 100000 && __builtin_amdgcn_s_memrealtime() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(16);
+}
+
+hipError_t mvhdp_launch_delay(int microseconds, hipStream_t s)
+{
+    if (microseconds <= 0) return hipSuccess;
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned int)microseconds * 100u);
     return hipGetLastError();
 }
 

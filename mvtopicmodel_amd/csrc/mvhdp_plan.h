@@ -123,6 +123,7 @@ struct PlanTuning {
     double walk_theta[MVHDP_MAXM] = {0};
     double primary_min_share = 0.10;            // the narrowest class holding at least this share of the tokens gets its own (primary) kernel
     int single_stream = 0;                      // 1: every class kernel on the handle's stream, one after another (diagnostics)
+    int fork_delay_us = 0;                      // microseconds the handle's stream is held between the fork event and the primary kernel (0: none)
     int widest_on_main = 0;                     // 1: the widest class on the handle's stream, the primary on a side stream (diagnostics)
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
 };

@@ -37,7 +37,7 @@ for d in sorted(glob.glob(f"{out_dir}/s[0-9]*")):
     tot["_sweeps_seen_" + d.rsplit("/", 1)[1]] = sweep + 1
 per = {c: v / (STEPS * TOK) for c, v in tot.items() if not c.startswith("_")}
 res = {
-    "source": "profiles/pmc_r02b.sh: separate rocprofv3 --kernel-trace --pmc passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --live-steps 0` "
+    "source": os.environ.get("PMC_SOURCE", "profiles/pmc_r02b.sh") + ": separate rocprofv3 --kernel-trace --pmc passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --live-steps 0` "
               "(C4, 1 GPU), all sweep kernels of the 20 timed sweeps; counter calibration in profiles/r02_fetch_calibration.txt",
     "tokens_per_launch": TOK,
     "per_token_raw": per,
@@ -50,4 +50,4 @@ res = {
 }
 res["measured_over_algorithmic"] = (res["fetch_bytes_per_token"] + res["write_bytes_per_token"]) / 1608.0
 print(json.dumps(res, indent=1))
-json.dump(res, open(f"{out_dir}/r02b_c4_pmc_summary.json", "w"), indent=1)
+json.dump(res, open(f"{out_dir}/{os.environ.get('PMC_TAG', 'r02b')}_c4_pmc_summary.json", "w"), indent=1)

@@ -1,8 +1,16 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_walk_threshold.py tests/test_gpu_kat7.py -m gpu -x -q > gpurun_out/r3_t8.log 2>&1; tail -4 gpurun_out/r3_t8.log
-python tools/per_sweep_times.py --sweeps 40 > gpurun_out/r3_ps_c4.json 2>/dev/null
-for w in C2 C3 C5; do python tools/per_sweep_times.py --workload $w --sweeps 30 > gpurun_out/r3_ps_$w.json 2>/dev/null; done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for d in 25 0; do
+MVHDP_FORK_DELAY_US=$d python tools/mode_times.py --mode seg8 --sweeps 34 > gpurun_out/r3_m6_seg8_d$d.json 2>/dev/null
+MVHDP_FORK_DELAY_US=$d python tools/mode_times.py --mode live4 --sweeps 34 > gpurun_out/r3_m6_live4_d$d.json 2>/dev/null
+MVHDP_FORK_DELAY_US=$d python tools/mode_times.py --mode deferred --sweeps 34 > gpurun_out/r3_m6_def_d$d.json 2>/dev/null
+done
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_seg8 -o trace -- python3 tools/mode_times.py --mode seg8 --sweeps 28 > /dev/null 2> gpurun_out/r3_p2_seg8.err
+python tools/kernel_timeline.py gpurun_out/prof_seg8 --last 1 > gpurun_out/r3_tl2_seg8.txt
+rm -rf gpurun_out/prof_seg8
 python -c "
 import json
-for w in ['c4','C2','C3','C5']:
-    d=json.load(open('gpurun_out/r3_ps_%s.json'%w)); k=d['kernel_ms']; print(w, round(sum(k[5:25])/20,3), k[-6:])
+for m in ['seg8','live4','def']:
+  for d in [25,0]:
+    j=json.load(open('gpurun_out/r3_m6_%s_d%d.json'%(m,d))); print(m,d, j['total_ms_sweeps_5_24'], j['total_ms_last_half'])
 "
+head -30 gpurun_out/r3_tl2_seg8.txt

@@ -89,6 +89,9 @@ def run_gpu(args):
         for m in range(c.M):
             s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z0[m])
         s.set_hyper(hy); s.build_counts()
+        if args.live16 is not None:
+            s.set_tuning(live16=args.live16)
+            name += " (live16=%d)" % args.live16
         curve = [{"sweep": 0, "ll_per_token": (s.model_log_likelihood() / ntok).tolist()}]
         ms = 0.0
         for it in range(1, args.sweeps + 1):
@@ -171,6 +174,7 @@ def main():
             p.add_argument("--live-segments", type=int, nargs="*", default=[1, 4, 16])
             p.add_argument("--segmented", type=int, nargs="*", default=[], help="also run SEGMENT_APPLY sweeps with these segment counts")
             p.add_argument("--only", nargs="*", default=[], help="keep only the modes whose name contains one of these strings")
+            p.add_argument("--live16", type=int, default=None, help="pin mvhdp_tuning.live16 (1: live sweeps keep the light n_wk rows in the 16-bit mirror)")
     p = sub.add_parser("table")
     p.add_argument("files", nargs="+")
     args = ap.parse_args()
