@@ -81,6 +81,9 @@ def main():
                          "does when nothing needs the counts in between; same integers")
     ap.add_argument("--torch-exchange", action="store_true",
                     help="N>1: the exchange through torch.distributed on host copies (the fallback path) instead of the library's own RCCL group")
+    ap.add_argument("--rehearse-native", action="store_true",
+                    help="N>1 ranks all on cuda:0 but WITH the library's own RCCL group: RCCL refuses two ranks on one GPU, so this "
+                         "exercises the id broadcast, the failure agreement across ranks and the fallback path end to end")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks all on cuda:0 with the gloo backend (host-staged all-reduce): exercises the "
                          "sharding logic on a 1-GPU box; not a performance number")
@@ -113,7 +116,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sweep has no CPU fallback")
-    if args.rehearse_on_one_gpu:
+    if args.rehearse_on_one_gpu or args.rehearse_native:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"

@@ -50,6 +50,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_FORK_DELAY_US")) h->tu.fork_delay_us = std::max(0, std::min(1000, atoi(f)));
     if (const char* f = getenv("MVHDP_FORCE_MODE")) { if (!strcmp(f, "serial")) h->tu.single_stream = 1; }   // "streams" (default): class kernels side by side
     if (const char* f = getenv("MVHDP_PRIMARY_MIN_SHARE")) { const double v = atof(f); if (v > 0.0 && v <= 1.0) h->tu.primary_min_share = v; }

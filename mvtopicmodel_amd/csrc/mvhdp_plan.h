@@ -123,6 +123,7 @@ struct PlanTuning {
     double walk_theta[MVHDP_MAXM] = {0};
     double primary_min_share = 0.10;            // the narrowest class holding at least this share of the tokens gets its own (primary) kernel
     int single_stream = 0;                      // 1: every class kernel on the handle's stream, one after another (diagnostics)
+    int narrow_wide = 0;                        // 1: deferred sweeps gather from the mirror in the wider variants too (experiment)
     int fork_delay_us = 0;                      // microseconds the handle's stream is held between the fork event and the primary kernel (0: none)
     int widest_on_main = 0;                     // 1: the widest class on the handle's stream, the primary on a side stream (diagnostics)
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
@@ -445,6 +446,8 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // every gathered row.  Needs the mirror to be this sweep's start counts: trees built in this call or still current.  A live sweep
     // keeps the mirror current itself (packed 16-bit atomics, see sweep_fast_kernel's LIVE16 path).
     if (mirror_ok && !p.live && p.cls[0].used && p.cls[0].fast && p.cls[0].walk) p.cls[0].narrow = 1;
+    if (mirror_ok && !p.live && tu.narrow_wide)                        // experiment: the wider variants on the mirror too
+        for (int c = 1; c < 5; c++) if (p.cls[c].used && p.cls[c].fast && p.cls[c].walk) p.cls[c].narrow = 1;
     // A live sweep updates n_wk while it samples: the mirror stays usable only if the sweep's own atomics keep it current, which takes
     // every kernel of the sweep in the NARROW (hence walk) flavour -- no generic kernel among them.
     if (want_live16) {

@@ -64,7 +64,10 @@ __device__ __forceinline__ double dpp_src_d(double x)
 
 // (Tried in round 3: skipping the long strides for short topic lists -- a step of stride s changes nothing below lane s -- with
 // wave-uniform branches on the list size: 30.1 ms instead of 28.8 per settled C4 sweep.  The five extra scalar branches per token
-// cost more than the skipped DPP steps save; the scalar unit is 64 % busy in this kernel, the vector unit 94 %.)
+// cost more than the skipped DPP steps save; the scalar unit is 64 % busy in this kernel, the vector unit 94 %.
+// Also tried: the mirror's saturation test without the slot test, the removed-slot test folded into the count (one select instead of
+// two), the new-topic comparisons skipped when there are no inactive topics -- the compiler answered with MORE vector instructions
+// (107 instead of 102.5 per token, SQ_INSTS_VALU) and the kernel was 1 % slower; source-level trimming of this loop has run out.)
 __device__ __forceinline__ double wave_incl_scan_d_dpp(double v)
 {
     v += dpp_src_d<0x111, 0xf, true>(v);    // row_shr:1
