@@ -173,6 +173,13 @@ const char* mvhdp_version(void);
 int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t num_docs,
                      const int64_t* doc_off /*[D+1]*/, const int32_t* tokens /*[N_m]*/);
 int mvhdp_set_assignments(mvhdp_handle h, int32_t m, const int32_t* z /*[N_m]*/);  /* topicSequence.getFeatures() PTM:481 */
+/* Which entities HAVE view m (Assignments[m] != null, MTA:19): present[d] = 1 also for an instance with an empty FeatureSequence,
+ * which the CSR alone cannot tell from a missing one.  NULL (the default) = present iff the span is non-empty.  The sweep does not
+ * care (WRK:341,403 treat null and length 0 alike); the statistics do: modelLogLikelihood's two phantom tokens of topic 0 and its
+ * modalityCnt (PTM:3348-3373: the backing array of an empty LabelSequence has length 2), totalDocsPerModality and
+ * docLengthCounts[0] (PTM:620-651), and the carry-over of printDocumentTopics (PTM:2873-2886: a present empty view scores with
+ * zeros, a missing one with the previous holder's counts).  Call after mvhdp_set_corpus of that view. */
+int mvhdp_set_view_presence(mvhdp_handle h, int32_t m, const uint8_t* present /*[D] or NULL*/);
 int mvhdp_get_assignments(mvhdp_handle h, int32_t m, int32_t* z /*[N_m]*/);
 
 /* ---- model state ---- */

@@ -10,7 +10,7 @@ MAX_M = 8
 # every symbol include/mvhdp.h declares
 ABI_SYMBOLS = [
     "mvhdp_create", "mvhdp_destroy", "mvhdp_last_error", "mvhdp_version",
-    "mvhdp_set_corpus", "mvhdp_set_assignments", "mvhdp_get_assignments",
+    "mvhdp_set_corpus", "mvhdp_set_assignments", "mvhdp_set_view_presence", "mvhdp_get_assignments",
     "mvhdp_set_hyper", "mvhdp_get_alpha", "mvhdp_build_counts", "mvhdp_build_trees",
     "mvhdp_build_inference_trees", "mvhdp_init_assignments_from_trees",
     "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
@@ -183,6 +183,7 @@ def load_library():
     L.mvhdp_version.restype = C.c_char_p
     L.mvhdp_set_corpus.argtypes = [vp, i32, i64, vp, vp]
     L.mvhdp_set_assignments.argtypes = [vp, i32, vp]
+    L.mvhdp_set_view_presence.argtypes = [vp, i32, vp]
     L.mvhdp_get_assignments.argtypes = [vp, i32, vp]
     L.mvhdp_set_hyper.argtypes = [vp, C.POINTER(HyperC)]
     L.mvhdp_get_alpha.argtypes = [vp, vp, vp]

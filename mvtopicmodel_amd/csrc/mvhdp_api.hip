@@ -167,7 +167,7 @@ static void release_device_resources(mvhdp_ctx* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
-    for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); }
+    for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); fr(h->d_present[m]); }
     fr(h->mm.counts); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
     fr(h->d_alpha); fr(h->d_inactive); fr(h->d_ctl);
     if (h->h_ctl) { hipHostFree(h->h_ctl); h->h_ctl = nullptr; }
@@ -240,6 +240,8 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     if (h->d_doc_off[m]) { hipFree(h->d_doc_off[m]); h->d_doc_off[m] = nullptr; }
     if (h->d_tok[m]) { hipFree(h->d_tok[m]); h->d_tok[m] = nullptr; }
     if (h->d_z[m]) { hipFree(h->d_z[m]); h->d_z[m] = nullptr; }
+    if (h->d_present[m]) { hipFree(h->d_present[m]); h->d_present[m] = nullptr; }
+    h->h_present[m].clear(); mm.present[m] = nullptr;
     HIPC(h, hipMalloc(&h->d_doc_off[m], (size_t)(D + 1) * sizeof(int64_t)));
     HIPC(h, hipMemcpy(h->d_doc_off[m], doc_off, (size_t)(D + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     const size_t nb = (size_t)std::max<int64_t>(N, 1) * sizeof(int32_t);
@@ -288,6 +290,27 @@ extern "C" int mvhdp_set_assignments(mvhdp_handle h, int32_t m, const int32_t* z
     // the counts no longer describe these assignments: a sampling sweep is refused until build_counts / set_counts /
     // counts_written says they do again (a frozen sweep, whose counts are a trained model's by design, is not)
     if (h->have_counts) h->counts_stale = true;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_set_view_presence(mvhdp_handle h, int32_t m, const uint8_t* present)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    if (m < 0 || m >= mm.M) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_view_presence: bad view");
+    if (!h->have_corpus[m]) FAIL(h, MVHDP_ERR_STATE, "set_view_presence before set_corpus");
+    HIPC(h, hipSetDevice(h->device));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (h->d_present[m]) { hipFree(h->d_present[m]); h->d_present[m] = nullptr; }
+    h->h_present[m].clear(); mm.present[m] = nullptr;
+    if (h->d_carry[m]) { hipFree(h->d_carry[m]); h->d_carry[m] = nullptr; }         // the carry-over map of doc_topic_proportions depends on it
+    if (!present || mm.D == 0) return MVHDP_OK;
+    for (int64_t d = 0; d < mm.D; d++)
+        if (!present[d] && h->h_doc_off[m][d + 1] > h->h_doc_off[m][d]) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_view_presence: an entity with tokens in the view is marked absent");
+    h->h_present[m].assign(present, present + mm.D);
+    HIPC(h, hipMalloc(&h->d_present[m], (size_t)mm.D));
+    HIPC(h, hipMemcpy(h->d_present[m], present, (size_t)mm.D, hipMemcpyHostToDevice));
+    mm.present[m] = h->d_present[m];
     return MVHDP_OK;
 }
 
@@ -1321,7 +1344,8 @@ extern "C" int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_we
             std::vector<int64_t> src((size_t)mm.D);
             int64_t last = -1;
             for (int64_t d = 0; d < mm.D; d++) {
-                if (h->h_doc_off[m][d + 1] > h->h_doc_off[m][d]) last = d;
+                const bool has = h->h_present[m].empty() ? h->h_doc_off[m][d + 1] > h->h_doc_off[m][d] : h->h_present[m][(size_t)d] != 0;
+                if (has) last = d;                             // (a present view without tokens is refreshed to zeros, PTM:2873-2886)
                 src[(size_t)d] = last;
             }
             HIPC(h, hipMalloc(&h->d_carry[m], (size_t)mm.D * sizeof(int64_t)));
@@ -1396,7 +1420,8 @@ extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
         double ll = 0;
         int64_t modalityCnt = 0;
         for (int64_t d = 0; d < mm.D; d++) {
-            if (h->h_doc_off[m][d + 1] > h->h_doc_off[m][d]) { ll += hdoc[d]; modalityCnt++; }     // PTM:3348-3367
+            const bool has = h->h_present[m].empty() ? h->h_doc_off[m][d + 1] > h->h_doc_off[m][d] : h->h_present[m][(size_t)d] != 0;
+            if (has) { ll += hdoc[d]; modalityCnt++; }                                              // PTM:3348-3367
         }
         ll += modalityCnt * log_gamma_stirling_host((double)mm.gamma[m] * mm.alpha_sum[m]);       // PTM:3373
         if (std::isnan(ll) || std::isinf(ll)) { out[m] = 0; continue; }                           // PTM:3375-3383

@@ -35,6 +35,8 @@ struct mvhdp_ctx {
     void* d_doc_off[MVHDP_MAXM]{};
     void* d_tok[MVHDP_MAXM]{};
     void* d_z[MVHDP_MAXM]{};
+    uint8_t* d_present[MVHDP_MAXM]{};        // mvhdp_set_view_presence (nullptr: inferred from the spans)
+    std::vector<uint8_t> h_present[MVHDP_MAXM];
     int64_t max_doc_tokens = -1;             // over all views, lazily computed
 
     double* d_alpha = nullptr;

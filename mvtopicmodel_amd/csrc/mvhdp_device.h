@@ -19,6 +19,11 @@ struct MvModel {
     const int64_t* doc_off[MVHDP_MAXM];
     const int32_t* tok[MVHDP_MAXM];
     int32_t* z[MVHDP_MAXM];
+    // [D] per view, or nullptr: 1 = the entity HAS this view (Assignments[m] != null, MTA:19) even if it holds no token.  nullptr (the
+    // default) = a view is present iff its span is non-empty.  Only the statistics either side of the sweep can tell the difference
+    // (the worker treats null and length 0 alike, WRK:341,403): modelLogLikelihood's phantom tokens and modalityCnt (PTM:3348-3373),
+    // totalDocsPerModality / docLengthCounts[0] (PTM:620-651), the carry-over of printDocumentTopics (PTM:2873-2886).
+    const uint8_t* present[MVHDP_MAXM];
     // [D] distinct topics of each entity's current assignments over all views = the size of its topic list (WRK:376-391) at
     // the NEXT visit.  Every sweep kernel writes it when it leaves an entity (slot_count_kernel after assignments came from
     // the host), so the next sweep routes every entity to the narrowest kernel variant that holds it without measuring

@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void doc_topic_hist_kernel(MvModel mm, int m, 
     const int64_t wstride = (int64_t)gridDim.x * nwaves;
     for (int64_t d = (int64_t)blockIdx.x * nwaves + wave; d < mm.D; d += wstride) {
         const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
-        if (e == b) continue;
+        if (mm.present[m] ? !mm.present[m][d] : e == b) continue;          // the entity lacks the view (a present view without tokens counts)
         for (int k = lane; k < K; k += WAVE) my[k] = 0;
         LDS_FENCE();
         for (int64_t i = b + lane; i < e; i += WAVE) { int zz = mm.z[m][i]; if (zz >= 0) atomicAdd(&my[zz], 1); }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void loglik_doc_kernel(MvModel mm, int m, doub
     const int64_t wstride = (int64_t)gridDim.x * wpb;
     for (int64_t d = (int64_t)blockIdx.x * wpb + wave; d < mm.D; d += wstride) {
         const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
-        if (e == b) { if (lane == 0) out[d] = 0.0; continue; }
+        if (mm.present[m] ? !mm.present[m][d] : e == b) { if (lane == 0) out[d] = 0.0; continue; }   // the entity lacks the view
         for (int k = lane; k < K; k += WAVE) cnt[k] = 0;
         LDS_FENCE();
         for (int64_t i = b + lane; i < e; i += WAVE) { int zz = mm.z[m][i]; atomicAdd(&cnt[zz < 0 ? 0 : zz], 1); }

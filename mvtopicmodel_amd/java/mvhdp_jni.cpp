@@ -170,6 +170,23 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetAssignment
     if (rc) throw_rt(env, s->h, rc, "mvhdp_set_assignments");
 }
 
+// which entities HAVE the view (Assignments[m] != null) even when its FeatureSequence is empty: mvhdp_set_view_presence
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetViewPresence(JNIEnv* env, jclass, jlong p, jint m, jbooleanArray present)
+{
+    Shard* s = S(p);
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "setViewPresence: bad view"); return; }
+    int rc;
+    if (!present) rc = mvhdp_set_view_presence(s->h, m, nullptr);
+    else {
+        if (bad_len(env, present, s->D, "setViewPresence")) return;
+        std::vector<uint8_t> v(static_cast<size_t>(s->D));
+        env->GetBooleanArrayRegion(present, 0, (jsize)s->D, reinterpret_cast<jboolean*>(v.data()));
+        rc = mvhdp_set_view_presence(s->h, m, v.data());
+    }
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_set_view_presence");
+}
+
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAssignments(JNIEnv* env, jclass, jlong p, jint m, jintArray z)
 {
     Shard* s = S(p);

@@ -44,6 +44,8 @@ public final class NativeSampler implements AutoCloseable {
     public void setCorpus(int m, long[] docOff, int[] tokens) { nSetCorpus(handle, m, docOff, tokens); }
     public void setAssignments(int m, int[] z) { nSetAssignments(handle, m, z); }
     public void getAssignments(int m, int[] z) { nGetAssignments(handle, m, z); }
+    /** present[d] = data.get(d).Assignments[m] != null: an instance with an EMPTY FeatureSequence is not a missing view (lines 3348-3373, 2873-2886). */
+    public void setViewPresence(int m, boolean[] present) { nSetViewPresence(handle, m, present); }
 
     public void setHyper(double[][] alpha, double[] alphaSum, double[] beta, double[] betaSum, double[] gamma,
                          double[][] p_a, double[][] p_b, boolean[] inactive) {
@@ -178,6 +180,7 @@ public final class NativeSampler implements AutoCloseable {
     private static native void nSetCorpus(long h, int m, long[] docOff, int[] tokens);
     private static native void nSetAssignments(long h, int m, int[] z);
     private static native void nGetAssignments(long h, int m, int[] z);
+    private static native void nSetViewPresence(long h, int m, boolean[] present);
     private static native void nSetHyper(long h, double[][] alpha, double[] alphaSum, double[] beta, double[] betaSum,
                                          double[] gamma, double[][] p_a, double[][] p_b, boolean[] inactive);
     private static native void nBuildCounts(long h);

@@ -164,6 +164,16 @@ class NativeSampler:
             raise ValueError("z length mismatch")
         self._ck(self.L.mvhdp_set_assignments(self.h, m, _ptr(z)))
 
+    def set_view_presence(self, m, present):
+        """present: uint8 [D] (1 = the entity has the view even without tokens) or None (inferred from the spans)."""
+        if present is None:
+            self._ck(self.L.mvhdp_set_view_presence(self.h, m, None))
+            return
+        p = np.ascontiguousarray(present, dtype=np.uint8)
+        if len(p) != self.D:
+            raise ValueError("presence mask length mismatch")
+        self._ck(self.L.mvhdp_set_view_presence(self.h, m, _ptr(p)))
+
     def get_assignments(self, m):
         z = np.empty(self.N[m], dtype=np.int32)
         self._ck(self.L.mvhdp_get_assignments(self.h, m, _ptr(z)))
