@@ -308,6 +308,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "sweep kernels of one mvhdp_sweep (dominant: sweep_fast_kernel<R>)", "bytes_per_token": bpt, "tokens_per_launch": local_tokens,
+                     "physical_bound_note": "the fixed-byte HBM yardstick of SURVEY 8d is nominal: the settled kernel gathers 2-byte counts and is "
+                                            "vector-ALU issue bound (SQ_ACTIVE_INST_VALU 94 % of the SIMD cycles, 102 VALU instructions per token: "
+                                            "profiles/r03_c4_sq_counters_settled.json), 5.2 G tokens/s whatever K",
                      "avg_kernel_ms": avg_kernel_s * 1e3},
         "sweep": {"changed_frac": last.changed / max(1, last.tokens),
                   "branch_frac": {"new": last.new_mass_cnt / max(1, last.tokens),
