@@ -161,10 +161,12 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             S_used = bcast_i(incl, 63);
         }
         LDS_FENCE();
-        // slots per lane: 1, 2 or 4 consecutive slots (slot i = lane*R_eff + r)
-        const int lg = (S_used <= 64) ? 0 : (S_used <= 128) ? 1 : (S_used <= 256) ? 2 : (S_used <= 512) ? 3 : 4;
-        const int R_eff = 1 << lg;
-        if (S_used > 1024 || R_eff > RMAX || (PACK && longest_view > 65535)) {   // too many topics (or tokens) for this variant:
+        // Slots per lane: RMAX consecutive slots (slot i = lane*RMAX + r), whatever the list's size: a list shorter than the variant's
+        // 64*RMAX slots simply occupies fewer lanes -- the per-token work is RMAX rounds either way -- and the shifts and masks by
+        // R_eff in the token loop are compile-time constants (round 3; it used to be the smallest power of two that holds the list).
+        constexpr int lg = (RMAX == 1) ? 0 : (RMAX == 2) ? 1 : (RMAX == 4) ? 2 : (RMAX == 8) ? 3 : 4;
+        constexpr int R_eff = RMAX;
+        if (S_used > 64 * RMAX || (PACK && longest_view > 65535)) {   // too many topics (or tokens) for this variant:
             n_misclass++;                                                        // route_kernel sent it here by mistake; the host fails the sweep
             continue;
         }
