@@ -1015,8 +1015,8 @@ int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats)
     mvhdp_sweep_stats st;
     stats_from_counters(hs, act, st);
     const unsigned long long negatives = hs[ST_NEGATIVE];
-    // (mvhdp_apply_delta below re-uses the pinned buffer's source counters: everything needed from it is copied by now except
-    // the histograms, which learn_from_sweep reads -- keep them)
+    // (the pinned buffer belongs to the handle: a sweep begun on it before this one returns would overwrite it -- what the
+    // planner learns from is copied out first)
     unsigned long long hist_keep[MVHDP_HIST_BINS + MVHDP_ENT_BINS];
     std::copy(meta + META_HIST, meta + META_HIST + MVHDP_HIST_BINS + MVHDP_ENT_BINS, hist_keep);
     unsigned long long hs_keep[ST_COUNT];
@@ -1101,8 +1101,6 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
     }
     while ((int)h->ev_many.size() < 2 * n) { hipEvent_t ev; HIPC(h, hipEventCreate(&ev)); h->ev_many.push_back(ev); }
     HIPC(h, hipEventRecord(h->ev[0], s));
-    const bool reuse_after_first = false;
-    (void)reuse_after_first;
     for (int i = 0; i < n; i++) {
         SweepOutcome oc;
         unsigned long long* d_st = h->d_stats_many + (size_t)i * ST_COUNT;
@@ -1126,7 +1124,7 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
     float ms_t = 0;
     hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
     int ret = MVHDP_OK;
-    double ms_sum = 0; unsigned long long tok_sum = 0;
+    double ms_sum = 0;
     for (int i = 0; i < n; i++) {
         const unsigned long long* hi = hs.data() + (size_t)i * ST_COUNT;
         mvhdp_sweep_stats st;
@@ -1134,7 +1132,7 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
         float ms_k = 0;
         hipEventElapsedTime(&ms_k, h->ev_many[2 * i], h->ev_many[2 * i + 1]);
         st.sweep_kernel_ms = ms_k; st.total_ms = ms_t / n;
-        ms_sum += ms_k; tok_sum += hi[ST_TOKENS];
+        ms_sum += ms_k;
         if (stats) stats[i] = st;
         if (hi[ST_MISCLASS]) { h->nslots_valid = false; FAIL(h, MVHDP_ERR_HIP, "internal: an entity reached a sweep kernel variant that cannot hold its topic list"); }
         if (hi[ST_NEGATIVE] && ret == MVHDP_OK) { h->err = "a topic count went below zero (UPD:202-215)"; ret = MVHDP_ERR_NEGATIVE_COUNT; }
@@ -1145,7 +1143,6 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
     for (int i = 0; i < n; i++) for (int k = 0; k < ST_COUNT; k++) acc[k] += hs[(size_t)i * ST_COUNT + k];
     const bool comparable = p.fast && !h->tu.walk_fixed && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN));
     learn_from_sweep(h, p, acc.data(), meta + META_HIST, ms_sum, comparable);
-    (void)tok_sum;
     return ret;
 }
 

@@ -1,8 +1,14 @@
-"""Document shards across GPUs: one process per GPU, each
-holding a contiguous entity range and a full replica of n_wk / n_k.  The only
+"""Document shards across GPUs, driven from Python through torch.distributed.
+
+SINCE ROUND 3 THE PRODUCT'S MULTI-GPU PATH IS mvhdp_group_* INSIDE libmvhdp.so (csrc/mvhdp_group.hip; Python view:
+mvtopicmodel_amd.native.NativeGroup): the same sequence -- sweep with NO_APPLY, sum of the deltas, apply by row ranges --
+with RCCL called by the library itself.  This module stays for what torch.distributed can do and the library cannot:
+the world_size-2 `gloo` tests on CPU (tests/test_dist_gloo.py, the shard backed by the test oracle), the host-staged
+rehearsal of N ranks on one GPU, and bench.py's fallback when the native group cannot be formed.
+
+One process per GPU, each holding a contiguous entity range and a full replica of n_wk / n_k.  The only
 exchange step of the path is one integer all-reduce of the sweep's count deltas
-(RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" on CPU in
-the tests, where the shard is backed by the test oracle instead of the GPU).
+(torch.distributed's "nccl" backend = RCCL over xGMI; "gloo" on CPU in the tests).
 
 The reference has no counterpart (single JVM, shared arrays PTM:84-87); the
 sharding follows its worker slices PTM:1051-1098: documents are the independent
