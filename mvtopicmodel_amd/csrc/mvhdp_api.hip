@@ -81,6 +81,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
         return MVHDP_ERR_INVALID_ARG;
     }
     for (int m = 0; m < M; m++) if (cfg->num_types[m] < 1) { g_create_error = "num_types[m] must be >= 1"; return MVHDP_ERR_INVALID_ARG; }
+    for (int m = 0; m < M; m++) if (cfg->num_types[m] >= (1 << 30)) { g_create_error = "num_types[m] must be below 2^30"; return MVHDP_ERR_INVALID_ARG; }
     if (cfg->doc_id_base < 0 || cfg->doc_id_base >= (1LL << 29)) { g_create_error = "doc_id_base out of range"; return MVHDP_ERR_INVALID_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {

@@ -55,13 +55,15 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 // loop and the per-view branch statistics the threshold search feeds on.  Without it every token is walked up front and nothing
 // is counted: where the best threshold is 0 (C2, C3) that code is 2-5 % faster for not carrying the rest.
 // NARROW (walk flavour only): the n_wk gather reads the 16-bit mirror of the counts (MvModel::counts16, written with the trees at
-// the start of the sweep) -- half the lines of the row; a saturated value (65535 = a heavy row, MvModel::heavy) sends the lane to
-// the 32-bit table, checked when the value is used, not when the gather is issued (the prefetch for the next token stays
-// asynchronous).  Same numbers, so same results.  A deferred sweep uses it for the 1-round variant only (the 2-round variant is 4 %
+// the start of the sweep) -- half the lines of the row -- for a light row, and the 32-bit table for a heavy one (MvModel::heavy: a
+// type with more than 65534 tokens, whose mirror cells all read 65535); the row's class travels with the token's type id (W_HEAVY),
+// so the choice is a scalar branch at the gather and the values need no check when they are used.  Same numbers, so same results.  A deferred sweep uses it for the 1-round variant only (the 2-round variant is 4 %
 // slower with it: two 2-byte loads per lane cost it more than the lines are worth).  A live sweep (SweepLaunch::live16) uses it for
 // every variant: there the chunk-end atomics of the light rows land IN the mirror -- two 16-bit cells per 32-bit word, +-1 or +-65536,
 // which cannot carry: a light row's cell stays below 65535 and a decrement only ever takes back a token that was counted -- so the
 // mirror is what every later token of the sweep reads (UPD:197-207 applied while the workers sample), at half the gather traffic.
+#define W_HEAVY 0x40000000                      // bit 30 of a lane's type id: the row is heavy (type ids stay below 2^30: mvhdp_create checks)
+#define W_ROW(w) ((w) & 0x3fffffff)
 template <int RMAX, bool DEBUG, bool WALK, bool NARROW>
 __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : 1))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
@@ -93,6 +95,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     int* wlen = (int*)(bitmap2 + 64);
     int* sk = wlen + 16;
     constexpr bool PACK = RMAX >= 8;                       // per-view slot counts as 16-bit values
+    // fp32 screening of the token loop's decisions (mvhdp_sweep_fast_token.inc): two more registers per slot, so not for the
+    // 8- and 16-round variants, which sit at their register limit; the debug flavour reports fp64 masses and decides in fp64
+    constexpr bool SCREEN = RMAX <= 4 && !DEBUG;
     int* sn = sk + S;
 #define sn_get(idx) (PACK ? (int)((const unsigned short*)sn)[(idx)] : sn[(idx)])
 #define sn_set(idx, v) do { if (PACK) ((unsigned short*)sn)[(idx)] = (unsigned short)(v); else sn[(idx)] = (v); } while (0)
@@ -215,28 +220,46 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 
             // per-view slot registers; WRK:395-410 totalMassOtherModalities (frozen for this view, Q3)
             int cn[RMAX];
-            double oth[RMAX], den[RMAX];
+            double oth[RMAX], den[RMAX];          // (kept in registers by the flavours without screening; see slot_consts)
             unsigned int onz = 0;
-#pragma unroll
-            for (int r = 0; r < RMAX; r++) {
-                cn[r] = 0; oth[r] = 0.0; den[r] = 1.0;
+            // oth and den of slot r of this lane, from what does not change while the view is sampled (the other views' counts of the
+            // entity, the view lengths, n_k): the flavours with fp32 screening keep only the fp32 forms in registers and call this again
+            // for the rare token that goes to fp64 -- same inputs, same operations, same doubles.
+            auto slot_consts = [&](int r, double& o, double& dn) {
+                o = 0.0; dn = 1.0;
                 const int i = lane * R_eff + r;
                 if (r < R_eff && i < S_used) {
                     const int k = skr[r] & 0x7fffffff;
-                    cn[r] = sn_get(m * S + i);
                     double acc = 0.0;
                     for (int j = 0; j < M; j++) {
                         if (j == m) continue;
                         const int cj = sn_get(j * S + i);
-                        if (cj != 0) onz |= 1u << r;
                         const int lj = wlen[j];
                         if (lj != 0)
                             acc += pd[m * M + j] * ((double)cj + mm.gamma[j] * mm.alpha[(int64_t)j * (K + 1) + k])
                                    / ((double)lj + mm.gamma[j] * mm.alpha_sum[j]);
                     }
-                    oth[r] = acc * scale_m;
-                    den[r] = (double)nk[k] + mm.beta_sum[m];
+                    o = acc * scale_m;
+                    dn = (double)nk[k] + mm.beta_sum[m];
                 }
+            };
+            float rden32[RMAX], brden32[RMAX], oth32[RMAX];      // the fp32 forms the screening works with: 1/den, beta/den, oth
+            const float beta32 = (float)beta_m;
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) {
+                cn[r] = 0;
+                const int i = lane * R_eff + r;
+                if (r < R_eff && i < S_used) {
+                    cn[r] = sn_get(m * S + i);
+                    for (int j = 0; j < M; j++) if (j != m && sn_get(j * S + i) != 0) onz |= 1u << r;
+                }
+                double o, dn;
+                slot_consts(r, o, dn);
+                oth[r] = SCREEN ? 0.0 : o;
+                den[r] = SCREEN ? 1.0 : dn;
+                rden32[r] = SCREEN ? __builtin_amdgcn_rcpf((float)dn) : 0.0f;
+                brden32[r] = beta32 * rden32[r];
+                oth32[r] = SCREEN ? (float)o : 0.0f;
             }
             // WRK:413-418 newTopicMassAllModalities
             double newAll = 0.0;
@@ -246,6 +269,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             }
             newAll = newAll * scale_m;
             const double newMass = (mm.first_inactive < 0) ? 0.0 : newAll / (double)K;   // WRK:515
+            // the fp32 copies the screening works with (wave-uniform ones as scalars)
+            const float pmm32 = uniform_f((float)p_mm), newMass32 = uniform_f((float)newMass);
 
             const int64_t base = mm.doc_off[m][d];
             const int64_t row0 = mm.rowbase[m];
@@ -261,9 +286,6 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 const bool tvalid = ti < lenm;
                 int w_l = tvalid ? mm.tok[m][base + ti] : -1;
                 int z_l = tvalid ? mm.z[m][base + ti] : -1;
-                // live16: does this token's row keep its counts in the mirror (light) or in the 32-bit table (heavy)?  (loaded here, used at the chunk's end)
-                bool light_l = false;
-                if (NARROW && sl.live16 && w_l >= 0 && w_l < Vm) light_l = mm.heavy[row0 + w_l] == 0;
                 int so_l = -1;
                 if (z_l >= 0) {
                     uint32_t w = bitmap[z_l >> 5];
@@ -278,6 +300,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     u2_l = bits_to_unit(x[2], x[3]);
                 }
                 if (w_l >= Vm) w_l = -1;                                     // WRK:427-428 marks OOV
+                // NARROW: the row's weight class rides in bit 30 of the type id (a light row's counts are in the 16-bit mirror, a heavy row's
+                // only in the 32-bit table, MvModel::heavy), so that the gather of a token's row knows the table to read from a scalar of
+                // the broadcast it does anyway -- nothing to check or resolve when the values are used.  (W_ROW strips the bit.)
+                if (NARROW && w_l >= 0 && mm.heavy[row0 + w_l]) w_l |= W_HEAVY;
+                const float u1f_l = (float)u1_l;                             // (may round to 1.0f: the screening then hands the token to fp64)
                 int znew_l = z_l;
                 const int nt = min(WAVE, lenm - c0);
 
@@ -293,10 +320,10 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 int zt_l = -1, st_l = -1;
                 const bool walk_l = tvalid && w_l >= 0 && (!WALK || u1_l >= walk_theta);
                 const unsigned long long walked = WALK ? __ballot(walk_l) : ~0ull;
-                if (WALK && tvalid && w_l >= 0 && !walk_l) root_l = mm.root[row0 + w_l];
+                if (WALK && tvalid && w_l >= 0 && !walk_l) root_l = mm.root[row0 + W_ROW(w_l)];
                 {
                     const bool act = walk_l;
-                    const double* __restrict__ dt = mm.dtab + (row0 + max(w_l, 0)) * (int64_t)mm.dt_nblk * 8;
+                    const double* __restrict__ dt = mm.dtab + (row0 + W_ROW(max(w_l, 0))) * (int64_t)mm.dt_nblk * 8;
                     double u = 0.0;
                     int i = 1;
                     // descent by 64-byte blocks of the descent table: three levels of the path per sector
@@ -329,6 +356,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
 
+                const float root32_l = (float)root_l;
                 MVHDP_TSEG(th);
                 // software pipeline: the n_wk values of the listed topics are gathered NB tokens ahead, into NB
                 // register buffers used in turn (the token loop is unrolled NB times so that no buffer is ever
@@ -339,13 +367,14 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #pragma unroll
                 for (int a = 0; a < NB; a++) {
                     const int w0 = bcast_i(w_l, min(a, nt - 1));
-                    const int64_t r0 = row0 + max(w0, 0);
+                    const int64_t r0 = row0 + W_ROW(max(w0, 0));
+                    const bool h0 = w0 >= 0 && (w0 & W_HEAVY);
                     const char* __restrict__ c0p = (const char*)(nwk + r0 * K);
                     const char* __restrict__ c0q = (const char*)(nwk16 + r0 * K);
 #pragma unroll
                     for (int r = 0; r < RMAX; r++) {
                         int v;
-                        if (NARROW) v = (int)*(const uint16_t*)(c0q + (koff[r] >> 1));          // (a saturated cell is resolved at use)
+                        if (NARROW && !h0) v = (int)*(const uint16_t*)(c0q + (koff[r] >> 1));
                         else v = (NB == 2 || r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
                         if (a == 0) gn[r] = v; else gn2[r] = v;
                     }
@@ -377,8 +406,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     const bool chg = tvalid && (w_l >= 0) && (znew_l != z_l) && !(sl.flags & MVHDP_SWEEP_FROZEN);
                     n_chg += (unsigned int)__popcll(__ballot(chg));
                     if (chg) {
-                        const int64_t rowK = (row0 + w_l) * K;
-                        if (NARROW && light_l) {
+                        const int64_t rowK = (row0 + W_ROW(w_l)) * K;
+                        if (NARROW && sl.live16 && !(w_l & W_HEAVY)) {
                             // a light row of a live16 sweep: its counts live in the mirror, two cells per word
                             unsigned int* m32 = (unsigned int*)mm.counts16;
                             if (z_l >= 0) { const int64_t c = rowK + z_l; __hip_atomic_fetch_add(&m32[c >> 1], 0u - (1u << ((c & 1) * 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

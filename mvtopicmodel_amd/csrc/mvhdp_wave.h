@@ -19,6 +19,19 @@ __device__ __forceinline__ int bcast_i(int v, int src_lane)
     return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_lane));
 }
 
+__device__ __forceinline__ float bcast_f(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src_lane)));
+}
+
+__device__ __forceinline__ double uniform_d(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float uniform_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
 __device__ __forceinline__ double bcast_d(double v, int src_lane)
 {
     int s = __builtin_amdgcn_readfirstlane(src_lane);
@@ -79,6 +92,32 @@ __device__ __forceinline__ double wave_incl_scan_d_dpp(double v)
     return v;
 }
 
+
+// The same scan in fp32: DPP is a 32-bit facility, so a step is ONE v_add_f32 with a DPP source (three instructions for fp64), and
+// fp32 issues at twice the fp64 rate.  Used by the fp32 screening of the token loop (mvhdp_sweep_fast_token.inc).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_src_f(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, BOUND));
+}
+
+__device__ __forceinline__ float wave_incl_scan_f_dpp(float v)
+{
+    v += dpp_src_f<0x111, 0xf, true>(v);    // row_shr:1   (the compiler fuses these four into v_add_f32_dpp)
+    v += dpp_src_f<0x112, 0xf, true>(v);    // row_shr:2
+    v += dpp_src_f<0x114, 0xf, true>(v);    // row_shr:4
+    v += dpp_src_f<0x118, 0xf, true>(v);    // row_shr:8
+    // row_bcast:15 -> rows 1 and 3, row_bcast:31 -> rows 2 and 3: with a row mask the rows that are not named keep their value, which
+    // is exactly the scan step -- one instruction each; written out because the compiler does not fuse a masked DPP move (it emits a
+    // zero move, the DPP move and an add).  The s_nop are the wait states a DPP read of a just-written VGPR needs: the hazard
+    // recogniser does not look inside inline assembly.
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
 
 // IEEE-754 correctly rounded n/d for operands that need no rescaling: exactly the
 // Newton/fma sequence hipcc emits for an fp64 divide (v_rcp_f64, two refinements,
