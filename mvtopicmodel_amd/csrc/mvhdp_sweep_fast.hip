@@ -4,7 +4,10 @@
 // where the per-entity state lives and when things are fetched:
 //
 //   slot i = lane*R + r  (R = 1 .. 16 slots per lane, R <= RMAX)  -> lane registers
-//     skr[r]  topic of the slot, sign bit = removed from the list (WRK:451-468) or never used
+//     koff[r] topic of the slot, as the byte offset of its count inside an n_wk row (topic * 4)
+//     live_m[r]  (scalar registers, one bit per lane) the slot is on the list: cleared when the topic is removed (WRK:451-468),
+//             never set for a slot the list does not reach -- a scalar mask, so a removal is scalar arithmetic and the token loop
+//             selects on it without a comparison
 //     cn[r]   localTopicCounts[m][topic] of the view being sampled (WRK:357,437,560)
 //     oth[r]  totalMassOtherModalities[topic]                       (WRK:399-410)
 //     den[r]  tokensPerTopic[m][topic] + betaSum[m]                 (WRK:507)
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     constexpr bool PACK = RMAX >= 8;                       // per-view slot counts as 16-bit values
     // fp32 screening of the token loop's decisions (mvhdp_sweep_fast_token.inc): two more registers per slot, so not for the
     // 8- and 16-round variants, which sit at their register limit; the debug flavour reports fp64 masses and decides in fp64
-    constexpr bool SCREEN = RMAX <= 4 && !DEBUG;
+    constexpr bool SCREEN = !DEBUG;
     int* sn = sk + S;
 #define sn_get(idx) (PACK ? (int)((const unsigned short*)sn)[(idx)] : sn[(idx)])
 #define sn_set(idx, v) do { if (PACK) ((unsigned short*)sn)[(idx)] = (unsigned short)(v); else sn[(idx)] = (v); } while (0)
@@ -198,12 +201,14 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             }
         }
         LDS_FENCE();
-        int skr[RMAX], koff[RMAX];
+        int koff[RMAX];
+        unsigned long long live_m[RMAX];
 #pragma unroll
         for (int r = 0; r < RMAX; r++) {
             const int i = lane * R_eff + r;
-            skr[r] = (r < R_eff && i < S_used) ? sk[i] : (int)0x80000000;  // unused slot = removed topic 0
-            koff[r] = (skr[r] & 0x7fffffff) << 2;                          // byte offset of the topic inside an n_wk row
+            const bool used = r < R_eff && i < S_used;
+            koff[r] = used ? sk[i] << 2 : 0;                               // byte offset of the topic inside an n_wk row (unused slot: topic 0, never live)
+            live_m[r] = __builtin_amdgcn_ballot_w64(used);
         }
 
         MVHDP_TSEG(tp);
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 o = 0.0; dn = 1.0;
                 const int i = lane * R_eff + r;
                 if (r < R_eff && i < S_used) {
-                    const int k = skr[r] & 0x7fffffff;
+                    const int k = koff[r] >> 2;
                     double acc = 0.0;
                     for (int j = 0; j < M; j++) {
                         if (j == m) continue;
@@ -274,6 +279,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 
             const int64_t base = mm.doc_off[m][d];
             const int64_t row0 = mm.rowbase[m];
+            const char* nwk_v = (const char*)(nwk + row0 * K);           // the view's rows of the counts, and of their 16-bit mirror
+            const char* nwk16_v = (const char*)(nwk16 + row0 * K);
+            int koffh[RMAX];                                             // (the slot's byte offset inside a mirror row)
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) koffh[r] = koff[r] >> 1;
             const int Vm = mm.V[m];
             const double walk_theta = sl.walk_theta[m];
             const unsigned int v_tok0 = n_tok, v_tree0 = c_tree;
@@ -364,31 +374,42 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 // own latency is what counts; one where six waves hide it and registers are what counts.
                 constexpr int NB = (RMAX >= 4) ? 2 : 1;
                 int gn[RMAX], gn2[RMAX];
+                // The loop visits the chunk's tokens of known types only, in position order, off a scalar mask: a token of a type
+                // outside the vocabulary (WRK:427-428 skips it) is counted here and never enters the loop -- no path through the loop body
+                // leaves the slot registers untouched, which is what lets the compiler update them in place.
+                unsigned long long rem = __ballot(tvalid && w_l >= 0);
+                n_oov += (unsigned int)__popcll(__ballot(tvalid && w_l < 0));
+                const int t_first = rem ? (int)__builtin_ctzll(rem) : 0;
 #pragma unroll
                 for (int a = 0; a < NB; a++) {
-                    const int w0 = bcast_i(w_l, min(a, nt - 1));
-                    const int64_t r0 = row0 + W_ROW(max(w0, 0));
+                    const unsigned long long ra = (a == 0) ? rem : (rem & (rem - 1));
+                    const int w0 = bcast_i(w_l, ra ? (int)__builtin_ctzll(ra) : t_first);
+                    const unsigned int r0 = (unsigned int)W_ROW(max(w0, 0));
                     const bool h0 = w0 >= 0 && (w0 & W_HEAVY);
-                    const char* __restrict__ c0p = (const char*)(nwk + r0 * K);
-                    const char* __restrict__ c0q = (const char*)(nwk16 + r0 * K);
+                    if (NARROW && !h0) {
+                        const gptr_t c0q = scalar_row(nwk16_v, r0, (unsigned int)K * 2u);
 #pragma unroll
-                    for (int r = 0; r < RMAX; r++) {
-                        int v;
-                        if (NARROW && !h0) v = (int)*(const uint16_t*)(c0q + (koff[r] >> 1));
-                        else v = (NB == 2 || r < R_eff) ? *(const int32_t*)(c0p + koff[r]) : 0;
-                        if (a == 0) gn[r] = v; else gn2[r] = v;
+                        for (int r = 0; r < RMAX; r++) { const int v = (int)*(const __attribute__((address_space(1))) uint16_t*)(c0q + (unsigned int)koffh[r]); if (a == 0) gn[r] = v; else gn2[r] = v; }
+                    } else {
+                        const gptr_t c0p = scalar_row(nwk_v, r0, (unsigned int)K * 4u);
+#pragma unroll
+                        for (int r = 0; r < RMAX; r++) { const int v = *(const __attribute__((address_space(1))) int32_t*)(c0p + (unsigned int)koff[r]); if (a == 0) gn[r] = v; else gn2[r] = v; }
                     }
                 }
 
-                for (int t = 0; t < nt; t += NB) {                          // WRK:425
+                while (rem) {                                               // WRK:425
+                    const int t = (int)__builtin_ctzll(rem);
+                    rem &= rem - 1;
 #define TOK_T t
 #define TOK_G gn
 #include "mvhdp_sweep_fast_token.inc"
 #undef TOK_T
 #undef TOK_G
                     if (aborted) break;
-                    if (NB == 2 && t + 1 < nt) {
-#define TOK_T (t + 1)
+                    if (NB == 2 && rem) {
+                        const int t1 = (int)__builtin_ctzll(rem);
+                        rem &= rem - 1;
+#define TOK_T t1
 #define TOK_G gn2
 #include "mvhdp_sweep_fast_token.inc"
 #undef TOK_T

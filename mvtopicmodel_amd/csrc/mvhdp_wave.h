@@ -24,6 +24,35 @@ __device__ __forceinline__ float bcast_f(float v, int src_lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src_lane)));
 }
 
+// v with lane `lane` (wave-uniform) set to `val` (wave-uniform): one v_writelane_b32 instead of a compare and a select.  This clang has
+// no builtin for it; the lane select goes through M0 (two different SGPR operands would exceed the constant-bus limit of the
+// encoding).  M0 is not saved: the compiler treats it as reserved and only ever loads it immediately before an instruction that
+// reads it (none in these kernels: `grep m0` on the listing of `make asmfast` shows these sequences only), and the scalar unit,
+// which these moves run on, is as busy as the vector unit in the token loop.
+__device__ __forceinline__ int wave_writelane(int v, int val, int lane)
+{
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "v_writelane_b32 %0, %1, m0"
+                 : "+v"(v) : "s"(val), "s"(lane));
+    return v;
+}
+// The address of a row of a table: base + index * row_bytes with a 32 x 32 -> 64-bit scalar multiply (two scalar instructions instead of
+// the five of a 64-bit one), handed on through an empty asm so that the compiler keeps it a scalar base: the per-lane part of a gather's
+// address is then the 32-bit offset operand of the load (global_load ..., v_off, s[base]) -- no vector address arithmetic, no 64-bit
+// per-lane pointers held in registers.
+typedef const __attribute__((address_space(1))) char* gptr_t;          // a pointer known to be to global memory (global_load, not flat_load)
+__device__ __forceinline__ gptr_t scalar_row(const char* base, unsigned int index, unsigned int row_bytes)
+{
+    unsigned long long a = (unsigned long long)base + (unsigned long long)index * row_bytes;
+    unsigned int lo = (unsigned int)a, hi = (unsigned int)(a >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (gptr_t)(((unsigned long long)hi << 32) | lo);
+}
+// ... and the per-lane 32-bit offset that goes with it: the empty asm keeps its zero-extension next to the load (hoisted out of the
+// loop it would come back as a 64-bit register pair and a vector add per load).
+// (The asm "touches" the caller's register in place -- no copy; once per token, on every path, or the two sides of a branch would
+// disagree about the register and a copy would reconcile them.)
+__device__ __forceinline__ void touch_lane_off(int& byte_offset) { asm volatile("" : "+v"(byte_offset)); }
 __device__ __forceinline__ double uniform_d(double x)
 {
     const long long b = __double_as_longlong(x);
