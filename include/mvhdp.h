@@ -263,7 +263,7 @@ int mvhdp_get_view_weights(mvhdp_handle h, double* p /*[D][M][M]*/);
  * (mvhdp_get_tuning) and hand them to another -- a document shard, a resumed chain -- and it does not search again. */
 typedef struct {
     int32_t force_primary;                       /* 0: the library chooses; 1,2,4,8,16: primary register variant; 32: generic kernel only */
-    int32_t narrow;                              /* -1: 16-bit mirror of n_wk wherever legal (default); 0: never */
+    int32_t narrow;                              /* -1: 16-bit mirror of n_wk wherever legal (default); 0: never; 1: for the 1-round kernel variant only */
     int32_t walk_fixed;                          /* 1: walk_theta[] as given, no search */
     int32_t single_stream;                       /* 1: all class kernels on the handle's stream (diagnostics) */
     int32_t live16;                              /* MVHDP_SWEEP_LIVE keeps the light n_wk rows current in the 16-bit mirror (half-width gathers): -1 where K >= 256 (default), 0 never, 1 always */

@@ -118,12 +118,12 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax);
 // The tuning block (include/mvhdp.h mvhdp_tuning): what a host may pin, and what the library has learnt
 struct PlanTuning {
     int force_primary = 0;                      // 0: choose; 1, 2, 4, 8, 16: the primary variant; 32: the generic kernel for everything
-    int narrow = -1;                            // -1: whenever legal; 0: never
+    int narrow = -1;                            // -1: whenever legal; 0: never; 1: the 1-round variant only
     int walk_fixed = 0;                         // 1: walk_theta below as it stands, no search
     double walk_theta[MVHDP_MAXM] = {0};
     double primary_min_share = 0.10;            // the narrowest class holding at least this share of the tokens gets its own (primary) kernel
     int single_stream = 0;                      // 1: every class kernel on the handle's stream, one after another (diagnostics)
-    int narrow_wide = 0;                        // 1: deferred sweeps gather from the mirror in the wider variants too (experiment)
+    int narrow_wide = 1;                        // 1: deferred sweeps gather from the mirror in the wider variants too (0: the 1-round variant only)
     int fork_delay_us = 0;                      // microseconds the handle's stream is held between the fork event and the primary kernel (0: none)
     int widest_on_main = 0;                     // 1: the widest class on the handle's stream, the primary on a side stream (diagnostics)
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
@@ -446,7 +446,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // every gathered row.  Needs the mirror to be this sweep's start counts: trees built in this call or still current.  A live sweep
     // keeps the mirror current itself (packed 16-bit atomics, see sweep_fast_kernel's LIVE16 path).
     if (mirror_ok && !p.live && p.cls[0].used && p.cls[0].fast && p.cls[0].walk) p.cls[0].narrow = 1;
-    if (mirror_ok && !p.live && tu.narrow_wide)                        // experiment: the wider variants on the mirror too
+    if (mirror_ok && !p.live && tu.narrow_wide && tu.narrow != 1)                      // the wider variants too (since the row's weight class travels with the type id: 1 % on C4)
         for (int c = 1; c < 5; c++) if (p.cls[c].used && p.cls[c].fast && p.cls[c].walk) p.cls[c].narrow = 1;
     // A live sweep updates n_wk while it samples: the mirror stays usable only if the sweep's own atomics keep it current, which takes
     // every kernel of the sweep in the NARROW (hence walk) flavour -- no generic kernel among them.

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     const int32_t* nk_all = mm.counts + mm.rowbase[M] * K;
     int32_t* dnwk = mm.delta;
 
-    unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_doc = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0, n_od = 0;
+    unsigned int n_tok = 0, n_chg = 0, c_new = 0, c_tree = 0, n_oov = 0, n_abort = 0, n_fb = 0, n_od = 0;
 
     // work queue: each wave pulls MVHDP_DOC_BATCH entities at a time from one global head
     const long long q_n1 = sl.q_list_count ? (long long)*sl.q_list_count : 0;
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 // leaves the slot registers untouched, which is what lets the compiler update them in place.
                 unsigned long long rem = __ballot(tvalid && w_l >= 0);
                 n_oov += (unsigned int)__popcll(__ballot(tvalid && w_l < 0));
+                n_tok += (unsigned int)__popcll(rem);                       // (counted here, not per token; an abandoned entity fails the sweep anyway)
                 const int t_first = rem ? (int)__builtin_ctzll(rem) : 0;
 #pragma unroll
                 for (int a = 0; a < NB; a++) {
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         if (n_tok) atomicAdd(&sl.stats[ST_TOKENS], (unsigned long long)n_tok);
         if (n_chg) atomicAdd(&sl.stats[ST_CHANGED], (unsigned long long)n_chg);
         if (c_new) atomicAdd(&sl.stats[ST_NEW], (unsigned long long)c_new);
+        const unsigned int c_doc = n_tok - c_new - c_tree;              // (the common branch is not counted per token)
         if (c_doc) atomicAdd(&sl.stats[ST_DOC], (unsigned long long)c_doc);
         if (c_tree) atomicAdd(&sl.stats[ST_TREE], (unsigned long long)c_tree);
         if (n_oov) atomicAdd(&sl.stats[ST_OOV], (unsigned long long)n_oov);

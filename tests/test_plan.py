@@ -53,7 +53,7 @@ def test_c4_early_chain_two_round_primary_and_a_four_round_class_beside_it():
     assert list(po.class_map)[:3] == [1, 1, 2]
     assert po.routed_prefix == 900_000                                      # entities with more than 128 tokens
     assert po.class_stream[1] == 0 and po.class_stream[2] == 3              # primary on the handle's stream, the wider class beside it
-    assert po.class_narrow[1] == 0
+    assert po.class_narrow[1] == po.class_walk[1]                           # the mirror goes with the walk flavour, whatever the variant
     assert po.class_grid[1] == 256 * 6                                      # 80 VGPRs: 6 waves per SIMD = 6 blocks of 4 waves per CU
 
 
@@ -64,7 +64,10 @@ def test_c4_settling_chain_one_round_primary_with_the_mirror():
     assert list(po.class_used) == [1, 1, 1, 0, 0, 0]
     assert po.routed_prefix == 1_000_000                                    # every entity has more than 64 tokens
     assert po.class_walk[0] == 1 and po.class_narrow[0] == 1 and po.class_theta0[0] == 0.5
-    assert po.class_narrow[1] == 0                                          # the mirror is the 1-round walk flavour's
+    assert po.class_narrow[1] == po.class_walk[1] and po.class_narrow[2] == po.class_walk[2]
+    p1 = probe(tok=[80_000_000, 66_000_000, 1_000_000], ent=[550_000, 449_000, 1_000, 0, 0, 0, 0, 0],
+               tuning=dict(walk_fixed=1, walk_theta=[0.5, 0.0, 0.0], narrow=1))
+    assert p1.class_narrow[0] == 1 and p1.class_narrow[1] == 0              # narrow = 1: the mirror for the 1-round variant only
     assert po.class_stream[0] == 0 and po.class_stream[1] == 3 and po.class_stream[2] == 3
     assert po.class_grid[0] == 256 * 7                                      # 72 VGPRs: 7 waves per SIMD
     # a live sweep cannot use the snapshot mirror; nor a sweep that re-uses trees which are not current
