@@ -400,24 +400,23 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 
                 while (rem) {                                               // WRK:425
                     const int t = (int)__builtin_ctzll(rem);
-                    rem &= rem - 1;
+                    rem &= ~(1ull << t);
 #define TOK_T t
 #define TOK_G gn
 #include "mvhdp_sweep_fast_token.inc"
 #undef TOK_T
 #undef TOK_G
-                    if (aborted) break;
                     if (NB == 2 && rem) {
                         const int t1 = (int)__builtin_ctzll(rem);
-                        rem &= rem - 1;
+                        rem &= ~(1ull << t1);
 #define TOK_T t1
 #define TOK_G gn2
 #include "mvhdp_sweep_fast_token.inc"
 #undef TOK_T
 #undef TOK_G
-                        if (aborted) break;
                     }
                 }
+            tokens_done:                                                    // (an abandoned entity jumps here with `aborted` set)
 
                 MVHDP_TSEG(tt);
                 // WRK:587-589 + UPD:197-218 for the whole chunk at once: lane t owns token t (old topic z_l,
