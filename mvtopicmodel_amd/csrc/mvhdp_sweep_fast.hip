@@ -51,6 +51,9 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #ifndef MVHDP_LB4
 #define MVHDP_LB4 4
 #endif
+#ifndef MVHDP_LB16
+#define MVHDP_LB16 1
+#endif
 #ifndef MVHDP_LB8
 #define MVHDP_LB8 1          // 3 waves/SIMD (168 VGPRs) spills 100 B/lane and is 13 % slower on C5 than 2 waves at 199
 #endif
@@ -68,7 +71,7 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #define W_HEAVY 0x40000000                      // bit 30 of a lane's type id: the row is heavy (type ids stay below 2^30: mvhdp_create checks)
 #define W_ROW(w) ((w) & 0x3fffffff)
 template <int RMAX, bool DEBUG, bool WALK, bool NARROW>
-__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : 1))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;

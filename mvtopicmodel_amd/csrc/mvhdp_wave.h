@@ -31,6 +31,8 @@ __device__ __forceinline__ float bcast_f(float v, int src_lane)
 // which these moves run on, is as busy as the vector unit in the token loop.
 __device__ __forceinline__ int wave_writelane(int v, int val, int lane)
 {
+    val = __builtin_amdgcn_readfirstlane(val);           // (free where the compiler knows the value to be uniform; where it does not, this is
+    lane = __builtin_amdgcn_readfirstlane(lane);         // what makes it a scalar register -- the "s" constraint alone does not)
     asm volatile("s_mov_b32 m0, %2\n\t"
                  "v_writelane_b32 %0, %1, m0"
                  : "+v"(v) : "s"(val), "s"(lane));
