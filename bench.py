@@ -27,6 +27,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def physical_bound_note():
+    """What the dominant kernel is bound by, from the committed SQ counters of the settled C4 kernel (profiles/pmc_r03_sq.sh)."""
+    note = ("the fixed-byte HBM yardstick of SURVEY 8d is nominal (it assumes 4-byte counts; the kernels gather 2-byte ones, so frac can "
+            "exceed 1): the sweep kernel is bound by instruction issue, not by memory")
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r03_c4_sq_counters_settled.json")))
+        per = lambda k: sq[k]["per_token"]
+        simd = per("SQ_WAVE_CYCLES") / 7.0                       # quad-cycles of a SIMD per token at 7 waves per SIMD
+        note += (f" -- settled 1-round kernel: {per('SQ_INSTS_VALU'):.0f} vector + {per('SQ_INSTS_SALU'):.0f} scalar instructions per token, "
+                 f"vector unit {100 * per('SQ_ACTIVE_INST_VALU') / simd:.0f} % and scalar unit {100 * per('SQ_ACTIVE_INST_SCA') / simd:.0f} % busy "
+                 f"({sum(sq['kernel_ms_last8']) / 8:.1f} ms per launch; profiles/r03_c4_sq_counters_settled.json)")
+    except Exception:
+        pass
+    return note
+
+
 def algorithmic_bytes_per_token(K):
     """one int32 n_wk row + token id + old assignment."""
     return 4 * K + 8
@@ -308,9 +324,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "sweep kernels of one mvhdp_sweep (dominant: sweep_fast_kernel<R>)", "bytes_per_token": bpt, "tokens_per_launch": local_tokens,
-                     "physical_bound_note": "the fixed-byte HBM yardstick of SURVEY 8d is nominal: the settled kernel gathers 2-byte counts and is "
-                                            "vector-ALU issue bound (SQ_ACTIVE_INST_VALU 94 % of the SIMD cycles, 102 VALU instructions per token: "
-                                            "profiles/r03_c4_sq_counters_settled.json), 5.2 G tokens/s whatever K",
+                     "physical_bound_note": physical_bound_note(),
                      "avg_kernel_ms": avg_kernel_s * 1e3},
         "sweep": {"changed_frac": last.changed / max(1, last.tokens),
                   "branch_frac": {"new": last.new_mass_cnt / max(1, last.tokens),
