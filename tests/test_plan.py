@@ -96,6 +96,18 @@ def test_every_kernel_flavour_has_its_own_walk_threshold():
     assert po.class_theta0[0] == 0.0 and po.class_walk[0] == 0                               # short rows: latency-bound, plain flavour
 
 
+def test_long_rows_take_the_mirror_even_when_no_view_is_steered():
+    """C5: K = 1000, the tree branch takes 44 % of the tokens, so no view has a walk threshold -- but a row of the counts is 4 KB, and
+    the 16-bit mirror (the walk flavour's) halves the lines of every gather: 51.9 against 64.4 ms per sweep."""
+    known = dict(tree_branch_share=[0.44, 0.45, 0.45, 0.45, 0.45])
+    kw = dict(K=1000, M=5, tok=[30_000_000, 40_000_000, 20_000_000, 20_000_000], ent=[400_000, 400_000, 150_000, 50_000, 0, 0, 0, 0])
+    po = probe(tuning=known, **kw)
+    used = [c for c in range(5) if po.class_used[c]]
+    assert used and all(po.class_walk[c] == 1 and po.class_narrow[c] == 1 and po.class_theta0[c] == 0.0 for c in used)
+    po = probe(tuning=dict(narrow=0, **known), **kw)
+    assert all(po.class_narrow[c] == 0 for c in used)
+
+
 def test_empty_classes_are_not_launched_unless_the_sizes_can_move():
     kw = dict(tok=[146_000_000, 1_000_000], ent=[990_000, 10_000, 0, 0, 0, 0, 0, 0])
     po = probe(**kw)
