@@ -34,6 +34,7 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 {
     size_t counts = (size_t)M * S_cap * (rmax >= 8 ? 2 : 4);
     size_t b = (size_t)(64 + 64 + 64 + 16 + S_cap) * 4 + counts;      // bitmap, prefix, bitmap of the new assignments, wlen, sk
+    b += (size_t)M * M * 12;                                           // per-entity view-pair constants: M*M doubles (qsh) + M*M floats (wsh)
     return (b + 15) & ~(size_t)15;
 }
 
@@ -99,7 +100,13 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     uint32_t* prefix = bitmap + 64;
     uint32_t* bitmap2 = prefix + 64;                       // topics of the entity's NEW assignments (MvModel::nslots)
     int* wlen = (int*)(bitmap2 + 64);
-    int* sk = wlen + 16;
+    // per-entity constants of the view pairs (m, j), formed once per entity with one lane per pair instead of once per view and slot:
+    //   qsh[m*M+j] = p[m][j] * gamma_j * alpha_j[K] / (len_j + gamma_j * alphaSum_j)     the terms of WRK:413-418, in fp64
+    //   wsh[m*M+j] = p[m][j] / (len_j + gamma_j * alphaSum_j)  (0 for j == m or an empty view)   the weights of WRK:399-410, rounded to
+    //                fp32: what the fp32 screening forms totalMassOtherModalities from (the fp64 path forms it exactly, slot_consts)
+    double* qsh = (double*)(wlen + 16);
+    float* wsh = (float*)(qsh + M * M);
+    int* sk = (int*)(wsh + M * M);
     constexpr bool PACK = RMAX >= 8;                       // per-view slot counts as 16-bit values
     // fp32 screening of the token loop's decisions (mvhdp_sweep_fast_token.inc): two more registers per slot, so not for the
     // 8- and 16-round variants, which sit at their register limit; the debug flavour reports fp64 masses and decides in fp64
@@ -214,8 +221,16 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             live_m[r] = __builtin_amdgcn_ballot_w64(used);
         }
 
-        MVHDP_TSEG(tp);
         const double* pd = (M > 1) ? (mm.p + d * M * M) : nullptr;        // WRK:327-337
+        if (lane < M * M) {                                               // (M <= 8: one lane per view pair)
+            const int pm = lane / M, pj = lane - pm * M;
+            const double dd = (double)wlen[pj] + mm.gamma[pj] * mm.alpha_sum[pj];
+            const double pmj = pd ? pd[lane] : 1.0;
+            qsh[lane] = pmj * (mm.gamma[pj] * mm.alpha[(int64_t)pj * (K + 1) + K]) / dd;          // WRK:416, operation for operation
+            wsh[lane] = (pj != pm && wlen[pj] != 0) ? (float)(pmj / dd) : 0.0f;
+        }
+        LDS_FENCE();
+        MVHDP_TSEG(tp);
         bool aborted = false;
 
         for (int m = 0; m < M && !aborted; m++) {                         // WRK:393
@@ -252,29 +267,44 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 }
             };
             float rden32[RMAX], brden32[RMAX], oth32[RMAX];      // the fp32 forms the screening works with: 1/den, beta/den, oth
-            const float beta32 = (float)beta_m;
+            const float beta32 = (float)beta_m, scale32 = (float)scale_m;
 #pragma unroll
             for (int r = 0; r < RMAX; r++) {
                 cn[r] = 0;
                 const int i = lane * R_eff + r;
-                if (r < R_eff && i < S_used) {
-                    cn[r] = sn_get(m * S + i);
-                    for (int j = 0; j < M; j++) if (j != m && sn_get(j * S + i) != 0) onz |= 1u << r;
+                const bool used = r < R_eff && i < S_used;
+                if (SCREEN) {
+                    // fp32 forms directly: a division per slot and other view (30 instructions) becomes a multiply-add with the pair's
+                    // weight -- on a corpus whose side views hold a handful of tokens (C5) this setup was a fifth of the wave's time
+                    float acc = 0.0f;
+                    double dn = 1.0;
+                    if (used) {
+                        const int k = koff[r] >> 2;
+                        cn[r] = sn_get(m * S + i);
+                        for (int j = 0; j < M; j++) {
+                            if (j == m) continue;
+                            const int cj = sn_get(j * S + i);
+                            if (cj != 0) onz |= 1u << r;
+                            acc = __builtin_fmaf(wsh[m * M + j], (float)cj + (float)(mm.gamma[j] * mm.alpha[(int64_t)j * (K + 1) + k]), acc);
+                        }
+                        dn = (double)nk[k] + mm.beta_sum[m];
+                    }
+                    oth[r] = 0.0; den[r] = 1.0;
+                    rden32[r] = __builtin_amdgcn_rcpf((float)dn);
+                    brden32[r] = beta32 * rden32[r];
+                    oth32[r] = acc * scale32;
+                } else {
+                    if (used) {
+                        cn[r] = sn_get(m * S + i);
+                        for (int j = 0; j < M; j++) if (j != m && sn_get(j * S + i) != 0) onz |= 1u << r;
+                    }
+                    slot_consts(r, oth[r], den[r]);
+                    rden32[r] = 0.0f; brden32[r] = 0.0f; oth32[r] = 0.0f;
                 }
-                double o, dn;
-                slot_consts(r, o, dn);
-                oth[r] = SCREEN ? 0.0 : o;
-                den[r] = SCREEN ? 1.0 : dn;
-                rden32[r] = SCREEN ? __builtin_amdgcn_rcpf((float)dn) : 0.0f;
-                brden32[r] = beta32 * rden32[r];
-                oth32[r] = SCREEN ? (float)o : 0.0f;
             }
-            // WRK:413-418 newTopicMassAllModalities
+            // WRK:413-418 newTopicMassAllModalities (the terms were formed with the entity's view pairs, summed here in the reference's order)
             double newAll = 0.0;
-            for (int j = 0; j < M; j++) {
-                double pmj = pd ? pd[m * M + j] : 1.0;
-                newAll += pmj * (mm.gamma[j] * mm.alpha[(int64_t)j * (K + 1) + K]) / ((double)wlen[j] + mm.gamma[j] * mm.alpha_sum[j]);
-            }
+            for (int j = 0; j < M; j++) newAll += qsh[m * M + j];
             newAll = newAll * scale_m;
             const double newMass = (mm.first_inactive < 0) ? 0.0 : newAll / (double)K;   // WRK:515
             // the fp32 copies the screening works with (wave-uniform ones as scalars)
