@@ -922,6 +922,11 @@ static void learn_from_sweep(mvhdp_ctx* h, const SweepPlan& p, const unsigned lo
                     100.0 * hs[ST_T_QUEUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_PROLOGUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_VIEW] / hs[ST_T_TOTAL],
                     100.0 * hs[ST_T_CHUNK_HEAD] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_TOKENS] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_CHUNK_END] / hs[ST_T_TOTAL],
                     (double)hs[ST_T_TOTAL] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
+        if (hs[ST_N_WAVES])
+            fprintf(stderr, "[mvhdp] cycles per token in a wave's first / second / later entities: %.0f / %.0f / %.0f (tokens %llu / %llu / %llu); per wave: block init %.0f cycles, wait + flush at the end %.0f, whole wave %.0f\n",
+                    (double)hs[ST_T_ENT0] / std::max<double>(1.0, (double)hs[ST_N_ENT0]), (double)hs[ST_T_ENT1] / std::max<double>(1.0, (double)hs[ST_N_ENT1]),
+                    (double)hs[ST_T_ENT2] / std::max<double>(1.0, (double)hs[ST_N_ENT2]), hs[ST_N_ENT0], hs[ST_N_ENT1], hs[ST_N_ENT2],
+                    (double)hs[ST_T_INIT] / hs[ST_N_WAVES], (double)hs[ST_T_FLUSH] / hs[ST_N_WAVES], (double)hs[ST_T_TOTAL] / hs[ST_N_WAVES]);
     }
     const double tokens = (double)hs[ST_TOKENS];
     h->wt.observe(comparable && tokens > 0, p.walk_cfg, mm.M, tokens > 0 ? kernel_ms * 1e6 / tokens : 0.0);

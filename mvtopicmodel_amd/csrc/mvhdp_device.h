@@ -100,7 +100,9 @@ enum {
     // in MVHDP_WALK_BINS bins -- what a walk threshold would cost in walks on demand (mvhdp_sweep's threshold search)
     ST_VIEW_BASE, ST_VIEW_LAST = ST_VIEW_BASE + MVHDP_VIEW_STATS * MVHDP_MAXM - 1,
     // wave cycles by segment, summed over waves; filled only by a -DMVHDP_TIMING build (diagnostics)
-    ST_T_QUEUE, ST_T_PROLOGUE, ST_T_VIEW, ST_T_CHUNK_HEAD, ST_T_TOKENS, ST_T_CHUNK_END, ST_T_TOTAL, ST_COUNT
+    ST_T_QUEUE, ST_T_PROLOGUE, ST_T_VIEW, ST_T_CHUNK_HEAD, ST_T_TOKENS, ST_T_CHUNK_END, ST_T_TOTAL,
+    ST_T_ENT0, ST_T_ENT1, ST_T_ENT2, ST_N_ENT0, ST_N_ENT1, ST_N_ENT2, ST_T_INIT, ST_T_FLUSH, ST_N_WAVES,   // (timing build: a wave's first, second, later entities; block init and flush)
+    ST_COUNT
 };
 
 size_t mvhdp_sweep_wave_bytes(int M, int S_cap);

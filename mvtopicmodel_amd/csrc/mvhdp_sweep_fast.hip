@@ -75,6 +75,9 @@ template <int RMAX, bool DEBUG, bool WALK, bool NARROW>
 __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MVHDP_TIMING
+    const unsigned long long t_begin0 = __builtin_amdgcn_s_memtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = uniform_i(threadIdx.x >> 6);
     const int K = mm.K, M = mm.M, S = sl.S_cap;
@@ -94,6 +97,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS + MVHDP_ENT_BINS + (WALK ? MVHDP_MAXM * MVHDP_VIEW_STATS : 0); i += blockDim.x) nkd[i] = 0;
     int32_t* const dnk_g = mm.delta + mm.rowbase[M] * K;    // n_k part of the delta buffer
     __syncthreads();
+#ifdef MVHDP_TIMING
+    const unsigned long long t_init_end = __builtin_amdgcn_s_memtime();
+#endif
 
     unsigned char* wb = smem + sl.block_shared_bytes + (size_t)wave * sl.wave_bytes;
     uint32_t* bitmap = (uint32_t*)wb;
@@ -129,7 +135,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     unsigned int n_misclass = 0;
 #ifdef MVHDP_TIMING
     // diagnostics: where a wave's cycles go (s_memtime stamps at the segment borders; the stamps cost ~10 %)
-    unsigned long long tq = 0, tp = 0, tv = 0, th = 0, tt = 0, te = 0;
+    unsigned long long tq = 0, tp = 0, tv = 0, th = 0, tt = 0, te = 0, t_ent[3] = {0, 0, 0}, n_ent[3] = {0, 0, 0};
+    int e_ord = 0;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     unsigned long long t_last = t_begin;
 #define MVHDP_TSEG(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - t_last; t_last = now_; } while (0)
@@ -152,6 +159,10 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         if (q < q_n1) d = (int64_t)sl.q_list[q];
         else { const int64_t o = sl.q_order_start + (q - q_n1) * sl.q_order_stride; d = sl.q_order ? (int64_t)sl.q_order[o] : o; }
         const int64_t dg = mm.doc_id_base + d;
+#ifdef MVHDP_TIMING
+        const unsigned long long t_e0 = __builtin_amdgcn_s_memtime();
+        const unsigned int n_tok_e0 = n_tok;
+#endif
 
         MVHDP_TSEG(tq);
         // ---- WRK:339-391: gather the entity's topics into the slot list ----
@@ -515,9 +526,15 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             }
         }
         LDS_FENCE();
+#ifdef MVHDP_TIMING
+        { const int b = e_ord < 2 ? e_ord : 2; t_ent[b] += __builtin_amdgcn_s_memtime() - t_e0; n_ent[b] += n_tok - n_tok_e0; e_ord++; }
+#endif
       }
     }
 
+#ifdef MVHDP_TIMING
+    const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
     for (int i = threadIdx.x; i < nkd_len; i += blockDim.x)
         if (nkd[i]) atomicAdd(&dnk_g[i], nkd[i]);
@@ -540,6 +557,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         atomicAdd(&sl.stats[ST_T_QUEUE], tq); atomicAdd(&sl.stats[ST_T_PROLOGUE], tp); atomicAdd(&sl.stats[ST_T_VIEW], tv);
         atomicAdd(&sl.stats[ST_T_CHUNK_HEAD], th); atomicAdd(&sl.stats[ST_T_TOKENS], tt); atomicAdd(&sl.stats[ST_T_CHUNK_END], te);
         atomicAdd(&sl.stats[ST_T_TOTAL], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+        for (int b = 0; b < 3; b++) { atomicAdd(&sl.stats[ST_T_ENT0 + b], t_ent[b]); atomicAdd(&sl.stats[ST_N_ENT0 + b], n_ent[b]); }
+        atomicAdd(&sl.stats[ST_T_INIT], t_init_end - t_begin0); atomicAdd(&sl.stats[ST_T_FLUSH], (unsigned long long)__builtin_amdgcn_s_memtime() - t_loop_end);
+        atomicAdd(&sl.stats[ST_N_WAVES], 1ull);
 #endif
     }
 }
