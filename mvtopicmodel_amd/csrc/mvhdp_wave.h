@@ -27,7 +27,7 @@ __device__ __forceinline__ float bcast_f(float v, int src_lane)
 // v with lane `lane` (wave-uniform) set to `val` (wave-uniform): one v_writelane_b32 instead of a compare and a select.  This clang has
 // no builtin for it; the lane select goes through M0 (two different SGPR operands would exceed the constant-bus limit of the
 // encoding).  M0 is not saved: the compiler treats it as reserved and only ever loads it immediately before an instruction that
-// reads it (none in these kernels: `grep m0` on the listing of `make asmfast` shows these sequences only), and the scalar unit,
+// reads it (none in these kernels: tests/test_abi.py disassembles the built library and fails on any other mention of m0), and the scalar unit,
 // which these moves run on, is as busy as the vector unit in the token loop.
 __device__ __forceinline__ int wave_writelane(int v, int val, int lane)
 {

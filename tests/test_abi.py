@@ -98,3 +98,37 @@ def test_one_hip_runtime_whatever_is_loaded_first():
         "print('one runtime', m['libamdhip64'][0])\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "one runtime" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_m0_is_touched_by_the_lane_write_sequences_only(tmp_path):
+    """wave_writelane (csrc/mvhdp_wave.h) moves the lane select through M0 in inline assembly without saving it: that is sound only
+    while the compiler itself never keeps a value in M0 in these kernels.  Disassemble the device code of the built library and check
+    that every mention of m0 is `s_mov_b32 m0, sN` immediately followed by `v_writelane_b32 vN, sM, m0`."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [shutil.which("objcopy"), os.path.join(llvm, "clang-offload-bundler"), os.path.join(llvm, "llvm-objdump")]
+    if not all(t and os.path.exists(t) for t in tools):
+        pytest.skip("binutils / ROCm LLVM tools not available")
+    lib = os.path.join(ROOT, "mvtopicmodel_amd", "lib", "libmvhdp.so")
+    fat = tmp_path / "fat.bin"
+    subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", lib, str(fat)], check=True)
+    data = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+    assert starts, "no offload bundle in the library"
+    seen = 0
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(data)])):
+        blob, co = tmp_path / f"b{n}.bin", tmp_path / f"d{n}.co"
+        blob.write_bytes(data[a:b])
+        subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={blob}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        text = subprocess.run([tools[2], "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        ins = [l.split("//")[0].strip() for l in text.split("\n") if "//" in l]
+        for i, l in enumerate(ins):
+            if not re.search(r"\bm0\b", l):
+                continue
+            seen += 1
+            if re.fullmatch(r"s_mov_b32 m0, s\d+", l):
+                assert i + 1 < len(ins) and re.fullmatch(r"v_writelane_b32 v\d+, s\d+, m0", ins[i + 1]), (l, ins[i + 1])
+            else:
+                assert re.fullmatch(r"v_writelane_b32 v\d+, s\d+, m0", l) and re.fullmatch(r"s_mov_b32 m0, s\d+", ins[i - 1]), l
+    assert seen > 0                                                          # (the sequences are there: the test looks at the right code)
