@@ -38,8 +38,8 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
     return (b + 15) & ~(size_t)15;
 }
 
-// Minimum waves per SIMD asked of the register allocator for each variant (measured on C4: the
-// 2-slot variant gains 5 % at 6 waves despite 64 B/lane of scratch and loses 15 % at 7).
+// Minimum waves per SIMD asked of the register allocator for each variant (measured on C4; the 2-slot variant lost 15 % at 7 waves
+// in round 2, when 72 registers meant heavy spilling -- with the round-3 token loop it gains 1.6 % there over 6).
 #ifndef MVHDP_LB1
 #define MVHDP_LB1 1          // the plain 1-slot variant allocates 70 VGPRs by itself (7 waves); bounding it costs 2 % on C2
 #endif
@@ -47,7 +47,7 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #define MVHDP_LB1W 7         // with the thresholded walk it would take 75 (6 waves): C3 loses 4 % there
 #endif
 #ifndef MVHDP_LB2
-#define MVHDP_LB2 6
+#define MVHDP_LB2 7
 #endif
 #ifndef MVHDP_LB4
 #define MVHDP_LB4 4
