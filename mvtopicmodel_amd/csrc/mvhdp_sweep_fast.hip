@@ -49,6 +49,9 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #ifndef MVHDP_LB2
 #define MVHDP_LB2 7
 #endif
+#ifndef MVHDP_LB2_ROOMY
+#define MVHDP_LB2_ROOMY 6
+#endif
 #ifndef MVHDP_LB4
 #define MVHDP_LB4 4
 #endif
@@ -71,8 +74,11 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 // mirror is what every later token of the sweep reads (UPD:197-207 applied while the workers sample), at half the gather traffic.
 #define W_HEAVY 0x40000000                      // bit 30 of a lane's type id: the row is heavy (type ids stay below 2^30: mvhdp_create checks)
 #define W_ROW(w) ((w) & 0x3fffffff)
-template <int RMAX, bool DEBUG, bool WALK, bool NARROW>
-__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? MVHDP_LB2 : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+// ROOMY (the 2-round variant on the mirror only): the same kernel compiled for 6 waves per SIMD (80 registers, a third of the scratch
+// of the 72-register build): where a row of the mirror is 1 KiB or more (K >= 512; C5: K = 1000) the seventh wave hides less than the
+// spills cost -- C5's 2-round kernel 16.9 ms at 6 waves, 18.4 at 7; C4's (K = 400) gains 2 % at 7.
+template <int RMAX, bool DEBUG, bool WALK, bool NARROW, bool ROOMY = false>
+__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? (ROOMY ? MVHDP_LB2_ROOMY : MVHDP_LB2) : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef MVHDP_TIMING
@@ -568,10 +574,15 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #undef sn_set
 
 // debug launches always take the WALK flavour (one instantiation fewer per variant; a threshold of 0 walks every token)
+static bool roomy_build(int rmax, int K) { return rmax == 2 && K >= 512; }
+
 template <int RMAX>
-static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow)
+static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow, int K = 0)
 {
-    if (narrow && walk && !debug) return (const void*)sweep_fast_kernel<RMAX, false, true, true>;
+    if (narrow && walk && !debug) {
+        if constexpr (RMAX == 2) { if (roomy_build(RMAX, K)) return (const void*)sweep_fast_kernel<2, false, true, true, true>; }
+        return (const void*)sweep_fast_kernel<RMAX, false, true, true>;
+    }
     return debug ? (const void*)sweep_fast_kernel<RMAX, true, true, false>
                  : walk ? (const void*)sweep_fast_kernel<RMAX, false, true, false> : (const void*)sweep_fast_kernel<RMAX, false, false, false>;
 }
@@ -583,10 +594,14 @@ static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid
     dim3 block(64 * sl.waves_per_block);
     const bool narrow = sl.narrow && sl.walk && !debug;
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0, narrow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0, narrow, mm.K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else if (narrow && roomy_build(RMAX, mm.K)) {
+        // (the plan sized the grid for the 72-register build: the seventh block of a CU waits for a free slot and finds the queue empty)
+        if constexpr (RMAX == 2) hipLaunchKernelGGL((sweep_fast_kernel<2, false, true, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+    }
     else if (narrow)  hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
     else if (sl.walk) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
     else              hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, false, false>), dim3(grid_blocks), block, lds, s, mm, sl);
