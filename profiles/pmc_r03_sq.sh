@@ -18,13 +18,13 @@ for d in ("a", "b"):
     agg = {}
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "sweep_fast_kernel<1, false, true, true>" in n:
+        if "sweep_fast_kernel<1, false, true, true" in n:
             agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in agg.items():
         v = v[-8:]
         out[k] = {"mean_per_launch": sum(v) / len(v), "per_token": sum(v) / len(v) / TOK}
 kt = glob.glob("$OUT/a/**/*kernel_trace.csv", recursive=True)[0]
-d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt)) if "sweep_fast_kernel<1, false, true, true>" in r["Kernel_Name"]]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt)) if "sweep_fast_kernel<1, false, true, true" in r["Kernel_Name"]]
 out["kernel_ms_last8"] = d[-8:]
 print(json.dumps(out, indent=1))
 open("$R/gpurun_out/r03_sq_summary.json", "w").write(json.dumps(out, indent=1))
