@@ -466,7 +466,6 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #undef TOK_G
                     }
                 }
-            tokens_done:                                                    // (an abandoned entity jumps here with `aborted` set)
 
                 MVHDP_TSEG(tt);
                 // WRK:587-589 + UPD:197-218 for the whole chunk at once: lane t owns token t (old topic z_l,
