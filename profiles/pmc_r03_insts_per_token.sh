@@ -1,4 +1,6 @@
-# usage: _sqw.sh WORKLOAD  -> VALU/SALU per token of the sweep kernels of the last sweeps
+#!/bin/bash
+# Round 3: vector / scalar / branch instructions per token of ALL sweep kernels of a 30-sweep chain from the random start, per workload
+# (one rocprofv3 --pmc pass with --kernel-trace only; GPU box, through gpurun):   bash profiles/pmc_r03_insts_per_token.sh C4
 R=$GRAFT_REPO_ROOT; W=$1
 OUT=$R/gpurun_out/sqw_$W
 mkdir -p $OUT
