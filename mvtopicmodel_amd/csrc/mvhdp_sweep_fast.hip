@@ -55,6 +55,9 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #ifndef MVHDP_LB4
 #define MVHDP_LB4 4
 #endif
+#ifndef MVHDP_NB2_FROM
+#define MVHDP_NB2_FROM 4     // variants with at least this many slots per lane gather two tokens ahead into two register buffers
+#endif
 #ifndef MVHDP_LB16
 #define MVHDP_LB16 1
 #endif
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 // register buffers used in turn (the token loop is unrolled NB times so that no buffer is ever
                 // copied while its load is in flight).  Two buffers where few waves share a SIMD and a wave's
                 // own latency is what counts; one where six waves hide it and registers are what counts.
-                constexpr int NB = (RMAX >= 4) ? 2 : 1;
+                constexpr int NB = (RMAX >= MVHDP_NB2_FROM) ? 2 : 1;
                 int gn[RMAX], gn2[RMAX];
                 // The loop visits the chunk's tokens of known types only, in position order, off a scalar mask: a token of a type
                 // outside the vocabulary (WRK:427-428 skips it) is counted here and never enters the loop -- no path through the loop body
