@@ -50,13 +50,12 @@ FastQMVWVParallelTopicModel::FastQMVWVParallelTopicModel(int numberOfTopics, int
 
 FastQMVWVParallelTopicModel::~FastQMVWVParallelTopicModel()
 {
-    if (h_) mvhdp_destroy(h_);
 }
 
 void FastQMVWVParallelTopicModel::check(int rc, const char* what)
 {
     if (rc != MVHDP_OK)
-        throw std::runtime_error(std::string(what) + ": " + mvhdp_last_error(h_) + " (code " + std::to_string(rc) + ")");
+        throw std::runtime_error(std::string(what) + ": " + dev_.lastError() + " (code " + std::to_string(rc) + ")");
 }
 
 void FastQMVWVParallelTopicModel::addInstances(const std::vector<InstanceList>& training, const std::string& batchId, int vectorSize)
@@ -130,16 +129,22 @@ void FastQMVWVParallelTopicModel::addInstances(const std::vector<InstanceList>& 
     for (int m = 0; m < M; m++)
         for (int c : typeTotals[m]) maxTypeCount[m] = std::max(maxTypeCount[m], c);
 
-    if (h_) { mvhdp_destroy(h_); h_ = nullptr; }
     mvhdp_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.num_topics = K; cfg.num_modalities = M; cfg.device = device_; cfg.doc_id_base = docIdBase_;
     for (int m = 0; m < M; m++) cfg.num_types[m] = numTypes[m];
-    int rc = mvhdp_create(&cfg, &h_);
-    if (rc != MVHDP_OK) throw std::runtime_error(std::string("mvhdp_create: ") + mvhdp_last_error(nullptr));
+    // one handle, or numShards_ document shards behind an mvhdp_group (device_model.h): contiguous entity ranges by token count
+    const int64_t D = (int64_t)data.size();
+    {
+        std::vector<int64_t> entityTokens((size_t)D, 0);
+        for (int64_t d = 0; d < D; d++)
+            for (int m = 0; m < M; m++) entityTokens[(size_t)d] += (int64_t)data[d].Assignments[m].tokens.size();
+        int rc = dev_.create(cfg, numShards_, entityTokens);
+        if (rc != MVHDP_OK) throw std::runtime_error(dev_.lastError());
+        h_ = dev_.first();
+    }
 
     // flatten MixTopicModelTopicAssignment -> CSR per view
-    const int64_t D = (int64_t)data.size();
     for (int m = 0; m < M; m++) {
         std::vector<int64_t> off(D + 1, 0);
         for (int64_t d = 0; d < D; d++) off[d + 1] = off[d] + (int64_t)data[d].Assignments[m].tokens.size();
@@ -149,12 +154,12 @@ void FastQMVWVParallelTopicModel::addInstances(const std::vector<InstanceList>& 
             std::copy(ta.tokens.begin(), ta.tokens.end(), tok.begin() + off[d]);
             std::copy(ta.topics.begin(), ta.topics.end(), z.begin() + off[d]);
         }
-        check(mvhdp_set_corpus(h_, m, D, off.data(), tok.data()), "mvhdp_set_corpus");
-        check(mvhdp_set_assignments(h_, m, z.data()), "mvhdp_set_assignments");
+        check(dev_.setCorpus(m, D, off.data(), tok.data()), "mvhdp_set_corpus");
+        check(dev_.setAssignments(m, z.data()), "mvhdp_set_assignments");
     }
     pushHyper();
-    check(mvhdp_build_counts(h_), "mvhdp_build_counts");              // PTM:529
-    check(mvhdp_build_trees(h_), "mvhdp_build_trees");                // PTM:531
+    check(dev_.buildCounts(), "mvhdp_build_counts");              // PTM:529
+    check(dev_.buildTrees(), "mvhdp_build_trees");                // PTM:531
     syncFromDevice(true);
 }
 
@@ -194,7 +199,7 @@ void FastQMVWVParallelTopicModel::pushHyper()
         hy.alpha_sum[m] = alphaSum[m]; hy.beta[m] = beta[m]; hy.beta_sum[m] = betaSum[m]; hy.gamma[m] = gamma[m];
         for (int j = 0; j < M; j++) { hy.p_a[m][j] = p_a[m][j]; hy.p_b[m][j] = p_b[m][j]; }
     }
-    check(mvhdp_set_hyper(h_, &hy), "mvhdp_set_hyper");
+    check(dev_.setHyper(&hy), "mvhdp_set_hyper");
 }
 
 void FastQMVWVParallelTopicModel::syncFromDevice(bool histograms)
@@ -204,11 +209,11 @@ void FastQMVWVParallelTopicModel::syncFromDevice(bool histograms)
     typeTopicCounts.resize(M);
     for (int m = 0; m < M; m++) {
         typeTopicCounts[m].resize((size_t)numTypes[m] * K);
-        check(mvhdp_get_counts(h_, m, typeTopicCounts[m].data(), tokensPerTopic[m].data()), "mvhdp_get_counts");
+        check(dev_.getCounts(m, typeTopicCounts[m].data(), tokensPerTopic[m].data()), "mvhdp_get_counts");
         int64_t N = 0;
         for (int64_t d = 0; d < D; d++) N += (int64_t)data[d].Assignments[m].tokens.size();
         std::vector<int32_t> z((size_t)std::max<int64_t>(N, 1));
-        check(mvhdp_get_assignments(h_, m, z.data()), "mvhdp_get_assignments");
+        check(dev_.getAssignments(m, z.data()), "mvhdp_get_assignments");
         int64_t o = 0;
         for (int64_t d = 0; d < D; d++) {                             // back into the very arrays getFeatures() returns
             TopicAssignment& ta = data[d].Assignments[m];
@@ -217,14 +222,14 @@ void FastQMVWVParallelTopicModel::syncFromDevice(bool histograms)
         }
         if (histograms) {
             topicDocCounts[m].assign((size_t)K * (histogramSize[m] + 1), 0);
-            check(mvhdp_get_doc_topic_hist(h_, m, topicDocCounts[m].data(), histogramSize[m] + 1,
-                                           docLengthCounts[m].data(), histogramSize[m] + 1), "mvhdp_get_doc_topic_hist");
+            check(dev_.docTopicHist(m, topicDocCounts[m].data(), histogramSize[m] + 1,
+                                    docLengthCounts[m].data(), histogramSize[m] + 1), "mvhdp_get_doc_topic_hist");
         }
     }
     // a topic activation (UPD:263-270) may have changed alpha / inActiveTopicIndex
     std::vector<double> a((size_t)M * (K + 1));
     std::vector<uint8_t> ina((size_t)K);
-    check(mvhdp_get_alpha(h_, a.data(), ina.data()), "mvhdp_get_alpha");
+    check(dev_.getAlpha(a.data(), ina.data()), "mvhdp_get_alpha");
     for (int m = 0; m < M; m++) std::copy(a.begin() + (size_t)m * (K + 1), a.begin() + (size_t)(m + 1) * (K + 1), alpha[m].begin());
     inActiveTopicIndex.clear();
     for (int k = 0; k < K; k++) if (ina[k]) inActiveTopicIndex.insert(k);
@@ -284,7 +289,7 @@ void FastQMVWVParallelTopicModel::optimizeP(bool appendMetadata)
     (void)appendMetadata;
     const int M = numModalities;
     std::vector<double> sums((size_t)M * M, 0.0);
-    check(mvhdp_view_overlap_sums(h_, sums.data()), "mvhdp_view_overlap_sums");      // PTM:2706-2782 on the device
+    check(dev_.viewOverlapSums(sums.data()), "mvhdp_view_overlap_sums");      // PTM:2706-2782 on the device
     pMean.assign(M, std::vector<double>(M, 0.0));
     for (int m = 0; m < M; m++) {                                                    // PTM:2784-2812
         pMean[m][m] = 1;
@@ -308,9 +313,9 @@ void FastQMVWVParallelTopicModel::optimizeBeta()
     for (int m = 0; m < M; m++) {                                                    // PTM:2293
         double prevBetaSum = betaSum[m];
         std::vector<int32_t> countHistogram((size_t)maxTypeCount[m] + 1, 0);
-        check(mvhdp_get_count_histogram(h_, m, countHistogram.data(), maxTypeCount[m] + 1), "mvhdp_get_count_histogram");  // PTM:2299-2309
+        check(dev_.countHistogram(m, countHistogram.data(), maxTypeCount[m] + 1), "mvhdp_get_count_histogram");  // PTM:2299-2309
         std::vector<int32_t> nk((size_t)K);
-        check(mvhdp_get_counts(h_, m, nullptr, nk.data()), "mvhdp_get_counts");
+        check(dev_.getCounts(m, nullptr, nk.data()), "mvhdp_get_counts");
         int maxTopicSize = 0;
         for (int topic = 0; topic < K; topic++) maxTopicSize = std::max(maxTopicSize, nk[topic]);
         std::vector<int32_t> topicSizeHistogram((size_t)maxTopicSize + 1, 0);
@@ -376,7 +381,7 @@ void FastQMVWVParallelTopicModel::optimizeDP()
     for (int m = 0; m < M; m++) {
         const int len = histogramSize[m] + 1;
         topicDocCounts[m].assign((size_t)K * len, 0);
-        check(mvhdp_get_doc_topic_hist(h_, m, topicDocCounts[m].data(), len, docLengthCounts[m].data(), len), "mvhdp_get_doc_topic_hist");
+        check(dev_.docTopicHist(m, topicDocCounts[m].data(), len, docLengthCounts[m].data(), len), "mvhdp_get_doc_topic_hist");
         for (int t = 0; t < K; t++) {
             const int32_t* tdc = topicDocCounts[m].data() + (size_t)t * len;
             for (int i = 0; i < len; i++) {
@@ -465,7 +470,7 @@ void FastQMVWVParallelTopicModel::optimizeGamma()
                 // the same two sums, every entity drawing from its own counter-based stream on the device (the
                 // reference's stream for them, `samp` over ThreadLocalRandom, cannot be seeded or replayed anyway)
                 const uint64_t seed = (randomSeed == -1) ? 0x9E3779B97F4A7C15ull : (uint64_t)(int64_t)randomSeed;
-                check(mvhdp_gamma_doc_statistics(h_, m, gamma[m], seed, (uint32_t)(gammaCalls_ * 16 + r), &qs, &qw), "mvhdp_gamma_doc_statistics");
+                check(dev_.gammaDocStatistics(m, gamma[m], seed, (uint32_t)(gammaCalls_ * 16 + r), &qs, &qw), "mvhdp_gamma_doc_statistics");
             } else
             for (size_t j = 0; j < docLengthCounts[m].size(); j++)
                 for (int i = 0; i < docLengthCounts[m][j]; i++) {
@@ -584,7 +589,7 @@ std::string FastQMVWVParallelTopicModel::displayTopWords(int numWords, int numLa
     typeTopicCounts.resize(M);
     for (int m = 0; m < M; m++) {                                                      // the counts only (not z)
         typeTopicCounts[m].resize((size_t)numTypes[m] * K);
-        check(mvhdp_get_counts(h_, m, typeTopicCounts[m].data(), tokensPerTopic[m].data()), "mvhdp_get_counts");
+        check(dev_.getCounts(m, typeTopicCounts[m].data(), tokensPerTopic[m].data()), "mvhdp_get_counts");
     }
     std::vector<std::vector<std::vector<std::pair<int32_t, int32_t>>>> topicSortedWords;
     for (int m = 0; m < M; m++) topicSortedWords.push_back(getSortedWords(m));
@@ -620,6 +625,7 @@ std::string FastQMVWVParallelTopicModel::printDocumentTopicsToString(double thre
 {
     const int M = numModalities, K = numTopics;
     if (!h_) throw std::runtime_error("printDocumentTopics() before addInstances()");
+    if (dev_.numShards() > 1) throw std::runtime_error("printDocumentTopics: the carry-over of PTM:2873-2886 runs over ONE handle's entities (setNumShards(1))");
     if (pMean.empty()) throw std::runtime_error("printDocumentTopics: pMean is not set (optimizeP has not run; PTM:134)");
     if (discrWeightPerModality.empty()) discrWeightPerModality.assign(M, 1.0);
     pushHyper();
@@ -666,7 +672,7 @@ void FastQMVWVParallelTopicModel::printState(const std::string& filename)
 std::vector<double> FastQMVWVParallelTopicModel::modelLogLikelihood()
 {
     std::vector<double> ll((size_t)numModalities, 0.0);
-    check(mvhdp_model_log_likelihood(h_, ll.data()), "mvhdp_model_log_likelihood");
+    check(dev_.logLikelihood(ll.data()), "mvhdp_model_log_likelihood");
     return ll;
 }
 
@@ -700,7 +706,7 @@ void FastQMVWVParallelTopicModel::estimate()
         mvhdp_sweep_stats st;
         const uint32_t sweepFlags = liveUpdates_ ? (MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(liveSegments_))
                                   : segmentedUpdates_ ? (MVHDP_SWEEP_SEGMENT_APPLY | MVHDP_SWEEP_LIVE_SEGMENTS(liveSegments_)) : 0u;
-        check(mvhdp_sweep(h_, (uint32_t)iteration, seed, sweepFlags, nullptr, nullptr, &st), "mvhdp_sweep");  // PTM:1213-1239
+        check(dev_.sweep((uint32_t)iteration, seed, sweepFlags, &st), "mvhdp_sweep");  // PTM:1213-1239
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         iterationLog.push_back({iteration, ms, st});
         if (iteration % 10 == 0 && printLogLikelihood) {               // PTM:1296-1304
@@ -714,7 +720,7 @@ void FastQMVWVParallelTopicModel::estimate()
         if (st.activated_topic >= 0) {                                // keep the host copy of alpha / inActiveTopicIndex current
             std::vector<double> a((size_t)M * (numTopics + 1));
             std::vector<uint8_t> ina((size_t)numTopics);
-            check(mvhdp_get_alpha(h_, a.data(), ina.data()), "mvhdp_get_alpha");
+            check(dev_.getAlpha(a.data(), ina.data()), "mvhdp_get_alpha");
             for (int m = 0; m < M; m++) std::copy(a.begin() + (size_t)m * (numTopics + 1), a.begin() + (size_t)(m + 1) * (numTopics + 1), alpha[m].begin());
             inActiveTopicIndex.clear();
             for (int k = 0; k < numTopics; k++) if (ina[k]) inActiveTopicIndex.insert(k);
@@ -741,6 +747,12 @@ void mvtm_set_last_error(const char* msg) { g_host_err = msg ? msg : ""; }
 int mvtm_model_set_device_gamma_statistics(void* p, int on)
 {
     ((FastQMVWVParallelTopicModel*)p)->setDeviceGammaStatistics(on != 0);
+    return 0;
+}
+
+int mvtm_model_set_shards(void* p, int n)
+{
+    ((FastQMVWVParallelTopicModel*)p)->setNumShards(n);
     return 0;
 }
 

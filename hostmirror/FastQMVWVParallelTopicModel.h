@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../include/mvhdp.h"
+#include "device_model.h"
 #include "java_random.h"
 #include "knowceans_samplers.h"
 
@@ -79,6 +80,10 @@ public:
     void setNumThreads(int threads) { numThreads = threads; }   // a hint only: parallelism is the GPU's
     void setDevice(int device) { device_ = device; }
     void setDocIdBase(int64_t base) { docIdBase_ = base; }      // document shards: global id of entity 0
+    // the model as n document shards behind an mvhdp_group (include/mvhdp.h), all on the chosen device: the same chain, the same
+    // statistics -- every call of this class is routed to its mvhdp_group_* counterpart (device_model.h).  Before addInstances().
+    void setNumShards(int n) { numShards_ = n < 1 ? 1 : n; }
+    int numShards() const { return numShards_; }
     // Update discipline of the sweeps estimate() runs: false = deferred (snapshot sweep, bit-reproducible: the parity
     // contract), true = MVHDP_SWEEP_LIVE (the updater threads' own discipline, UPD:197-218; profiles/r02_ll_curves.md)
     void setLiveUpdates(bool live, int treeRebuildsPerSweep = 0) { liveUpdates_ = live; liveSegments_ = treeRebuildsPerSweep; if (live) segmentedUpdates_ = false; }
@@ -192,7 +197,9 @@ private:
     JavaRandom sampRand_{0};                                    // stands in for ThreadLocalRandom.current()
     Randoms random_{0};                                         // the ctor's `random` field (PTM:241-246)
     bool hostSamplersSeeded_ = false;
-    mvhdp_handle h_ = nullptr;
+    DeviceModel dev_;                   // one handle, or document shards + their group
+    mvhdp_handle h_ = nullptr;          // = dev_.first(): the replicated model (and the whole model when there is one shard)
+    int numShards_ = 1;
     int device_ = 0;
     int64_t docIdBase_ = 0;
     bool liveUpdates_ = false, segmentedUpdates_ = false;

@@ -313,8 +313,10 @@ int mvhdp_tuner_probe(int32_t num_modalities, const double* tree_branch_share /*
  * members (on the device where members share a GPU, by RCCL all-reduce over xGMI between GPUs: the only collective of the
  * path), pipelined in row ranges with the update and F+tree rebuild of the rows that have arrived; with inactive topics the
  * activation key (MVHDP_ACT_KEY) is MIN-reduced so that every replica activates the same topic (UPD:263-270).  Results are
- * bit-identical to one handle holding every entity.  RCCL is opened at run time (librccl.so.1, or the file MVHDP_RCCL_LIB
- * names): a single-GPU host never loads it.  A handle belongs to at most one group; destroy the group before its members. */
+ * bit-identical to one handle holding every entity.  RCCL is opened at run time (a copy already mapped into the process, else the
+ * file MVHDP_RCCL_LIB names, else librccl.so.1): a single-GPU host never loads it.  A handle belongs to at most one group; destroy
+ * the group before its members (a group call on a group whose member is gone returns MVHDP_ERR_STATE).  Group calls leave the
+ * caller's current HIP device as they found it. */
 typedef struct mvhdp_group_ctx* mvhdp_group;
 #define MVHDP_UNIQUE_ID_BYTES 128
 typedef struct {
@@ -338,8 +340,29 @@ int mvhdp_group_get_info(mvhdp_group g, mvhdp_group_info* info);
 int mvhdp_group_set_exchange_chunks(mvhdp_group g, int32_t chunks /* 1..64 */);
 /* buildInitialTypeTopicCounts PTM:600-652 over all shards: every member counts its entities, the counts are summed over the group */
 int mvhdp_group_build_counts(mvhdp_group g);
-/* flags: MVHDP_SWEEP_LIVE (+ LIVE_SEGMENTS), EXACT_CHAIN, GENERIC_KERNEL; stats: one per local member, or NULL */
+/* flags: MVHDP_SWEEP_LIVE (+ LIVE_SEGMENTS), SEGMENT_APPLY (+ LIVE_SEGMENTS), EXACT_CHAIN, GENERIC_KERNEL; stats: one per local member, or NULL.
+ * Failure (one process per GPU): every rank enters the same collectives whatever happens locally; a rank whose sweep failed contributes
+ * zero deltas and raises a status word that is reduced with the tokensPerTopic part, so ALL ranks return an error from the same call
+ * (the failing rank its own, the others MVHDP_ERR_STATE) and none waits inside a collective for a rank that has given up.  After such
+ * an error call mvhdp_group_build_counts on every rank (a recount from the assignments) before the next sweep. */
 int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats);
+/* A host whose rank cannot go on calls this before its next mvhdp_group_sweep: that sweep samples nothing here and fails on every rank
+ * together (see above) instead of leaving the others inside an all-reduce. */
+int mvhdp_group_abort(mvhdp_group g);
+
+/* ---- the steps either side of the sweep for a sharded model: what estimate() does every optimizeInterval and every tenth iteration
+ * (PTM:1173-1210 -> optimizeP PTM:2698-2819, optimizeDP PTM:2440-2591, optimizeGamma PTM:2369-2438, optimizeBeta PTM:2288-2367;
+ * PTM:1296-1320 -> modelLogLikelihood PTM:3322-3452).  Statistics over the replicated counts are any member's; statistics over the
+ * entities are put together from the members -- in one process in ascending doc_id_base with the running sums carried from member to
+ * member (the single handle's additions in the single handle's order: bit-identical), across processes by adding every rank's partial
+ * result in rank order (equal to rounding; collective: every rank calls).  Arguments as for the single-handle functions. ---- */
+int mvhdp_group_set_hyper(mvhdp_group g, const mvhdp_hyper* hy);          /* every local member (replicated: every rank passes the same values) */
+int mvhdp_group_log_likelihood(mvhdp_group g, double* log_likelihood /*[M]*/);
+int mvhdp_group_doc_topic_hist(mvhdp_group g, int32_t m, int32_t* hist /*[K][hist_len]*/, int32_t hist_len,
+                               int32_t* doc_len_counts /*[len_len]*/, int32_t len_len);
+int mvhdp_group_count_histogram(mvhdp_group g, int32_t m, int32_t* hist, int32_t len);
+int mvhdp_group_view_overlap_sums(mvhdp_group g, double* sums /*[M][M]*/);
+int mvhdp_group_gamma_doc_statistics(mvhdp_group g, int32_t m, double gamma_m, uint64_t seed, uint32_t round, double* qs, double* qw);
 
 /* ---- interop for collectives and stream sharing ---- */
 int mvhdp_device_buffer(mvhdp_handle h, mvhdp_buffer which, void** dev_ptr, size_t* bytes);

@@ -66,6 +66,9 @@ void* mvtm_model_native_handle(void* model);
 /* update discipline of estimate()'s sweeps: 0 = deferred (parity contract), 1 = MVHDP_SWEEP_LIVE (UPD:197-218),
  * 2 = MVHDP_SWEEP_SEGMENT_APPLY (deterministic, segments applied in between); second argument = segments (0 = default) */
 int   mvtm_model_set_live_updates(void* model, int live, int tree_rebuilds_per_sweep);
+/* before add_instances: keep the model as n document shards behind an mvhdp_group (all on the model's device); estimate(), the
+ * optimize* steps and the log-likelihood then run over the group (mvhdp_group_*), same integers as one handle */
+int   mvtm_model_set_shards(void* model, int n);
 /* optimizeGamma's per-entity Bernoulli / Beta sums (PTM:2415-2433): 0 = sequential host loop (the reference's), 1 = device kernel */
 int   mvtm_model_set_device_gamma_statistics(void* model, int on);
 /* FastQMVWVTopicInferencer (INF:114-330) as one call chain: getInferencer() PTM:3457, then

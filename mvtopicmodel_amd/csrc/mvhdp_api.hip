@@ -114,7 +114,9 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     h->own_stream = true;
     for (auto& e : h->ev) CREATE_HIP(hipEventCreate(&e));
     const int64_t nrows = mm.rowbase[M];
-    const size_t cbytes = (size_t)(nrows * K + (int64_t)M * K) * sizeof(int32_t);
+    // (+ MVHDP_TAIL_WORDS behind the tokensPerTopic part of both buffers: the status word a group of document shards reduces together
+    // with that part, so that every rank learns of a failure on any rank inside the collective it has to enter anyway)
+    const size_t cbytes = (size_t)(nrows * K + (int64_t)M * K + MVHDP_TAIL_WORDS) * sizeof(int32_t);
     CREATE_HIP(hipMalloc(&mm.counts, cbytes));
     CREATE_HIP(hipMalloc(&mm.delta, cbytes));
     CREATE_HIP(hipMemset(mm.counts, 0, cbytes));
@@ -250,6 +252,7 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     HIPC(h, hipMalloc(&h->d_z[m], nb));
     if (N > 0) HIPC(h, hipMemcpy(h->d_tok[m], tokens, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPC(h, hipMemset(h->d_z[m], 0xff, nb));               // UNASSIGNED_TOPIC (-1), PTM:63
+    h->unassigned[m] = N > 0;
     h->h_doc_off[m].assign(doc_off, doc_off + D + 1);
     h->N[m] = N;
     h->have_corpus[m] = true;
@@ -282,11 +285,15 @@ extern "C" int mvhdp_set_assignments(mvhdp_handle h, int32_t m, const int32_t* z
     if (m < 0 || m >= h->mm.M) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_assignments: bad view");
     if (!h->have_corpus[m]) FAIL(h, MVHDP_ERR_STATE, "set_assignments before set_corpus");
     if (h->N[m] > 0 && !z) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_assignments: null z");
-    for (int64_t i = 0; i < h->N[m]; i++)
+    bool any_unassigned = false;
+    for (int64_t i = 0; i < h->N[m]; i++) {
         if (z[i] < -1 || z[i] >= h->mm.K) FAIL(h, MVHDP_ERR_INVALID_ARG, "set_assignments: topic out of range");
+        any_unassigned = any_unassigned || z[i] < 0;
+    }
     HIPC(h, hipSetDevice(h->device));
     HIPC(h, hipStreamSynchronize(h->stream));
     if (h->N[m] > 0) HIPC(h, hipMemcpy(h->d_z[m], z, (size_t)h->N[m] * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->unassigned[m] = any_unassigned;
     h->nslots_valid = false;
     // the counts no longer describe these assignments: a sampling sweep is refused until build_counts / set_counts /
     // counts_written says they do again (a frozen sweep, whose counts are a trained model's by design, is not)
@@ -424,6 +431,7 @@ extern "C" int mvhdp_init_assignments_from_trees(mvhdp_handle h, uint64_t seed)
     HIPC(h, hipSetDevice(h->device));
     HIPC(h, mvhdp_launch_init_from_trees(h->mm, (uint32_t)seed, (uint32_t)(seed >> 32), h->stream));     // reads the descent table only
     HIPC(h, hipStreamSynchronize(h->stream));
+    for (int m = 0; m < h->mm.M; m++) h->unassigned[m] = false;                                              // (every token got a topic, INF:169-199)
     h->nslots_valid = false;
     if (h->have_counts) h->counts_stale = true;
     return MVHDP_OK;
@@ -655,6 +663,8 @@ static void fill_plan_in(mvhdp_ctx* h, uint32_t flags, bool debug, bool batch, P
     std::copy(h->last_ent, h->last_ent + MVHDP_ENT_BINS, in.ent_hist);
     in.flags = flags; in.debug = debug; in.batch = batch;
     in.trees_current = h->have_trees;
+    in.unassigned = false;
+    for (int m = 0; m < mm.M; m++) in.unassigned = in.unassigned || h->unassigned[m];
     in.first_inactive = mm.first_inactive;
     in.num_cus = h->num_cus; in.max_lds = h->max_lds;
     in.regs = h->regs;
@@ -809,7 +819,9 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
             for (int c = 0; c < MVHDP_N_CLASSES; c++) { ca.class_map[c] = p.class_map[c]; ca.lists[c] = h->d_lists + (size_t)c * mm.D; }
             ca.check_views = compute_max_doc_tokens(h) > 65535 ? 1 : 0;
             ca.counts = class_counts;
-            ca.misrouted = (unsigned long long*)h->d_ovf_meta + META_MISROUTED;
+            // (counted with this sweep's own counters: in a batch -- mvhdp_sweep_many -- every sweep resets the shared control block,
+            // its statistics slot survives to the read-back at the end)
+            ca.misrouted = d_stats + ST_MISCLASS;
             step(mvhdp_launch_classify(mm, ca, s));
             step(hipEventRecord(h->ev_fork, s));
         }
@@ -1020,6 +1032,8 @@ int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats)
 
     mvhdp_sweep_stats st;
     stats_from_counters(hs, act, st);
+    // every entity was visited and none abandoned: no token of a known type is unassigned any more (WRK:557)
+    if (!p.frozen && p.only_seg < 0 && st.aborted_docs == 0) for (int m = 0; m < mm.M; m++) h->unassigned[m] = false;
     const unsigned long long negatives = hs[ST_NEGATIVE];
     // (the pinned buffer belongs to the handle: a sweep begun on it before this one returns would overwrite it -- what the
     // planner learns from is copied out first)
@@ -1083,7 +1097,9 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
     if (n == 0) return MVHDP_OK;
     MvModel& mm = h->mm;
     const bool frozen = (flags & MVHDP_SWEEP_FROZEN) != 0;
-    if (n == 1 || mm.first_inactive >= 0 || ((flags & MVHDP_SWEEP_NO_APPLY) && !frozen) || n > 4096) {
+    // (REUSE_TREES without FROZEN: the first sweep's update makes the trees stale, and a single call then says so -- MVHDP_ERR_STATE at
+    // the second sweep; the batch must not sample on from stale trees and a stale mirror instead)
+    if (n == 1 || mm.first_inactive >= 0 || ((flags & MVHDP_SWEEP_NO_APPLY) && !frozen) || ((flags & MVHDP_SWEEP_REUSE_TREES) && !frozen) || n > 4096) {
         for (int i = 0; i < n; i++) {
             const int rc = mvhdp_sweep(h, first_idx + (uint32_t)i, seed, flags, nullptr, nullptr, stats ? stats + i : nullptr);
             if (rc) return rc;
@@ -1149,6 +1165,7 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
     for (int i = 0; i < n; i++) for (int k = 0; k < ST_COUNT; k++) acc[k] += hs[(size_t)i * ST_COUNT + k];
     const bool comparable = p.fast && !h->tu.walk_fixed && !(flags & (MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_EXACT_CHAIN));
     learn_from_sweep(h, p, acc.data(), meta + META_HIST, ms_sum, comparable);
+    if (!p.frozen && acc[ST_ABORT] == 0) for (int m = 0; m < mm.M; m++) h->unassigned[m] = false;
     return ret;
 }
 
@@ -1304,14 +1321,14 @@ extern "C" int mvhdp_get_count_histogram(mvhdp_handle h, int32_t m, int32_t* his
     return MVHDP_OK;
 }
 
-extern "C" int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums)
+// optimizeP PTM:2706-2792: acc[m*M+i] += pDistr_Mean[m][i][doc] over this handle's entities, one after the other in entity order
+// (PTM:2789-2792).  A group of document shards in ONE process hands the accumulators from member to member (ascending doc_id_base): the
+// additions are then the single handle's, in the same order, bit for bit.
+int mvhdp_view_overlap_accumulate(mvhdp_ctx* h, double* acc)
 {
-    CHECK_H(h);
     MvModel& mm = h->mm;
-    if (!sums) FAIL(h, MVHDP_ERR_INVALID_ARG, "view_overlap_sums: null");
     int rc = require_corpus(h); if (rc) return rc;
     const int M = mm.M;
-    for (int i = 0; i < M * M; i++) sums[i] = 0.0;
     if (mm.D == 0) return MVHDP_OK;
     HIPC(h, hipSetDevice(h->device));
     double* d = nullptr;
@@ -1324,12 +1341,20 @@ extern "C" int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums)
     hipFree(d);
     HIPC(h, e);
     for (int i = 0; i < M * M; i++) {                     // PTM:2789-2792: sequential, entity order
-        double acc = 0;
+        double a = acc[i];
         const double* col = host.data() + (size_t)i * mm.D;
-        for (int64_t doc = 0; doc < mm.D; doc++) acc += col[doc];
-        sums[i] = acc;
+        for (int64_t doc = 0; doc < mm.D; doc++) a += col[doc];
+        acc[i] = a;
     }
     return MVHDP_OK;
+}
+
+extern "C" int mvhdp_view_overlap_sums(mvhdp_handle h, double* sums)
+{
+    CHECK_H(h);
+    if (!sums) FAIL(h, MVHDP_ERR_INVALID_ARG, "view_overlap_sums: null");
+    for (int i = 0; i < h->mm.M * h->mm.M; i++) sums[i] = 0.0;
+    return mvhdp_view_overlap_accumulate(h, sums);
 }
 
 extern "C" int mvhdp_doc_topic_proportions(mvhdp_handle h, const double* view_weights, int64_t d0, int64_t d1, double* out)
@@ -1394,55 +1419,86 @@ extern "C" int mvhdp_gamma_doc_statistics(mvhdp_handle h, int32_t m, double gamm
     return MVHDP_OK;
 }
 
-extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
+// modelLogLikelihood PTM:3322-3452 in two parts, so that a group of document shards can put them together (mvhdp_group_log_likelihood):
+// the DOCUMENT part of view m (PTM:3341-3367) belongs to the entities of a handle -- *ll and *cnt (modalityCnt) continue a sequential
+// sum in entity order --, the MODEL part (PTM:3373-3441: the modalityCnt term, the topic-word term over n_wk, the n_k terms) to the
+// replicated counts: once per model.
+int mvhdp_ll_doc_accumulate(mvhdp_ctx* h, int m, double* ll, int64_t* cnt)
 {
-    CHECK_H(h);
     MvModel& mm = h->mm;
-    if (!out) FAIL(h, MVHDP_ERR_INVALID_ARG, "model_log_likelihood: null");
     int rc = require_corpus(h); if (rc) return rc;
+    if (!h->have_hyper) FAIL(h, MVHDP_ERR_STATE, "model_log_likelihood before set_hyper");
+    if (m < 0 || m >= mm.M) FAIL(h, MVHDP_ERR_INVALID_ARG, "model_log_likelihood: bad view");
+    if (mm.D == 0) return MVHDP_OK;
+    HIPC(h, hipSetDevice(h->device));
+    double* d_doc = nullptr;
+    HIPC(h, hipMalloc(&d_doc, (size_t)mm.D * sizeof(double)));
+    std::vector<double> hdoc((size_t)mm.D);
+    hipError_t e = mvhdp_launch_loglik_doc(mm, m, d_doc, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hdoc.data(), d_doc, (size_t)mm.D * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_doc);
+    HIPC(h, e);
+    double a = *ll;
+    int64_t c = *cnt;
+    for (int64_t d = 0; d < mm.D; d++) {
+        const bool has = h->h_present[m].empty() ? h->h_doc_off[m][d + 1] > h->h_doc_off[m][d] : h->h_present[m][(size_t)d] != 0;
+        if (has) { a += hdoc[d]; c++; }                                                              // PTM:3348-3367
+    }
+    *ll = a; *cnt = c;
+    return MVHDP_OK;
+}
+
+int mvhdp_ll_model_finish(mvhdp_ctx* h, int m, double ll, int64_t modalityCnt, double* out)
+{
+    MvModel& mm = h->mm;
     if (!h->have_hyper || !h->have_counts) FAIL(h, MVHDP_ERR_STATE, "model_log_likelihood before set_hyper/build_counts");
+    if (m < 0 || m >= mm.M || !out) FAIL(h, MVHDP_ERR_INVALID_ARG, "model_log_likelihood: bad view");
     const int M = mm.M, K = mm.K;
+    ll += modalityCnt * log_gamma_stirling_host((double)mm.gamma[m] * mm.alpha_sum[m]);           // PTM:3373
+    if (std::isnan(ll) || std::isinf(ll)) { *out = 0; return MVHDP_OK; }                           // PTM:3375-3383
     HIPC(h, hipSetDevice(h->device));
     const int NP = 1024;
-    double *d_doc = nullptr, *d_part = nullptr;
+    double* d_part = nullptr;
     unsigned long long* d_nz = nullptr;
-    hipError_t e = hipMalloc(&d_doc, (size_t)std::max<int64_t>(mm.D, 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&d_part, NP * sizeof(double));
+    hipError_t e = hipMalloc(&d_part, NP * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&d_nz, sizeof(unsigned long long));
-    std::vector<double> hdoc((size_t)std::max<int64_t>(mm.D, 1)), hpart(NP);
+    std::vector<double> hpart(NP);
     std::vector<int32_t> nk((size_t)K);
-    for (int m = 0; m < M && e == hipSuccess; m++) {
-        unsigned long long nz = 0;
-        e = mvhdp_launch_loglik(mm, m, d_doc, d_part, NP, d_nz, h->stream);
-        if (e == hipSuccess && mm.D > 0) e = hipMemcpyAsync(hdoc.data(), d_doc, (size_t)mm.D * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(hpart.data(), d_part, NP * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(nk.data(), mm.counts + mm.rowbase[M] * K + (int64_t)m * K, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) break;
-        double ll = 0;
-        int64_t modalityCnt = 0;
-        for (int64_t d = 0; d < mm.D; d++) {
-            const bool has = h->h_present[m].empty() ? h->h_doc_off[m][d + 1] > h->h_doc_off[m][d] : h->h_present[m][(size_t)d] != 0;
-            if (has) { ll += hdoc[d]; modalityCnt++; }                                              // PTM:3348-3367
-        }
-        ll += modalityCnt * log_gamma_stirling_host((double)mm.gamma[m] * mm.alpha_sum[m]);       // PTM:3373
-        if (std::isnan(ll) || std::isinf(ll)) { out[m] = 0; continue; }                           // PTM:3375-3383
-        for (int i = 0; i < NP; i++) ll += hpart[i];                                                // PTM:3389-3415
-        if (std::isnan(ll) || std::isinf(ll)) ll = 0;
-        const double bv = mm.beta[m] * mm.V[m];
-        for (int topic = 0; topic < K; topic++) {                                                   // PTM:3417-3435
-            ll -= (bv + nk[topic]) == 0 ? 0 : log_gamma_stirling_host(bv + nk[topic]);
-            if (std::isnan(ll) || std::isinf(ll)) ll = 0;
-        }
-        ll += bv == 0 ? 0 : log_gamma_stirling_host(bv) * K;                                        // PTM:3438
-        ll -= mm.beta[m] == 0 ? 0 : log_gamma_stirling_host(mm.beta[m]) * (double)nz;               // PTM:3441
-        if (std::isinf(ll)) ll = 0;
-        out[m] = ll;
-    }
-    if (d_doc) hipFree(d_doc);
+    unsigned long long nz = 0;
+    if (e == hipSuccess) e = mvhdp_launch_loglik_topic(mm, m, d_part, NP, d_nz, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hpart.data(), d_part, NP * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(nk.data(), mm.counts + mm.rowbase[M] * K + (int64_t)m * K, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (d_part) hipFree(d_part);
     if (d_nz) hipFree(d_nz);
     HIPC(h, e);
+    for (int i = 0; i < NP; i++) ll += hpart[i];                                                    // PTM:3389-3415
+    if (std::isnan(ll) || std::isinf(ll)) ll = 0;
+    const double bv = mm.beta[m] * mm.V[m];
+    for (int topic = 0; topic < K; topic++) {                                                       // PTM:3417-3435
+        ll -= (bv + nk[topic]) == 0 ? 0 : log_gamma_stirling_host(bv + nk[topic]);
+        if (std::isnan(ll) || std::isinf(ll)) ll = 0;
+    }
+    ll += bv == 0 ? 0 : log_gamma_stirling_host(bv) * K;                                            // PTM:3438
+    ll -= mm.beta[m] == 0 ? 0 : log_gamma_stirling_host(mm.beta[m]) * (double)nz;                   // PTM:3441
+    if (std::isinf(ll)) ll = 0;
+    *out = ll;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_model_log_likelihood(mvhdp_handle h, double* out)
+{
+    CHECK_H(h);
+    if (!out) FAIL(h, MVHDP_ERR_INVALID_ARG, "model_log_likelihood: null");
+    int rc = require_corpus(h); if (rc) return rc;
+    if (!h->have_hyper || !h->have_counts) FAIL(h, MVHDP_ERR_STATE, "model_log_likelihood before set_hyper/build_counts");
+    for (int m = 0; m < h->mm.M; m++) {
+        double ll = 0;
+        int64_t cnt = 0;
+        rc = mvhdp_ll_doc_accumulate(h, m, &ll, &cnt); if (rc) return rc;
+        rc = mvhdp_ll_model_finish(h, m, ll, cnt, &out[m]); if (rc) return rc;
+    }
     return MVHDP_OK;
 }

@@ -72,6 +72,11 @@ struct mvhdp_ctx {
     unsigned long long last_hist[MVHDP_HIST_BINS]{};   // tokens by topic-list size class
     unsigned long long last_ent[MVHDP_ENT_BINS]{};     // entities by kernel class
     bool nslots_valid = false;               // MvModel::nslots and the two histograms describe the current assignments
+    // Some token of view m may still carry UNASSIGNED_TOPIC (-1, PTM:63): set by set_corpus (which fills z with -1) and by set_assignments
+    // when the host's array holds one, cleared when a full sweep has visited every entity without abandoning one.  A live sweep on the
+    // 16-bit mirror needs every row's total to be constant (a LIGHT row can then never reach 65535 in a cell); a first visit of an
+    // unassigned token only adds to its row, so while this is set live sweeps stay on the 32-bit table.
+    bool unassigned[MVHDP_MAXM]{};
     bool counts_stale = false;               // assignments were replaced (set_assignments / init_from_trees) and the counts not rebuilt since
     PlanRegs regs{};                         // register counts of the compiled kernels (occupancy)
     PlanTuning tu;                           // what the host pinned (mvhdp_set_tuning; environment read once at create)
@@ -88,6 +93,7 @@ bool mvhdp_is_live(mvhdp_ctx* h);
     (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
 #define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
 
+enum { MVHDP_TAIL_WORDS = 4 };               // int32 words allocated behind counts_len() in the counts and delta buffers ([0]: a group's status word)
 static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
 
 // d_ovf_meta (u64 words unless said otherwise): [META_HIST .. +MVHDP_HIST_BINS+MVHDP_ENT_BINS) what the sweep kernels leave for the next
@@ -127,3 +133,7 @@ struct PendingSweep {
 };
 int mvhdp_sweep_begin(mvhdp_ctx* h, uint32_t sweep_idx, uint64_t seed, uint32_t flags, const double* p_override, const mvhdp_debug* dbg, PendingSweep& ps);
 int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats);
+// pieces of the statistics either side of the sweep that a group of document shards composes (mvhdp_api.hip; see there)
+int mvhdp_view_overlap_accumulate(mvhdp_ctx* h, double* acc /*[M*M], continued*/);
+int mvhdp_ll_doc_accumulate(mvhdp_ctx* h, int m, double* ll, int64_t* cnt);
+int mvhdp_ll_model_finish(mvhdp_ctx* h, int m, double ll_doc, int64_t modalityCnt, double* out);

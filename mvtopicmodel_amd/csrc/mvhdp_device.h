@@ -133,8 +133,8 @@ hipError_t mvhdp_launch_doc_topic_hist(const MvModel& mm, int m, int32_t* hist, 
 hipError_t mvhdp_sweep_set_max_lds(size_t bytes);
 hipError_t mvhdp_launch_count_hist(const MvModel& mm, int m, int32_t* hist, int32_t len, hipStream_t s);
 hipError_t mvhdp_launch_view_overlap(const MvModel& mm, double* out, hipStream_t s);
-hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
-                               unsigned long long* nonzero, hipStream_t s);
+hipError_t mvhdp_launch_loglik_doc(const MvModel& mm, int m, double* doc_out, hipStream_t s);
+hipError_t mvhdp_launch_loglik_topic(const MvModel& mm, int m, double* partial, int n_partial, unsigned long long* nonzero, hipStream_t s);
 hipError_t mvhdp_launch_gamma_doc_stats(const MvModel& mm, int m, double gamma_m, uint32_t seed_lo, uint32_t seed_hi, uint32_t round,
                                         double* partial, int n_blocks, hipStream_t s);
 // counts every entity's topic list from z: writes MvModel::nslots and the histograms of SweepLaunch::slot_hist

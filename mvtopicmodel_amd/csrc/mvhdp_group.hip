@@ -44,17 +44,22 @@ Rccl* rccl()
     std::lock_guard<std::mutex> lk(g_rccl_mutex);
     if (g_rccl.lib) return &g_rccl;
     if (!g_rccl.why.empty()) return nullptr;
+    // Order: a copy that is ALREADY mapped into the process (PyTorch's: same soname, RTLD_NOLOAD maps nothing new), then the file the
+    // host names (MVHDP_RCCL_LIB: mvtopicmodel_amd/_lib.py points it at the torch wheel's copy so that a later `import torch` shares
+    // it), then the installation's own.  (The plain soname first would always succeed through this library's RUNPATH and the
+    // override would never be looked at.)
+    std::string errs;
+    if (void* l = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD)) { g_rccl.lib = l; g_rccl.path = "librccl.so.1 (already mapped)"; }
     std::vector<std::string> names;
-    names.push_back("librccl.so.1");                          // a copy that is mapped already (same soname) is re-used
     if (const char* e = getenv("MVHDP_RCCL_LIB")) names.push_back(e);
+    names.push_back("librccl.so.1");
     names.push_back("librccl.so");
     names.push_back("/opt/rocm/lib/librccl.so.1");
-    std::string errs;
     for (const std::string& n : names) {
+        if (g_rccl.lib) break;
         void* l = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!l) { errs += std::string(dlerror() ? dlerror() : "?") + "; "; continue; }
         g_rccl.lib = l; g_rccl.path = n;
-        break;
     }
     if (!g_rccl.lib) { g_rccl.why = "RCCL could not be opened: " + errs; return nullptr; }
 #define SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(g_rccl.lib, name); \
@@ -80,6 +85,15 @@ hipError_t launch_add_into(int32_t* dst, const int32_t* src, int64_t n, hipStrea
     return hipGetLastError();
 }
 
+__global__ void set_word_kernel(int32_t* p, int32_t v) { *p = v; }
+
+// the caller's current device, put back when a group call returns (a group call visits the devices of all its members)
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
 }  // namespace
 
 struct mvhdp_group_ctx {
@@ -98,6 +112,8 @@ struct mvhdp_group_ctx {
     int chunks = 4;                           // row ranges of one exchange: the apply + tree rebuild of range i runs while range i+1 is on the wire
     double last_exchange_ms = 0.0;
     long long sweeps = 0;
+    bool abort_raised = false;                // mvhdp_group_abort: the next sweep of this rank contributes nothing and fails on every rank
+    std::vector<int> by_entity;               // member indices by ascending doc_id_base: the order of the "in entity order" statistics
     std::string err;
 };
 
@@ -111,7 +127,14 @@ static bool group_live(mvhdp_group_ctx* g)
     return g_groups && g_groups->count(g) != 0;
 }
 
-#define CHECK_G(g) do { if (!(g) || !group_live(g)) return MVHDP_ERR_INVALID_ARG; } while (0)
+// a member destroyed before its group (the header asks for the other order) is noticed, not dereferenced
+static bool members_live(mvhdp_group_ctx* g)
+{
+    for (mvhdp_ctx* h : g->members) if (!mvhdp_is_live(h) || h->device_released) return false;
+    return true;
+}
+#define CHECK_G(g) do { if (!(g) || !group_live(g)) return MVHDP_ERR_INVALID_ARG; \
+                        if (!members_live(g)) { (g)->err = "a member handle of the group has been destroyed"; return MVHDP_ERR_STATE; } } while (0)
 #define GFAIL(g, code, msg) do { (g)->err = (msg); return (code); } while (0)
 #define GHIP(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
 #define GNCCL(g, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
@@ -151,6 +174,8 @@ static int group_common_init(mvhdp_group_ctx* g, int32_t n, const mvhdp_handle* 
         if (it == first_on_device.end()) { first_on_device[h->device] = i; g->leader_of.push_back(i); g->leaders.push_back(i); }
         else g->leader_of.push_back(it->second);
     }
+    for (int i = 0; i < n; i++) g->by_entity.push_back(i);
+    std::stable_sort(g->by_entity.begin(), g->by_entity.end(), [&](int a, int b) { return g->members[a]->mm.doc_id_base < g->members[b]->mm.doc_id_base; });
     for (int i = 0; i < n; i++) {
         hipEvent_t ev;
         GHIP(g, hipSetDevice(g->members[i]->device));
@@ -197,6 +222,7 @@ extern "C" int mvhdp_group_create(int32_t n, const mvhdp_handle* members, mvhdp_
     if (!out) { g_group_create_error = "group_create: null"; return MVHDP_ERR_INVALID_ARG; }
     *out = nullptr;
     int rc = validate_members(n, members); if (rc) return rc;
+    DeviceGuard dg;
     mvhdp_group_ctx* g = new mvhdp_group_ctx();
     rc = group_common_init(g, n, members);
     if (rc) { g_group_create_error = g->err; group_release(g); delete g; return rc; }
@@ -246,6 +272,7 @@ extern "C" int mvhdp_group_create_rank(mvhdp_handle member, const uint8_t* id, i
     int rc = validate_members(1, &member); if (rc) return rc;
     Rccl* r = rccl();
     if (!r) { g_group_create_error = "group_create_rank: " + g_rccl.why; return MVHDP_ERR_UNSUPPORTED; }
+    DeviceGuard dg;
     mvhdp_group_ctx* g = new mvhdp_group_ctx();
     rc = group_common_init(g, 1, &member);
     if (rc) { g_group_create_error = g->err; group_release(g); delete g; return rc; }
@@ -273,6 +300,7 @@ extern "C" int mvhdp_group_destroy(mvhdp_group g)
         std::lock_guard<std::mutex> lk(g_group_mutex);
         if (!g_groups || g_groups->erase(g) == 0) return MVHDP_ERR_INVALID_ARG;
     }
+    DeviceGuard dg;
     for (mvhdp_ctx* h : g->members) if (mvhdp_is_live(h) && !h->device_released) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
     group_release(g);
     delete g;
@@ -361,6 +389,7 @@ static int fan_out_range(mvhdp_group_ctx* g, bool counts, int64_t e0, int64_t e1
 extern "C" int mvhdp_group_build_counts(mvhdp_group g)
 {
     CHECK_G(g);
+    DeviceGuard dg;
     const int n = (int)g->members.size();
     for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_build_counts(g->members[i]));
     for (int i = 0; i < n; i++) { GHIP(g, hipSetDevice(g->members[i]->device)); GHIP(g, hipEventRecord(g->ev_swept[i], g->members[i]->stream)); }
@@ -378,82 +407,139 @@ extern "C" int mvhdp_group_build_counts(mvhdp_group g)
 
 // One exchange-terminated step: every member sweeps (all of its entities, or one segment of them) with NO_APPLY, the deltas are
 // summed over the group and applied by every replica.  st: per-member statistics of this step.
+//
+// Failure protocol (one process per GPU: a rank must never leave the others inside a collective).  Whatever happens locally, every
+// rank enters the SAME collectives -- their number depends only on replicated facts: the chunk count, the segment count taken from the
+// flags, whether the hyper-parameters hold inactive topics.  A rank whose sweep failed (or whose host called mvhdp_group_abort)
+// contributes zero deltas and a 1 in the status word behind the tokensPerTopic part, which is summed with that part: every rank reads
+// the sum at the end of the step and all return an error together.  After such an error the replicas agree with each other but not
+// with the failed rank's assignments: mvhdp_group_build_counts (a recount from z, collective) makes the model consistent again.
 static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, std::vector<mvhdp_sweep_stats>& st)
 {
     const int n = (int)g->members.size();
     const bool live = (flags & MVHDP_SWEEP_LIVE) != 0;
     std::vector<PendingSweep> ps((size_t)n);
-    // 1. every member's sweep goes on its device before any is waited for
-    for (int i = 0; i < n; i++) {
+    int local_err = MVHDP_OK;
+    auto note = [&](int rc, const std::string& what) { if (rc != MVHDP_OK && local_err == MVHDP_OK) { local_err = rc; g->err = what; } };
+    if (g->abort_raised) { note(MVHDP_ERR_STATE, "the host raised mvhdp_group_abort on this rank"); g->abort_raised = false; }
+    // 1. every member's sweep goes on its device before any is waited for; every sweep that was begun is finished, whatever happened
+    for (int i = 0; i < n && local_err == MVHDP_OK; i++) {
         mvhdp_ctx* h = g->members[i];
         // the trees a pipelined apply left behind are those of the counts this sweep starts from (a live sweep rebuilds per segment itself)
         const uint32_t reuse = (h->have_trees && !live) ? MVHDP_SWEEP_REUSE_TREES : 0u;
-        GMEM(g, i, mvhdp_sweep_begin(h, sweep_idx, seed, flags | MVHDP_SWEEP_NO_APPLY | reuse, nullptr, nullptr, ps[i]));
+        const int rc = mvhdp_sweep_begin(h, sweep_idx, seed, flags | MVHDP_SWEEP_NO_APPLY | reuse, nullptr, nullptr, ps[i]);
+        if (rc != MVHDP_OK) note(rc, "member " + std::to_string(i) + ": " + h->err);
     }
-    int first_err = MVHDP_OK;
     for (int i = 0; i < n; i++) {
+        if (!ps[i].open) continue;
         const int rc = mvhdp_sweep_finish(g->members[i], ps[i], &st[i]);
-        if (rc != MVHDP_OK && first_err == MVHDP_OK) { first_err = rc; g->err = "member " + std::to_string(i) + ": " + g->members[i]->err; }
+        if (rc != MVHDP_OK) note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err);
     }
-    if (first_err != MVHDP_OK) return first_err;
-    for (int i = 0; i < n; i++) { GHIP(g, hipSetDevice(g->members[i]->device)); GHIP(g, hipEventRecord(g->ev_swept[i], g->members[i]->stream)); }
-    // 2. the exchange, as a pipeline in stream order: the tokensPerTopic part first (every tree needs all of it), then the n_wk rows in
-    //    `chunks` ranges -- while range i+1 is on the wire, range i is applied and its F+trees rebuilt (mvhdp_apply_delta_rows)
-    mvhdp_ctx* L0 = g->members[g->leaders[0]];
-    GHIP(g, hipSetDevice(L0->device));
-    GHIP(g, hipEventRecord(g->ev_x0, L0->stream));
-    int rc = reduce_local(g, false); if (rc) return rc;
+    hipError_t he = hipSuccess;
+    auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && he == hipSuccess) { he = e; note(MVHDP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); } };
     const MvModel& mm = g->members[0]->mm;
     const int64_t rows = mm.rowbase[mm.M], K = mm.K, nk_off = rows * K, len = counts_len_of(g->members[0]);
-    rc = allreduce_range(g, false, nk_off, len); if (rc) return rc;
-    rc = fan_out_range(g, false, nk_off, len); if (rc) return rc;
-    for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_apply_delta_begin(g->members[i]));
+    if (local_err != MVHDP_OK) {
+        // nothing of this process enters the sum; its members' assignments may have moved without their counts: a recount is due
+        for (int i = 0; i < n; i++) {
+            mvhdp_ctx* h = g->members[i];
+            hipSetDevice(h->device);
+            hipMemsetAsync(h->mm.delta, 0, (size_t)len * sizeof(int32_t), h->stream);
+            h->delta_pending = false; h->delta_clean = true; h->counts_stale = true; h->have_trees = false; h->rows_applied = -1;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        mvhdp_ctx* h = g->members[i];
+        hip(hipSetDevice(h->device), "hipSetDevice");
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, h->stream, h->mm.delta + len, (g->leader_of[i] == i && local_err != MVHDP_OK) ? 1 : 0);
+        hip(hipEventRecord(g->ev_swept[i], h->stream), "hipEventRecord");
+    }
+    // 2. the exchange, as a pipeline in stream order: the tokensPerTopic part (and the status word) first -- every tree needs all of
+    //    it --, then the n_wk rows in `chunks` ranges: while range i+1 is on the wire, range i is applied and its F+trees rebuilt
+    //    (mvhdp_apply_delta_rows).  The collectives are issued whatever the local status; what touches a member's model is not.
+    mvhdp_ctx* L0 = g->members[g->leaders[0]];
+    hip(hipSetDevice(L0->device), "hipSetDevice");
+    hip(hipEventRecord(g->ev_x0, L0->stream), "hipEventRecord");
+    int xrc = reduce_local(g, false);
+    if (xrc == MVHDP_OK) xrc = allreduce_range(g, false, nk_off, len + 1);
+    if (xrc == MVHDP_OK) xrc = fan_out_range(g, false, nk_off, len + 1);
+    bool applying = local_err == MVHDP_OK && xrc == MVHDP_OK;
+    if (applying) for (int i = 0; i < n && applying; i++) { const int rc = mvhdp_apply_delta_begin(g->members[i]); if (rc) { note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err); applying = false; } }
     const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(g->chunks, rows));
     for (int c = 0; c < nch; c++) {
         const int64_t r0 = rows * c / nch, r1 = rows * (c + 1) / nch;
         if (r1 <= r0) continue;
-        rc = allreduce_range(g, false, r0 * K, r1 * K); if (rc) return rc;
-        rc = fan_out_range(g, false, r0 * K, r1 * K); if (rc) return rc;
-        for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_apply_delta_rows(g->members[i], r0, r1));
+        if (xrc == MVHDP_OK) xrc = allreduce_range(g, false, r0 * K, r1 * K);
+        if (xrc == MVHDP_OK) xrc = fan_out_range(g, false, r0 * K, r1 * K);
+        if (applying && xrc == MVHDP_OK)
+            for (int i = 0; i < n && applying; i++) { const int rc = mvhdp_apply_delta_rows(g->members[i], r0, r1); if (rc) { note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err); applying = false; } }
     }
     // 3. UPD:263-270 across shards: the first activating delta in (entity, view, position) order wins on every replica alike
     long long key = LLONG_MAX;
     const bool has_inactive = g->members[0]->mm.first_inactive >= 0;       // the hyper-parameters are replicated: every rank answers alike
     if (has_inactive) {
-        for (int i = 0; i < n; i++) key = std::min<long long>(key, (long long)st[i].activation_key);
-        if (!g->comms.empty() && g->nranks > 1) {
+        if (local_err == MVHDP_OK) for (int i = 0; i < n; i++) key = std::min<long long>(key, (long long)st[i].activation_key);
+        if (!g->comms.empty() && g->nranks > 1 && xrc == MVHDP_OK) {
             Rccl* r = &g_rccl;
             for (size_t l = 0; l < g->leaders.size(); l++) {
                 mvhdp_ctx* L = g->members[g->leaders[l]];
-                GHIP(g, hipSetDevice(L->device));
-                GHIP(g, hipMemcpyAsync(g->d_key[l], &key, sizeof key, hipMemcpyHostToDevice, L->stream));
+                hip(hipSetDevice(L->device), "hipSetDevice");
+                hip(hipMemcpyAsync(g->d_key[l], &key, sizeof key, hipMemcpyHostToDevice, L->stream), "hipMemcpyAsync");
             }
-            if (g->comms.size() > 1) GNCCL(g, r->GroupStart());
-            for (size_t l = 0; l < g->leaders.size(); l++) {
+            ncclResult_t nr = ncclSuccess;
+            if (g->comms.size() > 1) nr = r->GroupStart();
+            for (size_t l = 0; l < g->leaders.size() && nr == ncclSuccess; l++) {
                 mvhdp_ctx* L = g->members[g->leaders[l]];
-                GHIP(g, hipSetDevice(L->device));
-                GNCCL(g, r->AllReduce(g->d_key[l], g->d_key[l], 1, ncclInt64, ncclMin, g->comms[l], L->stream));
+                hip(hipSetDevice(L->device), "hipSetDevice");
+                nr = r->AllReduce(g->d_key[l], g->d_key[l], 1, ncclInt64, ncclMin, g->comms[l], L->stream);
             }
-            if (g->comms.size() > 1) GNCCL(g, r->GroupEnd());
-            GHIP(g, hipSetDevice(L0->device));
-            GHIP(g, hipMemcpyAsync(&key, g->d_key[0], sizeof key, hipMemcpyDeviceToHost, L0->stream));
-            GHIP(g, hipStreamSynchronize(L0->stream));
+            if (g->comms.size() > 1 && nr == ncclSuccess) nr = r->GroupEnd();
+            if (nr != ncclSuccess) note(MVHDP_ERR_HIP, std::string("activation key all-reduce: ") + r->GetErrorString(nr));
+            hip(hipSetDevice(L0->device), "hipSetDevice");
+            hip(hipMemcpyAsync(&key, g->d_key[0], sizeof key, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
+            hip(hipStreamSynchronize(L0->stream), "hipStreamSynchronize");
         }
     }
-    GHIP(g, hipSetDevice(L0->device));
-    GHIP(g, hipEventRecord(g->ev_x1, L0->stream));
+    if (xrc != MVHDP_OK && local_err == MVHDP_OK) local_err = xrc;         // (g->err was set where the collective failed)
+    // the status word of the whole group, read behind everything this step put on the first device's stream
+    int32_t failed_ranks = 0;
+    hip(hipSetDevice(L0->device), "hipSetDevice");
+    hip(hipEventRecord(g->ev_x1, L0->stream), "hipEventRecord");
+    hip(hipMemcpyAsync(&failed_ranks, L0->mm.delta + len, sizeof failed_ranks, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
+    hip(hipStreamSynchronize(L0->stream), "hipStreamSynchronize");
     const int32_t topic = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_TOPIC(key), view = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_VIEW(key);
-    first_err = MVHDP_OK;
     for (int i = 0; i < n; i++) {
-        const int rc2 = mvhdp_apply_delta_end(g->members[i], topic, view);
-        if (rc2 != MVHDP_OK && first_err == MVHDP_OK) { first_err = rc2; g->err = "member " + std::to_string(i) + ": " + g->members[i]->err; }
+        mvhdp_ctx* h = g->members[i];
+        if (applying) {
+            const int rc2 = mvhdp_apply_delta_end(h, topic, view);
+            if (rc2 != MVHDP_OK) note(rc2, "member " + std::to_string(i) + ": " + h->err);
+        } else if (h->rows_applied >= 0) {                  // a bracket this step opened and could not close
+            hipSetDevice(h->device); hipStreamSynchronize(h->stream);
+            h->rows_applied = -1; h->have_trees = false; h->counts_stale = true; h->delta_pending = false;
+        } else { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
         st[i].activation_key = key; st[i].activated_topic = topic; st[i].activated_modality = view;
         st[i].activations = topic >= 0 ? 1 : 0;
     }
     float ms = 0;
     hipSetDevice(L0->device);
     if (hipEventElapsedTime(&ms, g->ev_x0, g->ev_x1) == hipSuccess) g->last_exchange_ms += ms;
-    return first_err;
+    if (local_err != MVHDP_OK) return local_err;
+    if (failed_ranks > 0) {
+        // the other replicas applied the same (partial) sum and agree with each other; the model as a whole needs the recount
+        for (int i = 0; i < n; i++) g->members[i]->counts_stale = true;
+        GFAIL(g, MVHDP_ERR_STATE, "the sweep failed on " + std::to_string(failed_ranks) + " other rank(s) of the group: call mvhdp_group_build_counts on every rank");
+    }
+    return MVHDP_OK;
+}
+
+// A host whose rank cannot go on (an exception outside the library, a signal it handles) calls this BEFORE its next mvhdp_group_sweep:
+// that sweep then samples nothing here, enters the collectives with zero deltas and fails on every rank together -- nobody is left
+// waiting inside an all-reduce for a rank that will never arrive.
+extern "C" int mvhdp_group_abort(mvhdp_group g)
+{
+    CHECK_G(g);
+    g->abort_raised = true;
+    return MVHDP_OK;
 }
 
 // One Gibbs sweep of the whole model (see the head of this file).  flags: MVHDP_SWEEP_EXACT_CHAIN, MVHDP_SWEEP_GENERIC_KERNEL,
@@ -470,6 +556,7 @@ extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t see
     if (flags & (MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_FROZEN | 0xff000000u))
         GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: NO_APPLY, REUSE_TREES and ONLY_SEGMENT are set by the group itself; FROZEN is a single-handle mode");
     if ((flags & MVHDP_SWEEP_SEGMENT_APPLY) && (flags & MVHDP_SWEEP_LIVE)) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: SEGMENT_APPLY excludes LIVE");
+    DeviceGuard dg;
     const int n = (int)g->members.size();
     std::vector<mvhdp_sweep_stats> total((size_t)n), st((size_t)n);
     g->last_exchange_ms = 0.0;
@@ -477,7 +564,8 @@ extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t see
     if (flags & MVHDP_SWEEP_SEGMENT_APPLY) {
         int nseg = (int)((flags >> 16) & 0xffu);
         if (nseg == 0) nseg = 4;
-        for (int i = 0; i < n; i++) nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, g->members[i]->mm.D));   // (every member must have every segment)
+        // (the segment count comes from the flags alone -- every rank issues the same number of exchanges; a member with fewer entities
+        // than segments simply has empty ones)
         const uint32_t base = (flags & ~(MVHDP_SWEEP_SEGMENT_APPLY | MVHDP_SWEEP_LIVE_SEGMENTS(0xff))) | MVHDP_SWEEP_LIVE_SEGMENTS(nseg);
         for (int s = 0; s < nseg && ret == MVHDP_OK; s++) {
             ret = group_step(g, sweep_idx, seed, base | MVHDP_SWEEP_ONLY_SEGMENT(s), st);
@@ -499,4 +587,163 @@ extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t see
     g->sweeps++;
     if (stats) for (int i = 0; i < n; i++) stats[i] = total[i];
     return ret;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The steps either side of the sweep for a sharded model (what estimate() does every optimizeInterval and
+// every tenth iteration, PTM:1173-1210, PTM:1296-1320).  The counts are replicated, the entities are not: a statistic
+// over n_wk / n_k is any member's, a statistic over the entities is the members' put together --
+//   in ONE process, in ascending doc_id_base, carrying the running sum from member to member: the additions are those
+//   of a single handle holding every entity, in the same order, bit for bit;
+//   across processes (one member each), every rank's partial result is made known to all ranks (an all-reduce of a buffer
+//   that is zero outside the rank's own slot: exact) and added in rank order: deterministic for a given sharding, equal to
+//   the single handle's to rounding.  Collective there: every rank must call.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// all[r*n + i] = rank r's vals[i]; single process: all = vals
+int xrank_gather_f64(mvhdp_group_ctx* g, const double* vals, int n, std::vector<double>& all)
+{
+    if (!g->multi_process || g->nranks <= 1) { all.assign(vals, vals + n); return MVHDP_OK; }
+    mvhdp_ctx* L = g->members[g->leaders[0]];
+    const size_t total = (size_t)g->nranks * n;
+    std::vector<double> host(total, 0.0);
+    std::copy(vals, vals + n, host.begin() + (size_t)g->rank0 * n);
+    double* d = nullptr;
+    GHIP(g, hipSetDevice(L->device));
+    GHIP(g, hipMalloc(&d, total * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d, host.data(), total * sizeof(double), hipMemcpyHostToDevice, L->stream);
+    ncclResult_t nr = ncclSuccess;
+    if (e == hipSuccess) nr = g_rccl.AllReduce(d, d, total, ncclDouble, ncclSum, g->comms[0], L->stream);
+    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(host.data(), d, total * sizeof(double), hipMemcpyDeviceToHost, L->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
+    hipFree(d);
+    GHIP(g, e);
+    if (nr != ncclSuccess) GFAIL(g, MVHDP_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
+    all.swap(host);
+    return MVHDP_OK;
+}
+
+// vals[i] <- sum over ranks (integers: any order)
+int xrank_sum_i32(mvhdp_group_ctx* g, int32_t* vals, size_t n)
+{
+    if (!g->multi_process || g->nranks <= 1 || n == 0) return MVHDP_OK;
+    mvhdp_ctx* L = g->members[g->leaders[0]];
+    int32_t* d = nullptr;
+    GHIP(g, hipSetDevice(L->device));
+    GHIP(g, hipMalloc(&d, n * sizeof(int32_t)));
+    hipError_t e = hipMemcpyAsync(d, vals, n * sizeof(int32_t), hipMemcpyHostToDevice, L->stream);
+    ncclResult_t nr = ncclSuccess;
+    if (e == hipSuccess) nr = g_rccl.AllReduce(d, d, n, ncclInt32, ncclSum, g->comms[0], L->stream);
+    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(vals, d, n * sizeof(int32_t), hipMemcpyDeviceToHost, L->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
+    hipFree(d);
+    GHIP(g, e);
+    if (nr != ncclSuccess) GFAIL(g, MVHDP_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
+    return MVHDP_OK;
+}
+
+}  // namespace
+
+// the hyper-parameters are replicated: every local member takes them (every rank calls with the same values)
+extern "C" int mvhdp_group_set_hyper(mvhdp_group g, const mvhdp_hyper* hy)
+{
+    CHECK_G(g);
+    DeviceGuard dg;
+    for (size_t i = 0; i < g->members.size(); i++) GMEM(g, i, mvhdp_set_hyper(g->members[i], hy));
+    return MVHDP_OK;
+}
+
+// modelLogLikelihood PTM:3322-3452 of the whole model: the document part summed over every entity of every member in entity order,
+// the model part (modalityCnt term, topic-word term, tokensPerTopic terms) once, from the replicated counts.
+extern "C" int mvhdp_group_log_likelihood(mvhdp_group g, double* out)
+{
+    CHECK_G(g);
+    if (!out) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_log_likelihood: null");
+    DeviceGuard dg;
+    const int M = g->members[0]->mm.M;
+    for (int m = 0; m < M; m++) {
+        double ll = 0;
+        int64_t cnt = 0;
+        for (int i : g->by_entity) GMEM(g, i, mvhdp_ll_doc_accumulate(g->members[i], m, &ll, &cnt));
+        if (g->multi_process && g->nranks > 1) {
+            const double mine[2] = {ll, (double)cnt};
+            std::vector<double> all;
+            int rc = xrank_gather_f64(g, mine, 2, all); if (rc) return rc;
+            ll = 0; double c = 0;
+            for (int r = 0; r < g->nranks; r++) { ll += all[(size_t)2 * r]; c += all[(size_t)2 * r + 1]; }
+            cnt = (int64_t)c;
+        }
+        GMEM(g, 0, mvhdp_ll_model_finish(g->members[0], m, ll, cnt, &out[m]));
+    }
+    return MVHDP_OK;
+}
+
+// topicDocCounts[m][k][c] and docLengthCounts[m][len] (PTM:620-651, UPD:220-232) over every entity of every member
+extern "C" int mvhdp_group_doc_topic_hist(mvhdp_group g, int32_t m, int32_t* hist, int32_t hist_len, int32_t* doc_len_counts, int32_t len_len)
+{
+    CHECK_G(g);
+    DeviceGuard dg;
+    const int K = g->members[0]->mm.K;
+    const size_t nh = hist ? (size_t)K * (size_t)std::max(hist_len, 0) : 0, nl = doc_len_counts ? (size_t)std::max(len_len, 0) : 0;
+    std::vector<int32_t> th(nh), tl(nl);
+    if (hist) std::fill(hist, hist + nh, 0);
+    if (doc_len_counts) std::fill(doc_len_counts, doc_len_counts + nl, 0);
+    for (size_t i = 0; i < g->members.size(); i++) {
+        GMEM(g, i, mvhdp_get_doc_topic_hist(g->members[i], m, hist ? th.data() : nullptr, hist_len, doc_len_counts ? tl.data() : nullptr, len_len));
+        for (size_t q = 0; q < nh; q++) hist[q] += th[q];
+        for (size_t q = 0; q < nl; q++) doc_len_counts[q] += tl[q];
+    }
+    int rc = xrank_sum_i32(g, hist, nh); if (rc) return rc;
+    return xrank_sum_i32(g, doc_len_counts, nl);
+}
+
+// countHistogram of optimizeBeta PTM:2295-2309: a statistic of the replicated n_wk -- any member's
+extern "C" int mvhdp_group_count_histogram(mvhdp_group g, int32_t m, int32_t* hist, int32_t len)
+{
+    CHECK_G(g);
+    DeviceGuard dg;
+    GMEM(g, 0, mvhdp_get_count_histogram(g->members[0], m, hist, len));
+    return MVHDP_OK;
+}
+
+// optimizeP PTM:2706-2792: sums[m][i] over every entity, in entity order
+extern "C" int mvhdp_group_view_overlap_sums(mvhdp_group g, double* sums)
+{
+    CHECK_G(g);
+    if (!sums) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_view_overlap_sums: null");
+    DeviceGuard dg;
+    const int M = g->members[0]->mm.M;
+    for (int i = 0; i < M * M; i++) sums[i] = 0.0;
+    for (int i : g->by_entity) GMEM(g, i, mvhdp_view_overlap_accumulate(g->members[i], sums));
+    if (g->multi_process && g->nranks > 1) {
+        std::vector<double> all;
+        int rc = xrank_gather_f64(g, sums, M * M, all); if (rc) return rc;
+        for (int i = 0; i < M * M; i++) { double a = 0; for (int r = 0; r < g->nranks; r++) a += all[(size_t)r * M * M + i]; sums[i] = a; }
+    }
+    return MVHDP_OK;
+}
+
+// optimizeGamma's document level PTM:2415-2433 (mvhdp_gamma_doc_statistics): every entity draws from its own stream (global entity
+// id), so the two sums over a sharded model are the same random variables; the members' sums are added in entity order
+extern "C" int mvhdp_group_gamma_doc_statistics(mvhdp_group g, int32_t m, double gamma_m, uint64_t seed, uint32_t round, double* qs, double* qw)
+{
+    CHECK_G(g);
+    if (!qs || !qw) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_gamma_doc_statistics: null");
+    DeviceGuard dg;
+    double a = 0, b = 0;
+    for (int i : g->by_entity) {
+        double x = 0, y = 0;
+        GMEM(g, i, mvhdp_gamma_doc_statistics(g->members[i], m, gamma_m, seed, round, &x, &y));
+        a += x; b += y;
+    }
+    if (g->multi_process && g->nranks > 1) {
+        const double mine[2] = {a, b};
+        std::vector<double> all;
+        int rc = xrank_gather_f64(g, mine, 2, all); if (rc) return rc;
+        a = 0; b = 0;
+        for (int r = 0; r < g->nranks; r++) { a += all[(size_t)2 * r]; b += all[(size_t)2 * r + 1]; }
+    }
+    *qs = a; *qw = b;
+    return MVHDP_OK;
 }

@@ -44,6 +44,7 @@ struct PlanIn {
     bool debug = false;
     bool batch = false;                         // mvhdp_sweep_many: the plan must hold for several sweeps (lists move between them)
     bool trees_current = false;                 // the F+trees (and the 16-bit mirror) match the counts before this call
+    bool unassigned = false;                    // some token may still be unassigned (z = -1): row totals can grow during the sweep
     int first_inactive = -1;
     int num_cus = 256;
     size_t max_lds = 160 * 1024;
@@ -309,9 +310,11 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // (a deferred sweep accepts a segment count too: same integers as one segment, the trees being those of the snapshot)
     int nseg = (int)((flags >> 16) & 0xffu);
     if (nseg == 0) nseg = (p.live || p.seg_apply) ? 4 : 1;
-    if ((int64_t)nseg > in.D) nseg = (int)std::max<int64_t>(1, in.D);
-    p.nseg = nseg;
     p.only_seg = (int)(flags >> 24) - 1;                  // MVHDP_SWEEP_ONLY_SEGMENT(s): -1 = every segment
+    // (more segments than entities: a whole sweep uses fewer; a single-segment call keeps the caller's count -- segments beyond the
+    // last entity are empty -- so that document shards of different sizes walk through the same number of exchanges)
+    if ((int64_t)nseg > in.D && p.only_seg < 0) nseg = (int)std::max<int64_t>(1, in.D);
+    p.nseg = nseg;
     if (p.only_seg >= 0) {
         if (p.live || p.seg_apply) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT excludes LIVE and SEGMENT_APPLY");
         if (p.only_seg >= nseg) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT beyond the segment count");
@@ -379,7 +382,9 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // ---- walk thresholds of this sweep and the kernel flavours that go with them ----
     // which threshold group a class's kernel belongs to: decided by its flavour (below), which for class 0 depends on the mirror
     const bool mirror_ok = fast && !in.debug && tu.narrow != 0 && (!(flags & MVHDP_SWEEP_REUSE_TREES) || in.trees_current);
-    const bool want_live16 = mirror_ok && p.live && !p.frozen && (tu.live16 > 0 || (tu.live16 < 0 && K >= 256));
+    // (not while a token may be unassigned: its first visit only ADDS to its row, so a row classified light when its tree was built
+    // could reach 65535 in a cell -- read as "see the 32-bit table" -- or carry into the neighbouring cell of the packed word)
+    const bool want_live16 = mirror_ok && p.live && !p.frozen && !in.unassigned && (tu.live16 > 0 || (tu.live16 < 0 && K >= 256));
     auto group_of = [&](int c) { return c != 0 ? 2 : ((mirror_ok && (!p.live || want_live16)) ? 0 : 1); };
     double theta[WALK_GROUPS][MVHDP_MAXM] = {{0}};
     bool measure = false;

@@ -176,16 +176,19 @@ __global__ __launch_bounds__(256) void loglik_topic_kernel(const int32_t* __rest
     if (nz) atomicAdd(nonzero, (unsigned long long)nz);
 }
 
-hipError_t mvhdp_launch_loglik(const MvModel& mm, int m, double* doc_out, double* partial, int n_partial,
-                               unsigned long long* nonzero, hipStream_t s)
+hipError_t mvhdp_launch_loglik_doc(const MvModel& mm, int m, double* doc_out, hipStream_t s)
 {
-    if (mm.D > 0) {
-        int wpb = 4;
-        while (wpb > 1 && (size_t)wpb * mm.K * sizeof(int) > 60000) wpb >>= 1;
-        int64_t blocks = (mm.D + wpb - 1) / wpb;
-        int grid = (int)(blocks < 4096 ? blocks : 4096);
-        hipLaunchKernelGGL(loglik_doc_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * mm.K * sizeof(int), s, mm, m, doc_out);
-    }
+    if (mm.D <= 0) return hipSuccess;
+    int wpb = 4;
+    while (wpb > 1 && (size_t)wpb * mm.K * sizeof(int) > 60000) wpb >>= 1;
+    int64_t blocks = (mm.D + wpb - 1) / wpb;
+    int grid = (int)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(loglik_doc_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * mm.K * sizeof(int), s, mm, m, doc_out);
+    return hipGetLastError();
+}
+
+hipError_t mvhdp_launch_loglik_topic(const MvModel& mm, int m, double* partial, int n_partial, unsigned long long* nonzero, hipStream_t s)
+{
     hipError_t e = hipMemsetAsync(nonzero, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     int64_t n = (int64_t)mm.V[m] * mm.K;

@@ -75,6 +75,25 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 // every variant: there the chunk-end atomics of the light rows land IN the mirror -- two 16-bit cells per 32-bit word, +-1 or +-65536,
 // which cannot carry: a light row's cell stays below 65535 and a decrement only ever takes back a token that was counted -- so the
 // mirror is what every later token of the sweep reads (UPD:197-207 applied while the workers sample), at half the gather traffic.
+// How a live sweep's gathers see the other waves' atomics (diagnostics; tools/microbench/live_staleness.hip):
+// MVHDP_GATHER_SC = 0 plain loads, 1 agent scope (global_load ... sc1: past the CU's L1), 3 system scope (sc0 sc1), 4 non-temporal
+#ifndef MVHDP_GATHER_SC
+#define MVHDP_GATHER_SC 0
+#endif
+template <typename T>
+__device__ __forceinline__ int gather_cell(gptr_t p)
+{
+    const __attribute__((address_space(1))) T* q = (const __attribute__((address_space(1))) T*)p;
+#if MVHDP_GATHER_SC == 1
+    return (int)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif MVHDP_GATHER_SC == 3
+    return (int)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif MVHDP_GATHER_SC == 4
+    return (int)__builtin_nontemporal_load(q);
+#else
+    return (int)*q;
+#endif
+}
 #define W_HEAVY 0x40000000                      // bit 30 of a lane's type id: the row is heavy (type ids stay below 2^30: mvhdp_create checks)
 #define W_ROW(w) ((w) & 0x3fffffff)
 // ROOMY (the 2-round variant on the mirror only): the same kernel compiled for 6 waves per SIMD (80 registers, a third of the scratch
@@ -443,11 +462,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     if (NARROW && !h0) {
                         const gptr_t c0q = scalar_row(nwk16_v, r0, (unsigned int)K * 2u);
 #pragma unroll
-                        for (int r = 0; r < RMAX; r++) { const int v = (int)*(const __attribute__((address_space(1))) uint16_t*)(c0q + (unsigned int)koffh[r]); if (a == 0) gn[r] = v; else gn2[r] = v; }
+                        for (int r = 0; r < RMAX; r++) { const int v = gather_cell<uint16_t>(c0q + (unsigned int)koffh[r]); if (a == 0) gn[r] = v; else gn2[r] = v; }
                     } else {
                         const gptr_t c0p = scalar_row(nwk_v, r0, (unsigned int)K * 4u);
 #pragma unroll
-                        for (int r = 0; r < RMAX; r++) { const int v = *(const __attribute__((address_space(1))) int32_t*)(c0p + (unsigned int)koff[r]); if (a == 0) gn[r] = v; else gn2[r] = v; }
+                        for (int r = 0; r < RMAX; r++) { const int v = gather_cell<int32_t>(c0p + (unsigned int)koff[r]); if (a == 0) gn[r] = v; else gn2[r] = v; }
                     }
                 }
 

@@ -27,15 +27,16 @@ __device__ __forceinline__ float bcast_f(float v, int src_lane)
 // v with lane `lane` (wave-uniform) set to `val` (wave-uniform): one v_writelane_b32 instead of a compare and a select.  This clang has
 // no builtin for it; the lane select goes through M0 (two different SGPR operands would exceed the constant-bus limit of the
 // encoding).  M0 is not saved: the compiler treats it as reserved and only ever loads it immediately before an instruction that
-// reads it (none in these kernels: tests/test_abi.py disassembles the built library and fails on any other mention of m0), and the scalar unit,
-// which these moves run on, is as busy as the vector unit in the token loop.
+// reads it (none in these kernels: tests/test_abi.py disassembles the built library and fails on any other mention of m0) -- and the asm
+// declares the clobber, so a build with other flags stays sound without that test.  The scalar unit, which these moves run on, is as
+// busy as the vector unit in the token loop.
 __device__ __forceinline__ int wave_writelane(int v, int val, int lane)
 {
     val = __builtin_amdgcn_readfirstlane(val);           // (free where the compiler knows the value to be uniform; where it does not, this is
     lane = __builtin_amdgcn_readfirstlane(lane);         // what makes it a scalar register -- the "s" constraint alone does not)
     asm volatile("s_mov_b32 m0, %2\n\t"
                  "v_writelane_b32 %0, %1, m0"
-                 : "+v"(v) : "s"(val), "s"(lane));
+                 : "+v"(v) : "s"(val), "s"(lane) : "m0");
     return v;
 }
 // The address of a row of a table: base + index * row_bytes with a 32 x 32 -> 64-bit scalar multiply (two scalar instructions instead of

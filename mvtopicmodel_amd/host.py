@@ -19,7 +19,7 @@ HOST_SYMBOLS = [
     "mvtm_model_print_state", "mvtm_model_display_top_words", "mvtm_number_format5", "mvtm_model_print_document_topics", "mvtm_java_double_to_string", "mvtm_model_optimize_p", "mvtm_model_optimize_beta", "mvtm_model_log_likelihood", "mvtm_model_get_perplexities",
     "mvtm_model_seed_host_samplers", "mvtm_model_optimize_dp", "mvtm_model_optimize_gamma",
     "mvtm_cokus_stream", "mvtm_rand_antoniak_seq", "mvtm_random_samplers_stream", "mvtm_mallet_next_gamma_stream",
-    "mvtm_model_set_live_updates", "mvtm_model_set_device_gamma_statistics", "mvtm_model_get_inferencer", "mvtm_inferencer_delete", "mvtm_inferencer_configure",
+    "mvtm_model_set_live_updates", "mvtm_model_set_shards", "mvtm_model_set_device_gamma_statistics", "mvtm_model_get_inferencer", "mvtm_inferencer_delete", "mvtm_inferencer_configure",
     "mvtm_inferencer_infer", "mvtm_inferencer_num_entities", "mvtm_inferencer_view_tokens", "mvtm_inferencer_get_view",
     "mvtm_inferencer_doc_topics", "mvtm_inferencer_print_document_topics", "mvtm_inferencer_get_stats",
 ]
@@ -81,6 +81,7 @@ def _lib():
         L.mvtm_mallet_next_gamma_stream.argtypes = [i64, dbl, dbl, i32, vp]
         L.mvtm_model_set_live_updates.argtypes = [vp, i32, i32]
         L.mvtm_model_set_device_gamma_statistics.argtypes = [vp, i32]
+        L.mvtm_model_set_shards.argtypes = [vp, i32]
         L.mvtm_model_get_inferencer.argtypes = [vp, vp, vp]; L.mvtm_model_get_inferencer.restype = vp
         L.mvtm_inferencer_delete.argtypes = [vp]; L.mvtm_inferencer_delete.restype = None
         L.mvtm_inferencer_configure.argtypes = [vp, i32, i32, i32]
@@ -199,6 +200,10 @@ class FastQMVWVParallelTopicModel:
     def setSegmentedUpdates(self, segments=0):
         """MVHDP_SWEEP_SEGMENT_APPLY: deterministic sweeps in `segments` segments with the deltas applied in between."""
         self.L.mvtm_model_set_live_updates(self.p, 2, int(segments))
+
+    def setNumShards(self, n):
+        """Before addInstances: the model as n document shards behind an mvhdp_group; every step of estimate() runs over the group."""
+        self.L.mvtm_model_set_shards(self.p, int(n))
 
     def setDeviceGammaStatistics(self, on):
         """optimizeGamma's per-entity sums on the device instead of the reference's sequential host loop."""

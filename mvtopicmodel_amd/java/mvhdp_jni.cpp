@@ -12,6 +12,7 @@
 // A negative status becomes a RuntimeException carrying mvhdp_last_error().
 #include <jni.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -28,28 +29,55 @@ struct Shard {                       // what the jlong handle points to: the lib
     int V[MVHDP_MAX_MODALITIES] = {};
     jlong D = -1;
     jlong N[MVHDP_MAX_MODALITIES] = {};
+    int pins = 0;                    // JNI calls currently inside the library on this handle (guarded by g_reg_mutex)
 };
 
 // Every Shard (and group) the shim has handed to Java is listed here; a jlong that is not listed -- closed already, e.g. by a
-// finalizer racing an explicit close() -- is refused instead of dereferenced.
+// finalizer racing an explicit close() -- is refused instead of dereferenced.  A call that found its object PINS it for its
+// duration: close() takes the object out of the registry at once (no new call can find it) and then waits until the calls already
+// inside the library have returned before it frees anything -- a close() racing a sweep on another thread cannot pull the handle
+// from under it.
 std::mutex g_reg_mutex;
+std::condition_variable g_reg_cv;
 std::set<void*> g_shards, g_groups;
-
-inline Shard* S(jlong p)
-{
-    std::lock_guard<std::mutex> lk(g_reg_mutex);
-    return g_shards.count(reinterpret_cast<void*>(p)) ? reinterpret_cast<Shard*>(p) : nullptr;
-}
 
 struct Group {                        // an mvhdp_group and how many members it has in this process
     mvhdp_group g = nullptr;
     int members = 0;
+    int pins = 0;
 };
 
-inline Group* G(jlong p)
+template <class T>
+struct Pin {
+    T* s = nullptr;
+    Pin(std::set<void*>& reg, jlong p)
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        if (reg.count(reinterpret_cast<void*>(p))) { s = reinterpret_cast<T*>(p); s->pins++; }
+    }
+    ~Pin()
+    {
+        if (!s) return;
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        if (--s->pins == 0) g_reg_cv.notify_all();
+    }
+    Pin(const Pin&) = delete;
+    Pin& operator=(const Pin&) = delete;
+};
+struct ShardPin : Pin<Shard> { explicit ShardPin(jlong p) : Pin<Shard>(g_shards, p) {} };
+struct GroupPin : Pin<Group> { explicit GroupPin(jlong p) : Pin<Group>(g_groups, p) {} };
+
+// close(): out of the registry under the lock, then wait for the calls that are still inside
+template <class T>
+T* unregister_and_drain(std::set<void*>& reg, jlong p)
 {
-    std::lock_guard<std::mutex> lk(g_reg_mutex);
-    return g_groups.count(reinterpret_cast<void*>(p)) ? reinterpret_cast<Group*>(p) : nullptr;
+    std::unique_lock<std::mutex> lk(g_reg_mutex);
+    auto it = reg.find(reinterpret_cast<void*>(p));
+    if (it == reg.end()) return nullptr;
+    T* s = reinterpret_cast<T*>(*it);
+    reg.erase(it);
+    g_reg_cv.wait(lk, [&] { return s->pins == 0; });
+    return s;
 }
 
 void throw_msg(JNIEnv* env, const char* cls, const char* msg)
@@ -125,21 +153,15 @@ JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nCreate(JNIEn
 // nothing and touches nothing.
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nDestroy(JNIEnv*, jclass, jlong p)
 {
-    Shard* s = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_reg_mutex);
-        auto it = g_shards.find(reinterpret_cast<void*>(p));
-        if (it == g_shards.end()) return;
-        s = reinterpret_cast<Shard*>(*it);
-        g_shards.erase(it);
-    }
+    Shard* s = unregister_and_drain<Shard>(g_shards, p);
+    if (!s) return;
     mvhdp_destroy(s->h);
     delete s;
 }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetCorpus(JNIEnv* env, jclass, jlong p, jint m, jlongArray docOff, jintArray tokens)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M || !docOff || env->GetArrayLength(docOff) < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "setCorpus: bad view or docOff"); return; }
     const jsize D = env->GetArrayLength(docOff) - 1;
@@ -160,7 +182,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetCorpus(JNI
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetAssignments(JNIEnv* env, jclass, jlong p, jint m, jintArray z)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "setAssignments: bad view"); return; }
     if (s->N[m] > 0 && bad_len(env, z, s->N[m], "setAssignments")) return;
@@ -173,7 +195,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetAssignment
 // which entities HAVE the view (Assignments[m] != null) even when its FeatureSequence is empty: mvhdp_set_view_presence
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetViewPresence(JNIEnv* env, jclass, jlong p, jint m, jbooleanArray present)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "setViewPresence: bad view"); return; }
     int rc;
@@ -189,7 +211,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetViewPresen
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAssignments(JNIEnv* env, jclass, jlong p, jint m, jintArray z)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "getAssignments: bad view"); return; }
     if (s->N[m] == 0) return;
@@ -202,7 +224,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAssignment
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetHyper(JNIEnv* env, jclass, jlong p, jobjectArray alpha, jdoubleArray alphaSum,
         jdoubleArray beta, jdoubleArray betaSum, jdoubleArray gamma, jobjectArray p_a, jobjectArray p_b, jbooleanArray inactive)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     const jsize M = s->M, K1 = s->K + 1;
     if (bad_len(env, alpha, M, "setHyper alpha") || bad_len(env, p_a, M, "setHyper p_a") || bad_len(env, p_b, M, "setHyper p_b") ||
@@ -238,16 +260,16 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetHyper(JNIE
 }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildCounts(JNIEnv* env, jclass, jlong p)
-{ Shard* s = S(p); if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+{ ShardPin pin_(p); Shard* s = pin_.s; if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
   int rc = mvhdp_build_counts(s->h); if (rc) throw_rt(env, s->h, rc, "mvhdp_build_counts"); }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nBuildTrees(JNIEnv* env, jclass, jlong p)
-{ Shard* s = S(p); if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+{ ShardPin pin_(p); Shard* s = pin_.s; if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
   int rc = mvhdp_build_trees(s->h); if (rc) throw_rt(env, s->h, rc, "mvhdp_build_trees"); }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetCounts(JNIEnv* env, jclass, jlong p, jint m, jintArray nwk, jintArray nk)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M) { throw_msg(env, "java/lang/IllegalArgumentException", "getCounts: bad view"); return; }
     if ((nwk && bad_len(env, nwk, (jlong)s->V[m] * s->K, "getCounts typeTopicCounts")) || (nk && bad_len(env, nk, s->K, "getCounts tokensPerTopic"))) return;
@@ -259,7 +281,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetCounts(JNI
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetDocTopicHist(JNIEnv* env, jclass, jlong p, jint m, jintArray hist, jint histLen, jintArray lens)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (m < 0 || m >= s->M || histLen < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "getDocTopicHist: bad view or length"); return; }
     if (hist && bad_len(env, hist, (jlong)s->K * histLen, "getDocTopicHist hist")) return;
@@ -271,7 +293,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetDocTopicHi
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAlpha(JNIEnv* env, jclass, jlong p, jdoubleArray alphaFlat, jbooleanArray inactive)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (bad_len(env, alphaFlat, (jlong)s->M * (s->K + 1), "getAlpha alpha") || bad_len(env, inactive, s->K, "getAlpha inactive")) return;
     std::vector<double> a(static_cast<size_t>(s->M) * (s->K + 1));
@@ -284,7 +306,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetAlpha(JNIE
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv* env, jclass, jlong p, jint sweepIdx, jlong seed, jint flags, jdoubleArray pOverride, jobject out)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (pOverride && bad_len(env, pOverride, s->D * s->M * s->M, "sweep pOverride [D][M][M]")) return;
     mvhdp_sweep_stats st;
@@ -310,12 +332,12 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweep(JNIEnv*
 }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nApplyDelta(JNIEnv* env, jclass, jlong p, jint topic, jint modality)
-{ Shard* s = S(p); if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+{ ShardPin pin_(p); Shard* s = pin_.s; if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
   int rc = mvhdp_apply_delta(s->h, topic, modality); if (rc) throw_rt(env, s->h, rc, "mvhdp_apply_delta"); }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nModelLogLikelihood(JNIEnv* env, jclass, jlong p, jdoubleArray out)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (bad_len(env, out, s->M, "modelLogLikelihood")) return;
     double ll[MVHDP_MAX_MODALITIES];
@@ -335,7 +357,7 @@ static void stats_to_longs(const mvhdp_sweep_stats& st, jlong* o)
 // the iteration loop PTM:1146-1239 without a host round trip per iteration (mvhdp_sweep_many)
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweepMany(JNIEnv* env, jclass, jlong p, jint firstIdx, jint n, jlong seed, jint flags, jlongArray statsFlat)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (n < 0 || (statsFlat && bad_len(env, statsFlat, (jlong)n * 8, "sweepMany stats [n][8]"))) return;
     std::vector<mvhdp_sweep_stats> st(static_cast<size_t>(n > 0 ? n : 1));
@@ -352,7 +374,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSweepMany(JNI
 // doubles = {primaryMinShare, walkTheta[8], treeBranchShare[8]}
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetTuning(JNIEnv* env, jclass, jlong p, jintArray ints, jdoubleArray doubles)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (bad_len(env, ints, 8, "getTuning ints") || bad_len(env, doubles, 17, "getTuning doubles")) return;
     mvhdp_tuning t;
@@ -368,7 +390,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetTuning(JNI
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetTuning(JNIEnv* env, jclass, jlong p, jintArray ints, jdoubleArray doubles)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
     if (bad_len(env, ints, 8, "setTuning ints") || bad_len(env, doubles, 17, "setTuning doubles")) return;
     jint iv[8]; jdouble dv[17];
@@ -401,7 +423,7 @@ JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupCreate(
     env->GetLongArrayRegion(handles, 0, n, hp.data());
     std::vector<mvhdp_handle> hs;
     for (jsize i = 0; i < n; i++) {
-        Shard* s = S(hp[i]);
+        ShardPin pin_(hp[i]); Shard* s = pin_.s;
         if (!s) { throw_msg(env, "java/lang/IllegalStateException", "groupCreate: a member is closed"); return 0; }
         hs.push_back(s->h);
     }
@@ -425,7 +447,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupUniqueId
 
 JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupCreateRank(JNIEnv* env, jclass, jlong p, jbyteArray id, jint rank, jint nranks)
 {
-    Shard* s = S(p);
+    ShardPin pin_(p); Shard* s = pin_.s;
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return 0; }
     if (bad_len(env, id, MVHDP_UNIQUE_ID_BYTES, "groupCreateRank id")) return 0;
     uint8_t buf[MVHDP_UNIQUE_ID_BYTES];
@@ -440,21 +462,15 @@ JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupCreateR
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupDestroy(JNIEnv*, jclass, jlong p)
 {
-    Group* gr = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_reg_mutex);
-        auto it = g_groups.find(reinterpret_cast<void*>(p));
-        if (it == g_groups.end()) return;
-        gr = reinterpret_cast<Group*>(*it);
-        g_groups.erase(it);
-    }
+    Group* gr = unregister_and_drain<Group>(g_groups, p);
+    if (!gr) return;
     mvhdp_group_destroy(gr->g);
     delete gr;
 }
 
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupBuildCounts(JNIEnv* env, jclass, jlong p)
 {
-    Group* gr = G(p);
+    GroupPin gpin_(p); Group* gr = gpin_.s;
     if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
     int rc = mvhdp_group_build_counts(gr->g);
     if (rc) throw_group(env, gr->g, rc, "mvhdp_group_build_counts");
@@ -464,7 +480,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupBuildCou
 // returns the device milliseconds of the exchange (collectives + updates + tree rebuilds)
 JNIEXPORT jdouble JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupSweep(JNIEnv* env, jclass, jlong p, jint sweepIdx, jlong seed, jint flags, jlongArray statsFlat, jintArray act)
 {
-    Group* gr = G(p);
+    GroupPin gpin_(p); Group* gr = gpin_.s;
     if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return 0.0; }
     if ((statsFlat && bad_len(env, statsFlat, (jlong)gr->members * 8, "groupSweep stats [members][8]")) || (act && bad_len(env, act, 3, "groupSweep act"))) return 0.0;
     std::vector<mvhdp_sweep_stats> st(static_cast<size_t>(gr->members));
@@ -478,6 +494,107 @@ JNIEXPORT jdouble JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupSweep
     if (act) { const jint a[3] = {st[0].activated_topic, st[0].activated_modality, st[0].activations}; env->SetIntArrayRegion(act, 0, 3, a); }
     mvhdp_group_info info;
     return mvhdp_group_get_info(gr->g, &info) == MVHDP_OK ? info.last_exchange_ms : 0.0;
+}
+
+// ---- the steps either side of the sweep: one handle, and a sharded model (mvhdp_group_*) ----
+// countHistogram of optimizeBeta PTM:2295-2309
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGetCountHistogram(JNIEnv* env, jclass, jlong p, jint m, jintArray hist)
+{
+    ShardPin pin_(p); Shard* s = pin_.s;
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (m < 0 || m >= s->M || !hist || env->GetArrayLength(hist) < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "getCountHistogram: bad view or array"); return; }
+    int rc;
+    { Ints a(env, hist, 0); if (a.failed()) return; rc = mvhdp_get_count_histogram(s->h, m, reinterpret_cast<int32_t*>(a.p), env->GetArrayLength(hist)); }
+    if (rc) throw_rt(env, s->h, rc, "mvhdp_get_count_histogram");
+}
+
+// optimizeP PTM:2706-2792: sums [M*M]
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nViewOverlapSums(JNIEnv* env, jclass, jlong p, jdoubleArray sums)
+{
+    ShardPin pin_(p); Shard* s = pin_.s;
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (bad_len(env, sums, (jlong)s->M * s->M, "viewOverlapSums")) return;
+    double v[MVHDP_MAX_MODALITIES * MVHDP_MAX_MODALITIES];
+    int rc = mvhdp_view_overlap_sums(s->h, v);
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_view_overlap_sums"); return; }
+    env->SetDoubleArrayRegion(sums, 0, s->M * s->M, v);
+}
+
+// optimizeGamma's document level PTM:2415-2433: out = {qs, qw}
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGammaDocStatistics(JNIEnv* env, jclass, jlong p, jint m, jdouble gammaM, jlong seed, jint round, jdoubleArray out)
+{
+    ShardPin pin_(p); Shard* s = pin_.s;
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (bad_len(env, out, 2, "gammaDocStatistics")) return;
+    double v[2];
+    int rc = mvhdp_gamma_doc_statistics(s->h, m, gammaM, static_cast<uint64_t>(seed), static_cast<uint32_t>(round), &v[0], &v[1]);
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_gamma_doc_statistics"); return; }
+    env->SetDoubleArrayRegion(out, 0, 2, v);
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupAbort(JNIEnv* env, jclass, jlong p)
+{
+    GroupPin gpin_(p); Group* gr = gpin_.s;
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    int rc = mvhdp_group_abort(gr->g);
+    if (rc) throw_group(env, gr->g, rc, "mvhdp_group_abort");
+}
+
+// modelLogLikelihood PTM:3322-3452 of the sharded model: out [M] (M = out.length, checked by the library's own loop bound)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupModelLogLikelihood(JNIEnv* env, jclass, jlong p, jdoubleArray out)
+{
+    GroupPin gpin_(p); Group* gr = gpin_.s;
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    if (!out || env->GetArrayLength(out) < 1 || env->GetArrayLength(out) > MVHDP_MAX_MODALITIES) { throw_msg(env, "java/lang/IllegalArgumentException", "groupModelLogLikelihood: one entry per view"); return; }
+    double ll[MVHDP_MAX_MODALITIES] = {};
+    int rc = mvhdp_group_log_likelihood(gr->g, ll);
+    if (rc) { throw_group(env, gr->g, rc, "mvhdp_group_log_likelihood"); return; }
+    env->SetDoubleArrayRegion(out, 0, env->GetArrayLength(out), ll);
+}
+
+// topicDocCounts / docLengthCounts over every entity of every member: hist [K*histLen] (K = hist.length / histLen)
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupGetDocTopicHist(JNIEnv* env, jclass, jlong p, jint m, jintArray hist, jint histLen, jintArray lens)
+{
+    GroupPin gpin_(p); Group* gr = gpin_.s;
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    if (histLen < 1 || (hist && env->GetArrayLength(hist) % histLen != 0)) { throw_msg(env, "java/lang/IllegalArgumentException", "groupGetDocTopicHist: hist must hold K rows of histLen"); return; }
+    int rc;
+    { Ints a(env, hist, 0), b(env, lens, 0); if (a.failed() || b.failed()) return;
+      rc = mvhdp_group_doc_topic_hist(gr->g, m, reinterpret_cast<int32_t*>(a.p), histLen, reinterpret_cast<int32_t*>(b.p), lens ? env->GetArrayLength(lens) : 0); }
+    if (rc) throw_group(env, gr->g, rc, "mvhdp_group_doc_topic_hist");
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupGetCountHistogram(JNIEnv* env, jclass, jlong p, jint m, jintArray hist)
+{
+    GroupPin gpin_(p); Group* gr = gpin_.s;
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    if (!hist || env->GetArrayLength(hist) < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "groupGetCountHistogram: empty array"); return; }
+    int rc;
+    { Ints a(env, hist, 0); if (a.failed()) return; rc = mvhdp_group_count_histogram(gr->g, m, reinterpret_cast<int32_t*>(a.p), env->GetArrayLength(hist)); }
+    if (rc) throw_group(env, gr->g, rc, "mvhdp_group_count_histogram");
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupViewOverlapSums(JNIEnv* env, jclass, jlong p, jdoubleArray sums)
+{
+    GroupPin gpin_(p); Group* gr = gpin_.s;
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    const jsize n = sums ? env->GetArrayLength(sums) : 0;
+    if (n < 1 || n > MVHDP_MAX_MODALITIES * MVHDP_MAX_MODALITIES) { throw_msg(env, "java/lang/IllegalArgumentException", "groupViewOverlapSums: M*M entries"); return; }
+    double v[MVHDP_MAX_MODALITIES * MVHDP_MAX_MODALITIES] = {};
+    int rc = mvhdp_group_view_overlap_sums(gr->g, v);
+    if (rc) { throw_group(env, gr->g, rc, "mvhdp_group_view_overlap_sums"); return; }
+    env->SetDoubleArrayRegion(sums, 0, n, v);
+}
+
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupGammaDocStatistics(JNIEnv* env, jclass, jlong p, jint m, jdouble gammaM, jlong seed, jint round, jdoubleArray out)
+{
+    GroupPin gpin_(p); Group* gr = gpin_.s;
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    if (bad_len(env, out, 2, "groupGammaDocStatistics")) return;
+    double v[2];
+    int rc = mvhdp_group_gamma_doc_statistics(gr->g, m, gammaM, static_cast<uint64_t>(seed), static_cast<uint32_t>(round), &v[0], &v[1]);
+    if (rc) { throw_group(env, gr->g, rc, "mvhdp_group_gamma_doc_statistics"); return; }
+    env->SetDoubleArrayRegion(out, 0, 2, v);
 }
 
 }  // extern "C"

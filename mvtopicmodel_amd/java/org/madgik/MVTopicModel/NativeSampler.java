@@ -68,6 +68,12 @@ public final class NativeSampler implements AutoCloseable {
     /** Multi-GPU: after the all-reduce of the delta buffer; (topic, modality) = winner of the MIN-reduced activation key. */
     public void applyDelta(int activatedTopic, int activatedModality) { nApplyDelta(handle, activatedTopic, activatedModality); }
     public double[] modelLogLikelihood(int numModalities) { double[] ll = new double[numModalities]; nModelLogLikelihood(handle, ll); return ll; }
+    /** countHistogram of optimizeBeta (lines 2295-2309): hist[c] = (type, topic) pairs of view m holding count c. */
+    public void getCountHistogram(int m, int[] hist) { nGetCountHistogram(handle, m, hist); }
+    /** optimizeP (lines 2706-2792): sums[m*M+i] = sum over the entities, in entity order, of pDistr_Mean[m][i][doc]. */
+    public double[] viewOverlapSums(int numModalities) { double[] s = new double[numModalities * numModalities]; nViewOverlapSums(handle, s); return s; }
+    /** optimizeGamma's document level (lines 2415-2433): {qs, qw}, every entity drawing from its own counter-based stream. */
+    public double[] gammaDocStatistics(int m, double gammaM, long seed, int round) { double[] o = new double[2]; nGammaDocStatistics(handle, m, gammaM, seed, round, o); return o; }
 
     /**
      * n sweeps (indices firstIdx .. firstIdx+n-1) enqueued back to back, one synchronisation at the end: the iteration loop
@@ -162,6 +168,18 @@ public final class NativeSampler implements AutoCloseable {
             return out;
         }
 
+        /** This rank cannot go on: its next sweep contributes nothing and fails on EVERY rank together (nobody waits in a collective). */
+        public void abort() { nGroupAbort(g); }
+
+        // The steps either side of the sweep for the sharded model (what estimate() does every optimizeInterval and every tenth
+        // iteration, lines 1173-1210 and 1296-1320): statistics of the replicated counts are any member's, statistics over the
+        // entities are put together from the members in entity order.  setHyper: call NativeSampler.setHyper on every member.
+        public double[] modelLogLikelihood(int numModalities) { double[] ll = new double[numModalities]; nGroupModelLogLikelihood(g, ll); return ll; }
+        public void getDocTopicHist(int m, int[] histFlat, int histLen, int[] docLengthCounts) { nGroupGetDocTopicHist(g, m, histFlat, histLen, docLengthCounts); }
+        public void getCountHistogram(int m, int[] hist) { nGroupGetCountHistogram(g, m, hist); }
+        public double[] viewOverlapSums(int numModalities) { double[] s = new double[numModalities * numModalities]; nGroupViewOverlapSums(g, s); return s; }
+        public double[] gammaDocStatistics(int m, double gammaM, long seed, int round) { double[] o = new double[2]; nGroupGammaDocStatistics(g, m, gammaM, seed, round, o); return o; }
+
         @Override
         public void close() { if (g != 0) { nGroupDestroy(g); g = 0; } }
     }
@@ -200,4 +218,13 @@ public final class NativeSampler implements AutoCloseable {
     private static native void nGroupDestroy(long g);
     private static native void nGroupBuildCounts(long g);
     private static native double nGroupSweep(long g, int sweepIdx, long seed, int flags, long[] statsFlat, int[] act);
+    private static native void nGetCountHistogram(long h, int m, int[] hist);
+    private static native void nViewOverlapSums(long h, double[] sums);
+    private static native void nGammaDocStatistics(long h, int m, double gammaM, long seed, int round, double[] out);
+    private static native void nGroupAbort(long g);
+    private static native void nGroupModelLogLikelihood(long g, double[] out);
+    private static native void nGroupGetDocTopicHist(long g, int m, int[] histFlat, int histLen, int[] docLengthCounts);
+    private static native void nGroupGetCountHistogram(long g, int m, int[] hist);
+    private static native void nGroupViewOverlapSums(long g, double[] sums);
+    private static native void nGroupGammaDocStatistics(long g, int m, double gammaM, long seed, int round, double[] out);
 }

@@ -438,6 +438,43 @@ class NativeGroup:
     def build_counts(self):
         self._ck(self.L.mvhdp_group_build_counts(self.g))
 
+    def abort(self):
+        """This rank cannot go on: its next sweep contributes nothing and fails on every rank together."""
+        self._ck(self.L.mvhdp_group_abort(self.g))
+
+    # -- the steps either side of the sweep, for the sharded model (mvhdp_group_*: include/mvhdp.h) --
+    def set_hyper(self, hy):
+        for s in self.members:
+            s.set_hyper(hy)                     # (keeps the arrays alive per member; same effect as mvhdp_group_set_hyper)
+
+    def model_log_likelihood(self):
+        M = self.members[0].M
+        ll = np.zeros(M, dtype=np.float64)
+        self._ck(self.L.mvhdp_group_log_likelihood(self.g, _ptr(ll)))
+        return ll
+
+    def get_doc_topic_hist(self, m, hist_len, len_len=0):
+        hist = np.empty((self.members[0].K, hist_len), dtype=np.int32)
+        dl = np.empty(max(len_len, 1), dtype=np.int32) if len_len > 0 else None
+        self._ck(self.L.mvhdp_group_doc_topic_hist(self.g, m, _ptr(hist), hist_len, _ptr(dl), len_len))
+        return hist, (dl[:len_len] if dl is not None else None)
+
+    def get_count_histogram(self, m, length):
+        h = np.zeros(length, dtype=np.int32)
+        self._ck(self.L.mvhdp_group_count_histogram(self.g, m, _ptr(h), length))
+        return h
+
+    def view_overlap_sums(self):
+        M = self.members[0].M
+        s = np.zeros((M, M), dtype=np.float64)
+        self._ck(self.L.mvhdp_group_view_overlap_sums(self.g, _ptr(s)))
+        return s
+
+    def gamma_doc_statistics(self, m, gamma_m, seed, round_idx):
+        qs, qw = C.c_double(), C.c_double()
+        self._ck(self.L.mvhdp_group_gamma_doc_statistics(self.g, int(m), float(gamma_m), int(seed), int(round_idx), C.byref(qs), C.byref(qw)))
+        return qs.value, qw.value
+
     def sweep(self, sweep_idx, seed, flags=0):
         """One sweep of the whole model; the list of the local members' statistics."""
         n = len(self.members)

@@ -131,4 +131,10 @@ def test_m0_is_touched_by_the_lane_write_sequences_only(tmp_path):
                 assert i + 1 < len(ins) and re.fullmatch(r"v_writelane_b32 v\d+, s\d+, m0", ins[i + 1]), (l, ins[i + 1])
             else:
                 assert re.fullmatch(r"v_writelane_b32 v\d+, s\d+, m0", l) and re.fullmatch(r"s_mov_b32 m0, s\d+", ins[i - 1]), l
+        # the hand-written row-broadcast scan steps (wave_incl_scan_f_dpp) carry their own s_nop for the VGPR-write -> DPP-read hazard;
+        # the other DPP hazard -- a VALU write of EXEC needs five wait states before a DPP instruction -- is outside what the asm can
+        # see: no v_cmpx may sit within the five instructions in front of one
+        for i, l in enumerate(ins):
+            if l.startswith("v_add_f32_dpp") and "row_bcast" in l:
+                assert not any(x.startswith("v_cmpx") for x in ins[max(0, i - 6):i]), ins[max(0, i - 6):i + 1]
     assert seen > 0                                                          # (the sequences are there: the test looks at the right code)

@@ -192,3 +192,135 @@ def test_group_create_errors():
     with pytest.raises(MvhdpError):
         NativeGroup([])
     a.close(); b.close()
+
+
+def _shards_at(c, hy, z, bounds):
+    out = []
+    for lo, hi in bounds:
+        sub = c.slice_docs(lo, hi)
+        zs = [z[m][c.doc_off[m][lo]:c.doc_off[m][hi]] for m in range(c.M)]
+        out.append(make_native(sub, hy, zs, doc_id_base=lo))
+    return out
+
+
+def test_statistics_of_a_sharded_model_equal_the_single_handle():
+    """The steps either side of the sweep (PTM:1173-1210, PTM:1296-1320) for a sharded model: three members on one device against ONE
+    handle holding every entity, through a schedule of sweeps, statistics and a change of hyper-parameters (what an optimise step
+    does).  Integers exactly; the floating-point sums are the single handle's additions in the single handle's order (one process:
+    the running sums travel from member to member), so they are compared for equality too -- and the log-likelihood to 1e-12."""
+    K, V = 60, [700, 90, 70]
+    c = small_corpus(K, V, 180, [40, 5, 6], 96)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(3)]
+    one = make_native(c, hy, z)
+    shards = _shards(c, hy, z, 3)
+    maxlen = [int(np.diff(c.doc_off[m]).max()) + 1 for m in range(3)]
+    with NativeGroup(shards) as g:
+        g.build_counts()
+
+        def compare():
+            ll1, llg = one.model_log_likelihood(), g.model_log_likelihood()
+            assert np.allclose(ll1, llg, rtol=1e-12, atol=0) and np.array_equal(ll1, llg), (ll1, llg)
+            assert np.array_equal(one.view_overlap_sums(), g.view_overlap_sums())
+            for m in range(3):
+                h1, d1 = one.get_doc_topic_hist(m, maxlen[m], maxlen[m])
+                hg, dg = g.get_doc_topic_hist(m, maxlen[m], maxlen[m])
+                assert np.array_equal(h1, hg) and np.array_equal(d1, dg)
+                assert np.array_equal(one.get_count_histogram(m, 300), g.get_count_histogram(m, 300))
+                for rnd in (0, 3):
+                    q1, w1 = one.gamma_doc_statistics(m, 1.3, 99, rnd)
+                    qg, wg = g.gamma_doc_statistics(m, 1.3, 99, rnd)
+                    assert q1 == qg and abs(w1 - wg) <= 1e-12 * abs(w1)
+
+        compare()
+        for it in range(6):
+            one.sweep(it, 21)
+            g.sweep(it, 21)
+            if it in (1, 4):
+                compare()
+            if it == 2:                                                     # an optimise step: new hyper-parameters on every replica
+                hy2 = Hyper.defaults(K, V)
+                hy2.alpha[:, :K] *= 1.7; hy2.alpha_sum[:] = hy2.alpha[:, :K].sum(axis=1)
+                hy2.beta[:] = [0.02, 0.015, 0.011]; hy2.beta_sum[:] = hy2.beta * np.array(V); hy2.gamma[:] = [1.2, 0.8, 1.1]
+                one.set_hyper(hy2); g.set_hyper(hy2)
+        for m in range(3):
+            assert np.array_equal(np.concatenate([s.get_assignments(m) for s in shards]), one.get_assignments(m))
+    one.close()
+    for s in shards:
+        s.close()
+
+
+def test_a_failing_member_fails_the_sweep_for_everybody_and_a_recount_recovers():
+    """mvhdp_group_sweep's failure protocol: a member whose sweep cannot start (here: its assignments were replaced behind the counts'
+    back) makes the call fail -- after every sweep that WAS begun has been finished and every collective entered -- and
+    mvhdp_group_build_counts makes the model consistent again; mvhdp_group_abort does the same on request; a group whose member was
+    destroyed says so instead of touching freed memory."""
+    K, V = 40, [500, 60]
+    c = small_corpus(K, V, 160, [50, 6], 97)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(2)]
+    shards = _shards(c, hy, z, 3)
+    with NativeGroup(shards) as g:
+        g.build_counts()
+        o.sweep(0, 4); g.sweep(0, 4)
+        _assert_group_equals_oracle(o, shards, c)
+        shards[1].set_assignments(0, shards[1].get_assignments(0))          # member 1: counts stale -> its sweep is refused
+        with pytest.raises(MvhdpError) as ei:
+            g.sweep(1, 4)
+        assert "member 1" in str(ei.value)
+        with pytest.raises(MvhdpError):
+            g.sweep(1, 4)                                                   # still refused: every member now needs the recount
+        g.build_counts()                                                    # recount from z on every member + sum
+        for m in range(2):
+            o.set_assignments(m, np.concatenate([s.get_assignments(m) for s in shards]))
+        o.build_counts()
+        _assert_group_equals_oracle(o, shards, c)
+        o.sweep(2, 4); g.sweep(2, 4)
+        _assert_group_equals_oracle(o, shards, c)
+        g.abort()
+        with pytest.raises(MvhdpError) as ei:
+            g.sweep(3, 4)
+        assert "abort" in str(ei.value)
+        g.build_counts()
+        o.sweep(4, 4); g.sweep(4, 4)
+        _assert_group_equals_oracle(o, shards, c)
+        shards[2].close()                                                   # (the header asks for the other order)
+        with pytest.raises(MvhdpError) as ei:
+            g.sweep(5, 4)
+        assert ei.value.code == -2
+    for s in shards[:2]:
+        s.close()
+
+
+def test_segmented_group_sweep_with_a_member_shorter_than_the_segment_count():
+    """Every rank must walk through the same number of exchanges: the segment count comes from the flags, a member with fewer entities
+    than segments has empty segments (it used to clip the count -- and would have issued fewer collectives than its peers)."""
+    from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY
+    from mvtopicmodel_amd.native import SWEEP_SEGMENT_APPLY
+    K, V = 30, [400, 50]
+    c = small_corpus(K, V, 90, [30, 5], 98)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(2)]
+    bounds = [(0, 60), (60, 62), (62, 90)]                                  # the middle member holds two entities
+    nseg = 5
+    tot = sum(np.diff(c.doc_off[m]) for m in range(c.M))
+    shards = _shards_at(c, hy, z, bounds)
+    seg_docs = [[] for _ in range(nseg)]
+    for lo, hi in bounds:
+        order = lo + np.argsort(-tot[lo:hi], kind="stable")
+        for sidx in range(nseg):
+            seg_docs[sidx].append(order[sidx::nseg])
+    with NativeGroup(shards) as g:
+        g.build_counts()
+        for it in range(2):
+            for sidx in range(nseg):
+                r = o.sweep_list(it, 17, np.sort(np.concatenate(seg_docs[sidx])), flags=ORC_NO_APPLY, want_delta=True)
+                o.apply_delta(r["delta_nwk"], r["delta_nk"], -1, -1)
+            sts = g.sweep(it, 17, flags=SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(nseg))
+            assert sum(st.tokens for st in sts) == c.total_tokens
+            _assert_group_equals_oracle(o, shards, c)
+    for sh in shards:
+        sh.close()

@@ -96,7 +96,7 @@ def test_single_view_is_plain_lda_path():
     model.close()
 
 
-def _run_schedule(K, V, D, lam, cseed, seed, iters, burnin, interval, alpha=0.1):
+def _run_schedule(K, V, D, lam, cseed, seed, iters, burnin, interval, alpha=0.1, shards=1):
     """estimate() of the host mirror against the same schedule replayed on the oracle (C sweep + the Python restatement
     of the two randomised steps under the same injected streams).  Returns (model, oracle, hyper state) after `iters`."""
     import math
@@ -109,6 +109,7 @@ def _run_schedule(K, V, D, lam, cseed, seed, iters, burnin, interval, alpha=0.1)
     training = [(np.arange(c.D, dtype=np.int64), c.doc_off[m], c.tokens[m], V[m]) for m in range(M)]
     model = FastQMVWVParallelTopicModel(K, M, alpha, 0.01)
     model.setNumIterations(iters); model.setBurninPeriod(burnin); model.setOptimizeInterval(interval); model.setRandomSeed(seed)
+    model.setNumShards(shards)
     model.addInstances(training)
 
     o = Oracle(K, V)
@@ -202,6 +203,35 @@ def test_estimate_with_optimize_steps_matches_oracle_schedule():
     sums = o.optimize_p_sums()
     assert pm[0, 1] == sums[0, 1] / min(present[0], present[1])
     # LL/token recorded at iteration 10 (PTM:1302-1303)
+    tok = [int(c.doc_off[m][-1]) for m in range(3)]
+    for m in range(3):
+        per = model.perplexities(m)
+        assert len(per) == 2 and abs(per[1] - state["ll"][m] / tok[m]) < 1e-9 * abs(per[1])
+    model.close()
+
+
+def test_estimate_over_document_shards_is_the_single_handle_chain():
+    """estimate() with the model kept as three document shards behind an mvhdp_group (setNumShards): burn-in, the four optimise steps
+    every second iteration, the log-likelihood every tenth -- every step routed to its mvhdp_group_* counterpart -- replayed on the
+    oracle exactly like the single-handle schedule: the same integers, the same hyper-parameters bit for bit, the same LL/token."""
+    K, V = 30, [400, 50, 40]
+    model, o, c, hy, inactive, dp, statics, samp, rnd, optimize_round, state, max_type_count, present, hist_len = \
+        _run_schedule(K, V, 150, [40, 6, 5], 321, 5, 10, 2, 2, shards=3)
+    assert state["n_opt"] == 4
+    alpha, asum, ina, tables = model.optimizeDP()
+    from oracle import dp_samplers as dps
+    hists = [o.get_doc_topic_hist(m, hist_len[m], hist_len[m]) for m in range(3)]
+    dp.alpha = [list(map(float, a)) for a in hy.alpha]; dp.gamma = list(map(float, hy.gamma))
+    dp.inactive = set(np.flatnonzero(inactive).tolist())
+    dps.optimize_dp(dp, [h[0] for h in hists], statics, rnd)
+    assert np.array_equal(alpha, np.array(dp.alpha)) and np.array_equal(asum, np.array(dp.alphaSum))
+    bb, bbs = model.optimizeBeta()
+    for m in range(3):
+        ob, obs = o.optimize_beta(m, max_type_count[m])
+        assert bb[m] == ob and bbs[m] == obs
+    pa, pm = model.optimizeP()
+    sums = o.optimize_p_sums()
+    assert pm[0, 1] == sums[0, 1] / min(present[0], present[1]) and pm[1, 2] == sums[1, 2] / min(present[1], present[2])
     tok = [int(c.doc_off[m][-1]) for m in range(3)]
     for m in range(3):
         per = model.perplexities(m)

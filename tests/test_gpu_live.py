@@ -204,3 +204,38 @@ def test_live_and_deferred_sweeps_reach_the_same_likelihood():
     assert a1 > a0 + 0.3 and b1 > b0 + 0.3
     assert b1 > a1 - 0.005 * abs(a1)
     assert abs(a1 - b1) < 0.06 * abs(a1)
+
+
+def test_live_sweep_over_unassigned_tokens_stays_off_the_16_bit_mirror():
+    """A first visit of an unassigned token (z = -1, PTM:63) only ADDS to its row: the row's total grows during the sweep, and a row
+    classified light when its tree was built could reach 65535 in a mirror cell (read as "see the 32-bit table") or carry into the
+    neighbouring cell of the packed word.  So while some token may be unassigned a live sweep stays on the 32-bit table whatever
+    mvhdp_tuning.live16 says: one type with more than 65535 tokens, all unassigned, every count still the count of z afterwards."""
+    from mvtopicmodel_amd import NativeSampler
+    K, V = 8, [40]
+    rng = np.random.default_rng(5)
+    D, L = 720, 100
+    tok = rng.integers(1, V[0], size=D * L).astype(np.int32)
+    tok[rng.random(D * L) < 0.95] = 0                                       # type 0: ~68 400 tokens, far beyond a mirror cell
+    assert np.count_nonzero(tok == 0) > 65535
+    off = (np.arange(D + 1) * L).astype(np.int64)
+    s = NativeSampler(K, V, device=0)
+    s.set_corpus(0, off, tok)                                               # z = -1 everywhere
+    s.set_hyper(Hyper.defaults(K, V))
+    s.build_counts()
+    s.set_tuning(live16=1)
+
+    class C1:                                                               # (the shape _check_counts_are_counts_of_z wants)
+        M, V, tokens = 1, [40], [tok]
+    for it in range(3):
+        st = s.sweep(it, 9, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2))
+        assert st.tokens == D * L
+        _check_counts_are_counts_of_z(C1, s, K)
+    # from the second sweep on nothing is unassigned: the mirror is in use again (type 0 as a heavy row), and a host that hands in
+    # assignments with a hole switches it off again
+    z = s.get_assignments(0)
+    z[7] = -1
+    s.set_assignments(0, z); s.build_counts()
+    st = s.sweep(5, 9, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2))
+    _check_counts_are_counts_of_z(C1, s, K)
+    s.close()

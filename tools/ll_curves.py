@@ -84,25 +84,38 @@ def run_gpu(args):
         modes.append((f"gpu deferred in {n} segments, applied in between", SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(n)))
     if args.only:
         modes = [mo for mo in modes if any(o in mo[0] for o in args.only)]
-    for name, flags in modes:
-        s = NativeSampler(c.K, c.V)
-        for m in range(c.M):
-            s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z0[m])
-        s.set_hyper(hy); s.build_counts()
-        if args.live16 is not None:
-            s.set_tuning(live16=args.live16)
-            name += " (live16=%d)" % args.live16
-        curve = [{"sweep": 0, "ll_per_token": (s.model_log_likelihood() / ntok).tolist()}]
-        ms = 0.0
-        for it in range(1, args.sweeps + 1):
-            st = s.sweep(it, args.seed, flags=flags)
-            ms += st.total_ms
-            if it % args.every == 0 or it == args.sweeps:
-                curve.append({"sweep": it, "ll_per_token": (s.model_log_likelihood() / ntok).tolist(),
-                              "changed_frac": st.changed / max(1, st.tokens), "ms_per_sweep": ms / it})
-        print(f"{name}: final LL/token {curve[-1]['ll_per_token']}  {ms / args.sweeps:.2f} ms/sweep", flush=True)
-        runs[name] = curve
-        s.close()
+    # every mode, for every pinned live16 setting and every seed asked for (several seeds of one mode = the noise band of a chain)
+    l16s = args.live16 if args.live16 else [None]
+    seeds = args.seeds if args.seeds else [args.seed]
+    for name0, flags in modes:
+      for l16 in l16s:
+        if l16 is not None and not (flags & SWEEP_LIVE):
+            if l16 != l16s[0]:
+                continue                       # (live16 only concerns live sweeps: one run of the others)
+        for seed in seeds:
+            s = NativeSampler(c.K, c.V)
+            for m in range(c.M):
+                s.set_corpus(m, c.doc_off[m], c.tokens[m]); s.set_assignments(m, z0[m])
+            s.set_hyper(hy); s.build_counts()
+            name = name0
+            if l16 is not None and (flags & SWEEP_LIVE):
+                s.set_tuning(live16=l16)
+                name += " (live16=%d)" % l16
+            if len(seeds) > 1:
+                name += " seed %d" % seed
+            if args.tag:
+                name += " [%s]" % args.tag
+            curve = [{"sweep": 0, "ll_per_token": (s.model_log_likelihood() / ntok).tolist()}]
+            ms = 0.0
+            for it in range(1, args.sweeps + 1):
+                st = s.sweep(it, seed, flags=flags)
+                ms += st.total_ms
+                if it % args.every == 0 or it == args.sweeps:
+                    curve.append({"sweep": it, "ll_per_token": (s.model_log_likelihood() / ntok).tolist(),
+                                  "changed_frac": st.changed / max(1, st.tokens), "ms_per_sweep": ms / it})
+            print(f"{name}: final LL/token {curve[-1]['ll_per_token']}  {ms / args.sweeps:.2f} ms/sweep", flush=True)
+            runs[name] = curve
+            s.close()
     json.dump({"runs": runs, "workload": args.workload, "docs": c.D, "tokens": c.total_tokens}, open(args.out, "w"), indent=1)
 
 
@@ -174,7 +187,9 @@ def main():
             p.add_argument("--live-segments", type=int, nargs="*", default=[1, 4, 16])
             p.add_argument("--segmented", type=int, nargs="*", default=[], help="also run SEGMENT_APPLY sweeps with these segment counts")
             p.add_argument("--only", nargs="*", default=[], help="keep only the modes whose name contains one of these strings")
-            p.add_argument("--live16", type=int, default=None, help="pin mvhdp_tuning.live16 (1: live sweeps keep the light n_wk rows in the 16-bit mirror)")
+            p.add_argument("--live16", type=int, nargs="*", default=[], help="pin mvhdp_tuning.live16 (1: live sweeps keep the light n_wk rows in the 16-bit mirror); several values = one run each")
+            p.add_argument("--seeds", type=int, nargs="*", default=[], help="one run per seed of every mode (the noise band of a chain)")
+            p.add_argument("--tag", default="", help="appended to the run names (which library build this was)")
     p = sub.add_parser("table")
     p.add_argument("files", nargs="+")
     args = ap.parse_args()
