@@ -27,20 +27,42 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def physical_bound_note():
-    """What the dominant kernel is bound by, from the committed SQ counters of the settled C4 kernel (profiles/pmc_r03_sq.sh)."""
-    note = ("the fixed-byte HBM yardstick of SURVEY 8d is nominal (it assumes 4-byte counts; the kernels gather 2-byte ones, so frac can "
-            "exceed 1): the sweep kernel is bound by instruction issue, not by memory")
+SIMDS = 256 * 4           # CUs x SIMDs per CU
+SIMD_CLOCK_GHZ = 2.4      # MI355X peak engine clock
+
+
+def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred"):
+    """The two ceilings that can actually bind the sweep kernels, as fractions below 1 (the fixed-byte yardstick of SURVEY 8d assumes
+    4-byte counts and a whole row per token; the kernels gather 2-byte cells, so that fraction passes 1):
+
+      physical  fabric bytes per token -- (TCC_EA0_RDREQ x 128 B + WRITE_SIZE), the PMC passes of profiles/profile_r04.sh over the very
+                window this command times -- x tokens per launch / the kernel time measured HERE, against the 8 TB/s HBM peak and
+                against what a bare gather of the same rows reaches on this chip (tools/microbench/gather_patterns.hip)
+      issue     cycles per token during which a SIMD's vector ALU (scalar unit) is busy -- SQ_ACTIVE_INST_VALU / _SCA x 4 of the SQ
+                pass of the same recipe -- x tokens per second here, against 1024 SIMDs x 2.4 GHz
+
+    Counters cannot be read inside an un-profiled run: the per-token figures are the committed profile's (same build, same command),
+    the rate is this run's.  Returns (physical, issue) dicts or (None, None) when the profile of this workload is not committed."""
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r03_c4_sq_counters_settled.json")))
-        per = lambda k: sq[k]["per_token"]
-        simd = per("SQ_WAVE_CYCLES") / 7.0                       # quad-cycles of a SIMD per token at 7 waves per SIMD
-        note += (f" -- settled 1-round kernel: {per('SQ_INSTS_VALU'):.0f} vector + {per('SQ_INSTS_SALU'):.0f} scalar instructions per token, "
-                 f"vector unit {100 * per('SQ_ACTIVE_INST_VALU') / simd:.0f} % and scalar unit {100 * per('SQ_ACTIVE_INST_SCA') / simd:.0f} % busy "
-                 f"({sum(sq['kernel_ms_last8']) / 8:.1f} ms per launch; profiles/r03_c4_sq_counters_settled.json)")
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r04_roofline_inputs.json")))
+        w = prof["workloads"][workload][mode]
     except Exception:
-        pass
-    return note
+        return None, None
+    tok_s = tokens_per_launch / avg_kernel_s
+    bpt = w["fabric_read_bytes_per_token"] + w["write_bytes_per_token"]
+    gbs = tok_s * bpt / 1e9
+    ceil = prof.get("gather_ceiling_GBs")
+    physical = {"bytes_per_token": bpt, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                "gather_ceiling": ceil, "frac_of_gather_ceiling": (gbs / ceil) if ceil else None,
+                "source": w.get("pmc_source"), "gather_ceiling_source": prof.get("gather_ceiling_source")}
+    issue = None
+    if "valu_busy_cycles_per_token" in w:
+        cap = SIMDS * SIMD_CLOCK_GHZ * 1e9
+        issue = {"valu_busy_cycles_per_token": w["valu_busy_cycles_per_token"], "scalar_busy_cycles_per_token": w["scalar_busy_cycles_per_token"],
+                 "valu_insts_per_token": w.get("valu_insts_per_token"), "scalar_insts_per_token": w.get("scalar_insts_per_token"),
+                 "simd_cycles_per_s": cap, "frac": tok_s * w["valu_busy_cycles_per_token"] / cap,
+                 "frac_scalar": tok_s * w["scalar_busy_cycles_per_token"] / cap, "source": w.get("sq_source")}
+    return physical, issue
 
 
 def algorithmic_bytes_per_token(K):
@@ -293,24 +315,17 @@ def main():
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     bpt = algorithmic_bytes_per_token(K)
     achieved = local_tokens * bpt / avg_kernel_s / 1e9
-    # HBM-side traffic of the same kernels from the committed PMC passes (profiles/profile_r03.sh: separate FETCH_SIZE /
-    # TCC_EA0_RDREQ / WRITE_SIZE runs of this very command, this build); bytes per token there x tokens per launch here.  Counters
-    # cannot be read inside an un-profiled run, so the per-token figure is the profiled window's, the rate is this run's.
-    traffic = None
+    # the ceilings that can bind (fractions below 1) and, from the same committed PMC passes, `traffic`: the fabric bytes per second
+    physical, issue = physical_rooflines(args.workload, local_tokens, avg_kernel_s, "live" if args.live else "deferred")
+    traffic = physical["achieved"] if physical else None
     traffic_note = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_c4_pmc_summary.json")))
-        if args.workload == "C4":
-            bpt_meas = pm["fetch_bytes_per_token"] + pm["write_bytes_per_token"]
-            traffic = local_tokens * bpt_meas / avg_kernel_s / 1e9
-            traffic_note = (f"{bpt_meas:.0f} B/token = TCC_EA0_RDREQ x 128 B (= 2 x FETCH_SIZE: the gfx950 correction, calibrated "
-                            "on this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits "
-                            "included; PMC passes of profiles/profile_r03.sh over the 20 timed sweeps of `--steps 20 --warmup 5` "
-                            "(a rocprofv3 run of its own, same build; the 1-round kernel on the 16-bit mirror of the counts takes the "
-                            "entities with short topic lists from sweep 2 on, so the per-token figure is BELOW the algorithmic 4K+8 "
-                            "bytes, which assume 4-byte counts), the rate is this run's")
-    except Exception:
-        pass
+    if physical:
+        traffic_note = (f"{physical['bytes_per_token']:.0f} B/token = TCC_EA0_RDREQ x 128 B (= 2 x FETCH_SIZE: the gfx950 correction, calibrated on "
+                        "this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits included; PMC passes of "
+                        "profiles/profile_r04.sh over the timed sweeps of this very command (a rocprofv3 run of its own, same build), the rate is this run's")
+    binding = None
+    if physical and issue and physical.get("frac_of_gather_ceiling"):
+        binding = "issue (vector ALU)" if issue["frac"] >= physical["frac_of_gather_ceiling"] else "gather ceiling of the fabric"
     out = {
         "metric": "gibbs_tokens_per_sec", "value": value, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -324,7 +339,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "sweep kernels of one mvhdp_sweep (dominant: sweep_fast_kernel<R>)", "bytes_per_token": bpt, "tokens_per_launch": local_tokens,
-                     "physical_bound_note": physical_bound_note(),
+                     "nominal_note": "achieved / frac are the fixed-byte yardstick of SURVEY 8d (4K+8 bytes per token whatever the kernel reads: "
+                                     "it assumes 4-byte counts, the kernels gather 2-byte cells, so frac can pass 1); `physical` and `issue` are the "
+                                     "ceilings that can bind, both below 1",
+                     "physical": physical, "issue": issue, "binds": binding,
                      "avg_kernel_ms": avg_kernel_s * 1e3},
         "sweep": {"changed_frac": last.changed / max(1, last.tokens),
                   "branch_frac": {"new": last.new_mass_cnt / max(1, last.tokens),

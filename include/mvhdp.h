@@ -267,7 +267,10 @@ typedef struct {
     int32_t walk_fixed;                          /* 1: walk_theta[] as given, no search */
     int32_t single_stream;                       /* 1: all class kernels on the handle's stream (diagnostics) */
     int32_t live16;                              /* MVHDP_SWEEP_LIVE keeps the light n_wk rows current in the 16-bit mirror (half-width gathers): -1 where K >= 256 (default), 0 never, 1 always */
-    int32_t reserved;
+    int32_t single_wave;                         /* diagnostics, 0 by default.  1: every sweep kernel runs as ONE wavefront (one block of 64 threads), the class kernels one
+                                                    after another, and a live sweep waits for its chunk-end atomics and drops its L1 before it goes on: a live sweep then IS
+                                                    the sequential algorithm (every token sees every earlier update of the same segment), so the 32-bit form and the 16-bit
+                                                    mirror form must give the same integers (tests/test_gpu_live.py) */
     double  walk_theta[MVHDP_MAX_MODALITIES];    /* with walk_fixed: walk a token's word tree up front iff u1 >= walk_theta[view] */
     double  primary_min_share;                   /* narrowest kernel class holding this share of the tokens gets its own kernel (0 = default 0.10) */
     int32_t learnt_walk_step[4];                 /* searched threshold in 1/20 steps per kernel flavour: [0] 1-round variant on the 16-bit mirror, [1] 1-round

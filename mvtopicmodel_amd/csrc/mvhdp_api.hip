@@ -720,7 +720,8 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
 
     SweepLaunch sl{};
     sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
-    sl.flags = flags & 0xffffu; sl.S_cap = p.S_cap;
+    sl.flags = flags & 0x7fffu; sl.S_cap = p.S_cap;
+    if (h->tu.single_wave && p.live) sl.flags |= MVHDP_SL_STRICT_LIVE;
     sl.q_order_stride = 1;
     sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
     sl.live16 = p.live16 ? 1 : 0;
@@ -1178,6 +1179,7 @@ extern "C" int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t)
     memset(t, 0, sizeof *t);
     t->force_primary = h->tu.force_primary; t->narrow = h->tu.narrow; t->walk_fixed = h->tu.walk_fixed;
     t->single_stream = h->tu.single_stream; t->primary_min_share = h->tu.primary_min_share; t->live16 = h->tu.live16;
+    t->single_wave = h->tu.single_wave;
     for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) { t->walk_theta[m] = h->tu.walk_theta[m]; t->tree_branch_share[m] = h->wt.walk_f[m]; }
     for (int g = 0; g < WALK_GROUPS; g++) t->learnt_walk_step[g] = g == h->wt.walk_cls ? h->wt.walk_i : h->wt.walk_i_by[g];
     t->learnt_walk_step[3] = -1;
@@ -1195,6 +1197,7 @@ extern "C" int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t)
     h->tu.force_primary = fp; h->tu.narrow = t->narrow; h->tu.walk_fixed = t->walk_fixed ? 1 : 0;
     h->tu.single_stream = t->single_stream ? 1 : 0;
     h->tu.live16 = t->live16 < 0 ? -1 : (t->live16 ? 1 : 0);
+    h->tu.single_wave = t->single_wave ? 1 : 0;
     h->tu.primary_min_share = t->primary_min_share > 0.0 ? t->primary_min_share : 0.10;
     for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) h->tu.walk_theta[m] = t->walk_theta[m];
     if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) h->wt.restore(t->learnt_walk_step, t->tree_branch_share, h->mm.M);
@@ -1221,7 +1224,7 @@ extern "C" int mvhdp_plan_probe(const mvhdp_plan_input* pi, const mvhdp_tuning* 
     wt.init_defaults(in.K);
     if (t) {
         tu.force_primary = t->force_primary; tu.narrow = t->narrow; tu.walk_fixed = t->walk_fixed; tu.single_stream = t->single_stream;
-        tu.live16 = t->live16;
+        tu.live16 = t->live16; tu.single_wave = t->single_wave ? 1 : 0;
         if (t->primary_min_share > 0) tu.primary_min_share = t->primary_min_share;
         for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) tu.walk_theta[m] = t->walk_theta[m];
         if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) wt.restore(t->learnt_walk_step, t->tree_branch_share, in.M);

@@ -55,10 +55,13 @@ struct MvModel {
     int32_t first_inactive;            // inActiveTopicIndex.first() or -1
 };
 
+// SweepLaunch::flags, internal: a live sweep waits for its chunk-end atomics and invalidates the CU's L1 before it goes on (with one
+// resident wave the sweep is then the sequential algorithm: mvhdp_tuning.single_wave)
+#define MVHDP_SL_STRICT_LIVE 0x8000u
 struct SweepLaunch {
     uint32_t sweep_idx;
     uint32_t seed_lo, seed_hi;
-    uint32_t flags;                    // MVHDP_SWEEP_EXACT_CHAIN
+    uint32_t flags;                    // MVHDP_SWEEP_* (low 15 bits) | MVHDP_SL_STRICT_LIVE
     int32_t  S_cap;                    // dense-slot capacity per wave (multiple of 64)
     int32_t  waves_per_block;
     uint32_t block_shared_bytes;       // n_k delta table (unless nk_global) + the topic-list histogram

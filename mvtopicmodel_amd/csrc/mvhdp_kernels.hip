@@ -696,6 +696,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(MvModel mm, SweepLaunch sl)
                     }
                 }
                 if (tvalid) mm.z[m][base + ti] = znew_l;                     // coalesced write-back of the chunk
+                if (sl.flags & MVHDP_SL_STRICT_LIVE) {                       // (diagnostics: mvhdp_tuning.single_wave)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
                 if (tvalid && znew_l >= 0) atomicOr(&bitmap2[znew_l >> 5], 1u << (znew_l & 31));
             }
         }

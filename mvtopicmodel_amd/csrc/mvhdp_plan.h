@@ -127,6 +127,7 @@ struct PlanTuning {
     int narrow_wide = 1;                        // 1: deferred sweeps gather from the mirror in the wider variants too (0: the 1-round variant only)
     int fork_delay_us = 0;                      // microseconds the handle's stream is held between the fork event and the primary kernel (0: none)
     int widest_on_main = 0;                     // 1: the widest class on the handle's stream, the primary on a side stream (diagnostics)
+    int single_wave = 0;                        // diagnostics: every sweep kernel as one wavefront, class kernels one after another, live sweeps strictly ordered
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
 };
 
@@ -376,6 +377,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
         const int bpc = plan_blocks_per_cu(regs, 64 * g.wpb, g.lds);
         const int64_t need = (in.D + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
         g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)in.num_cus * bpc));
+        if (tu.single_wave) { g.wpb = 1; g.lds = p.block_shared_bytes + g.wave_bytes; g.grid = 1; }
         return true;
     };
 
@@ -427,11 +429,11 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
             if (c < 5 && geometry(true, c, w, g)) { g.walk = w; }
             else { g = gen; g.walk = 0; }                               // no room for that variant's slot state (or class 5): the generic kernel
             g.used = true;
-            g.stream = (c == pc || tu.single_stream) ? PLAN_STREAM_MAIN : stream_of[c];
+            g.stream = (c == pc || tu.single_stream || tu.single_wave) ? PLAN_STREAM_MAIN : stream_of[c];
             for (int m = 0; m < MVHDP_MAXM; m++) g.theta[m] = theta[group_of(c)][m];
             p.cls[c] = g;
         }
-        if (!tu.single_stream && tu.widest_on_main) {
+        if (!tu.single_stream && !tu.single_wave && tu.widest_on_main) {
             // widest first: the handle's stream, then side streams A, B, C in turn (the last one shared by whatever is left)
             int next = PLAN_STREAM_MAIN;
             for (int c = MVHDP_N_CLASSES - 1; c >= pc; c--) if (p.cls[c].used) { p.cls[c].stream = next; next = std::min(next + 1, (int)PLAN_STREAM_C); }

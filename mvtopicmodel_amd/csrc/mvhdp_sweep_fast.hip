@@ -522,6 +522,10 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 }
                 if (tvalid) mm.z[m][base + ti] = znew_l;                     // coalesced write-back of the chunk
                 if (tvalid && znew_l >= 0) atomicOr(&bitmap2[znew_l >> 5], 1u << (znew_l & 31));
+                if (sl.flags & MVHDP_SL_STRICT_LIVE) {                       // (diagnostics: the chunk's updates have landed before anything else is read)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
                 MVHDP_TSEG(te);
             }
 

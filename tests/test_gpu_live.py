@@ -239,3 +239,61 @@ def test_live_sweep_over_unassigned_tokens_stays_off_the_16_bit_mirror():
     st = s.sweep(5, 9, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2))
     _check_counts_are_counts_of_z(C1, s, K)
     s.close()
+
+
+@pytest.mark.parametrize("K,V,D,lam,cseed", [(40, [500, 60, 50], 150, [40, 5, 6], 41), (200, [3000, 300], 120, [160, 9], 42)])
+def test_one_wave_live_sweep_is_sequential_so_the_mirror_form_equals_the_32_bit_form(K, V, D, lam, cseed):
+    """The deterministic pin of the live sweep's two forms.  With ONE resident wavefront, ONE segment and every chunk's atomics waited
+    for (mvhdp_tuning.single_wave) a live sweep is the sequential algorithm: every token sees every earlier update.  The form that
+    keeps the light rows in the 16-bit mirror (packed +-1 / +-65536 atomics, 2-byte gathers, trees from the mirror, widen at the end)
+    and the form on the 32-bit table must then give the same assignments and the same counts, integer for integer."""
+    c = small_corpus(K, V, D, lam, cseed)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(c.M)]
+    a, b = make_native(c, hy, z), make_native(c, hy, z)
+    a.set_tuning(live16=0, single_wave=1)
+    b.set_tuning(live16=1, single_wave=1)
+    for it in range(4):
+        sa = a.sweep(it, 13, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1))
+        sb = b.sweep(it, 13, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1))
+        assert sa.tokens == sb.tokens == c.total_tokens and sa.changed == sb.changed
+        assert (sa.new_mass_cnt, sa.topic_doc_mass_cnt, sa.word_ftree_mass_cnt) == (sb.new_mass_cnt, sb.topic_doc_mass_cnt, sb.word_ftree_mass_cnt)
+        for m in range(c.M):
+            assert np.array_equal(a.get_assignments(m), b.get_assignments(m)), f"sweep {it}: assignments differ in view {m}"
+            (wa, ka), (wb, kb) = a.get_counts(m), b.get_counts(m)
+            assert np.array_equal(wa, wb) and np.array_equal(ka, kb)
+        _check_counts_are_counts_of_z(c, b, K)
+    # ... and it is not the deferred sweep (the updates ARE seen): a third handle, deferred, same stream, different assignments
+    d = make_native(c, hy, z)
+    d.sweep(0, 13)
+    assert any(not np.array_equal(d.get_assignments(m), z[m]) for m in range(c.M))
+    a.close(); b.close(); d.close()
+
+
+def test_one_wave_live_sweep_with_a_heavy_row():
+    """The same pin where one type holds more than 65534 tokens (a heavy row: its counts stay on the 32-bit table in both forms)."""
+    from mvtopicmodel_amd import NativeSampler
+    K, V = 8, [40]
+    rng = np.random.default_rng(6)
+    D, L = 700, 100
+    tok = rng.integers(1, V[0], size=D * L).astype(np.int32)
+    tok[rng.random(D * L) < 0.95] = 0
+    assert np.count_nonzero(tok == 0) > 65535
+    off = (np.arange(D + 1) * L).astype(np.int64)
+    z0 = rng.integers(0, K, size=D * L).astype(np.int32)
+    hs = []
+    for l16 in (0, 1):
+        s = NativeSampler(K, V, device=0)
+        s.set_corpus(0, off, tok); s.set_assignments(0, z0)
+        s.set_hyper(Hyper.defaults(K, V)); s.build_counts()
+        s.set_tuning(live16=l16, single_wave=1)
+        hs.append(s)
+    for it in range(2):
+        for s in hs:
+            s.sweep(it, 17, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1))
+        assert np.array_equal(hs[0].get_assignments(0), hs[1].get_assignments(0))
+        (wa, ka), (wb, kb) = hs[0].get_counts(0), hs[1].get_counts(0)
+        assert np.array_equal(wa, wb) and np.array_equal(ka, kb)
+    for s in hs:
+        s.close()

@@ -10,8 +10,10 @@
 // interval I = T / (writes per second), so a read that sees the memory's current content has mean age I (memoryless); a read served
 // from a cache has the age of the cached copy on top.  Reported: mean age / I per flavour (1 = fresh) and the share of reads older
 // than 8 I.
-//   flavours: plain | sc1 (agent scope: bypasses the CU's L1) | sc0 sc1 (system scope) | nt
-//   hipcc --offload-arch=gfx950 -O3 -o live_staleness live_staleness.hip && ./live_staleness
+//   read flavours:  plain | sc1 (agent scope: bypasses the CU's L1) | sc0 sc1 (system scope) | nt
+//   write flavours: atomic (global_atomic_umax_x2, executed at the memory side) | sc1 store (write-through) | plain store (stays dirty in
+//                   the writer's L2 until it is written back: the case that is NOT coherent across XCDs)
+//   hipcc --offload-arch=gfx950 -O3 -o live_staleness live_staleness.hip && ./live_staleness [blocks iters reads_per_write write_flavour]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +34,15 @@ __device__ __forceinline__ unsigned long long load_cell(const unsigned long long
 }
 
 // one lane per (wave, lane) stream: the 64 lanes of a wave read 64 different random lines per step (as a gather does)
-template <int FLAVOUR>
+template <int WRITE>
+__device__ __forceinline__ void store_cell(unsigned long long* p, unsigned long long v)
+{
+    if (WRITE == 0) __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (WRITE == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // global_store_dwordx2 ... sc1
+    else *(volatile unsigned long long*)p = v;
+}
+
+template <int FLAVOUR, int WRITE>
 __global__ __launch_bounds__(256) void staleness_kernel(unsigned long long* table, unsigned int lines, int iters, int reads_per_write,
                                                         unsigned long long threshold, unsigned long long* out /*[4]: sum age, reads, old reads, writes*/)
 {
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(256) void staleness_kernel(unsigned long long* tabl
         }
         rs = rs * 1664525u + 1013904223u;
         const unsigned int line = (unsigned int)(((unsigned long long)(rs >> 4) * lines) >> 28);
-        __hip_atomic_fetch_max(table + (size_t)line * 16, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        store_cell<WRITE>(table + (size_t)line * 16, (unsigned long long)__builtin_amdgcn_s_memrealtime());
         w++;
     }
     // wave totals -> four atomics per wave
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void staleness_kernel(unsigned long long* tabl
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], sum); atomicAdd(&out[1], n); atomicAdd(&out[2], old); atomicAdd(&out[3], w); }
 }
 
-template <int FLAVOUR>
+template <int FLAVOUR, int WRITE>
 static void run(const char* name, unsigned long long* table, unsigned int lines, int blocks, int iters, int rpw, double interval_guess_ticks)
 {
     unsigned long long* out; CK(hipMalloc(&out, 32));
@@ -67,7 +77,7 @@ static void run(const char* name, unsigned long long* table, unsigned int lines,
     for (int pass = 0; pass < 2; pass++) {
         CK(hipMemset(out, 0, 32));
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((staleness_kernel<FLAVOUR>), dim3(blocks), dim3(256), 0, 0, table, lines, iters, rpw, (unsigned long long)(8 * interval), out);
+        hipLaunchKernelGGL((staleness_kernel<FLAVOUR, WRITE>), dim3(blocks), dim3(256), 0, 0, table, lines, iters, rpw, (unsigned long long)(8 * interval), out);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         unsigned long long h[4]; CK(hipMemcpy(h, out, 32, hipMemcpyDeviceToHost));
@@ -85,14 +95,16 @@ int main(int argc, char** argv)
     const int blocks = argc > 1 ? atoi(argv[1]) : 256 * 7;          // 7 waves per SIMD, like the 1-round sweep kernel
     const int iters = argc > 2 ? atoi(argv[2]) : 400;
     const int rpw = argc > 3 ? atoi(argv[3]) : 8;
+    const int wf = argc > 4 ? atoi(argv[4]) : 0;
+    printf("writes: %s\n", wf == 0 ? "agent-scope atomic max (memory side)" : wf == 1 ? "sc1 (write-through) stores" : "plain stores");
     const unsigned int sizes[] = {8192u, 65536u, 114688u /* 14 MB: C3's mirror */, 393216u /* 48 MB: C4's mirror */, 786432u /* 96 MB: C4's counts */};
     for (unsigned int lines : sizes) {
         unsigned long long* table; CK(hipMalloc(&table, (size_t)lines * 128));
         CK(hipMemset(table, 0, (size_t)lines * 128));
-        run<0>("plain", table, lines, blocks, iters, rpw, 100.0);
-        run<1>("sc1", table, lines, blocks, iters, rpw, 100.0);
-        run<2>("sc0sc1", table, lines, blocks, iters, rpw, 100.0);
-        run<3>("nt", table, lines, blocks, iters, rpw, 100.0);
+        if (wf == 0) { run<0, 0>("plain", table, lines, blocks, iters, rpw, 100.0); run<1, 0>("sc1", table, lines, blocks, iters, rpw, 100.0);
+                       run<2, 0>("sc0sc1", table, lines, blocks, iters, rpw, 100.0); run<3, 0>("nt", table, lines, blocks, iters, rpw, 100.0); }
+        else if (wf == 1) { run<0, 1>("plain", table, lines, blocks, iters, rpw, 100.0); run<1, 1>("sc1", table, lines, blocks, iters, rpw, 100.0); }
+        else { run<0, 2>("plain", table, lines, blocks, iters, rpw, 100.0); run<1, 2>("sc1", table, lines, blocks, iters, rpw, 100.0); }
         CK(hipFree(table));
         printf("\n");
     }
