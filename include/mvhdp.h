@@ -148,6 +148,15 @@ typedef struct {
  * entities ordered by decreasing token count (ties by entity index). */
 #define MVHDP_SWEEP_SEGMENT_APPLY 0x40u
 
+/* With MVHDP_SWEEP_SEGMENT_APPLY: the updater runs BESIDE the samplers, as UPD:164-297 runs beside WRK:186-233 -- the deltas of
+ * segment s are applied (and the F+trees rebuilt) while segment s+1 is being sampled, so segment s+2 is the first to see them:
+ * every token of segment s samples against the counts after segment s-2 (segments 0 and 1: the sweep-start counts).  Still a
+ * deterministic chain, followed by the oracle segment by segment (tests/test_gpu_segmented.py); one segment staler than plain
+ * SEGMENT_APPLY at the same segment count, and without its per-segment stall: no kernel boundary ever idles the chip, because two
+ * segments are in flight (the model is kept twice: +1 copy of counts, mirror and descent tables).  Not with inactive topics (the
+ * activation of UPD:263-270 needs the host between segments): MVHDP_ERR_UNSUPPORTED. */
+#define MVHDP_SWEEP_SEGMENT_OVERLAP 0x80u
+
 /* Only segment s (0-based) of the MVHDP_SWEEP_LIVE_SEGMENTS(n) interleaved segments is swept: the entities at positions s, s+n,
  * s+2n, ... of the longest-first order; the statistics cover those entities.  With it a HOST drives a segmented sweep and can put
  * anything between two segments -- an all-reduce over document shards, a look at the counts (tests/test_gpu_full_size.py checks
@@ -276,6 +285,10 @@ typedef struct {
     int32_t learnt_walk_step[4];                 /* searched threshold in 1/20 steps per kernel flavour: [0] 1-round variant on the 16-bit mirror, [1] 1-round
                                                     variant on 32-bit rows, [2] the wider variants; -1: none yet (the library's default); [3] reserved */
     double  tree_branch_share[MVHDP_MAX_MODALITIES]; /* tree-branch (WRK:533) share of each view's tokens in the last measured sweep; < 0: not measured */
+    int32_t live_overlap;                        /* MVHDP_SWEEP_LIVE with several segments: -1 (default) / 1: the next segment's trees are rebuilt (from the live counts)
+                                                    and its kernels launched when the current segment is nearly through, so that no segment border idles the chip;
+                                                    0: one segment after the other (the round-3 form) */
+    int32_t reserved2;
 } mvhdp_tuning;
 int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t);
 int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t);

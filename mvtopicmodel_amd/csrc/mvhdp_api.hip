@@ -49,6 +49,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_NARROW")) h->tu.narrow = atoi(f) != 0 ? -1 : 0;
     if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
+    if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_FORK_DELAY_US")) h->tu.fork_delay_us = std::max(0, std::min(1000, atoi(f)));
@@ -176,6 +177,11 @@ static void release_device_resources(mvhdp_ctx* h)
     if (h->h_ctl) { hipHostFree(h->h_ctl); h->h_ctl = nullptr; }
     h->d_stats = nullptr; h->d_act_key = nullptr; h->d_doc_counter = nullptr; h->d_ovf_meta = nullptr;
     fr(h->d_doc_order); fr(h->d_lists); fr(h->d_nslots); fr(h->d_stats_many);
+    fr(h->ov.counts2); fr(h->ov.counts16_2); fr(h->ov.dtab2); fr(h->ov.root2); fr(h->ov.trees2); fr(h->ov.delta2); fr(h->ov.delta3); fr(h->ov.ctl2); fr(h->ov.lists2);
+    for (auto& e : h->ov.ev_seg) if (e) { hipEventDestroy(e); e = nullptr; }
+    if (h->ov.ev_start) { hipEventDestroy(h->ov.ev_start); h->ov.ev_start = nullptr; }
+    if (h->ov.x1) { hipStreamDestroy(h->ov.x1); h->ov.x1 = nullptr; }
+    if (h->ov.xa) { hipStreamDestroy(h->ov.xa); h->ov.xa = nullptr; }
     for (auto& e : h->ev_many) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& e : h->ev) if (e) { hipEventDestroy(e); e = nullptr; }
     if (h->ev_fork) { hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
@@ -259,6 +265,7 @@ extern "C" int mvhdp_set_corpus(mvhdp_handle h, int32_t m, int64_t D, const int6
     h->max_doc_tokens = -1;
     if (h->d_doc_order) { hipFree(h->d_doc_order); h->d_doc_order = nullptr; }
     if (h->d_lists) { hipFree(h->d_lists); h->d_lists = nullptr; }
+    if (h->ov.lists2) { hipFree(h->ov.lists2); h->ov.lists2 = nullptr; }
     if (h->d_nslots) { hipFree(h->d_nslots); h->d_nslots = nullptr; }
     mm.nslots = nullptr;
     for (auto& c : h->d_carry) if (c) { hipFree(c); c = nullptr; }
@@ -704,12 +711,294 @@ static int alloc_debug(mvhdp_ctx* h, const mvhdp_debug* dbg, DebugBufs& db)
     return MVHDP_OK;
 }
 
+// The control words and entity lists one segment's kernels work with (a second set exists for overlapped segments: two segments in flight)
+struct SegCtl {
+    unsigned int* class_counts;        // [MVHDP_N_CLASSES] lengths of the route pass's lists
+    unsigned long long* qheads;        // [8] one work-queue head per kernel class
+    int32_t* lists;                    // [MVHDP_N_CLASSES][D] entity lists (nullptr: the handle's own, allocated on first use)
+};
+
+// Route pass + every class kernel of segment `seg` on stream s (the wider classes on the side streams behind a fork event, joined
+// back into s): positions seg, seg + nseg, ... of the longest-first order.  mk = the model these kernels read and update.
+static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const MvModel& mk, const SweepLaunch& sl, int seg, hipStream_t s,
+                                         const SegCtl& ctl, unsigned long long* d_stats)
+{
+    const MvModel& mm = h->mm;
+    const int nseg = p.nseg;
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    auto share = [&](int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
+    const int64_t n_seg = share(mm.D);
+    unsigned int* class_counts = ctl.class_counts;
+    // entities a class kernel of this segment is sized for (an upper bound is enough: the queue is dynamic)
+    double tok_tot = 0;
+    for (int b = 0; b < MVHDP_HIST_BINS; b++) tok_tot += (double)h->last_hist[b];
+    const bool sizes_known = h->last_ent[MVHDP_N_CLASSES] == 0 && tok_tot > 0;
+    auto blocks_for = [&](int64_t n, const ClassLaunch& g) {
+        const int64_t need = (n + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
+        return (int)std::max<int64_t>(1, std::min<int64_t>(need, g.grid));
+    };
+    {
+        const int64_t H_seg = p.route ? share(p.H) : 0;
+        ClassifyArgs ca{};
+        int32_t* lists = ctl.lists ? ctl.lists : h->d_lists;
+        bool used_stream[PLAN_N_STREAMS] = {};
+        if (p.route && H_seg > 0) {
+            if (!ctl.lists && !h->d_lists) step(hipMalloc(&h->d_lists, (size_t)MVHDP_N_CLASSES * mm.D * sizeof(int32_t)));
+            lists = ctl.lists ? ctl.lists : h->d_lists;
+            if (!h->ev_fork) step(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            if (e != hipSuccess) return e;
+            ca.order = h->d_doc_order; ca.n = H_seg; ca.start = seg; ca.stride = nseg;
+            for (int c = 0; c < MVHDP_N_CLASSES; c++) { ca.class_map[c] = p.class_map[c]; ca.lists[c] = lists + (size_t)c * mm.D; }
+            ca.check_views = compute_max_doc_tokens(h) > 65535 ? 1 : 0;
+            ca.counts = class_counts;
+            // (counted with this sweep's own counters: in a batch -- mvhdp_sweep_many -- every sweep resets the shared control block,
+            // its statistics slot survives to the read-back at the end)
+            ca.misrouted = d_stats + ST_MISCLASS;
+            step(mvhdp_launch_classify(mm, ca, s));
+            step(hipEventRecord(h->ev_fork, s));
+        }
+        // every class kernel of the segment, the widest (longest entities: the sweep's critical path) first; the plan says on which
+        // stream (the widest on the handle's own, the primary on a side stream behind the fork event, see mvhdp_plan.h)
+        for (int c = MVHDP_N_CLASSES - 1; c >= p.pc && e == hipSuccess; c--) {
+            const ClassLaunch& g = p.cls[c];
+            if (!g.used) continue;
+            if (c != p.pc && !(p.route && H_seg > 0)) continue;   // nothing was routed in this segment: the primary alone
+            hipStream_t st = s;
+            if (g.stream != PLAN_STREAM_MAIN && p.route && H_seg > 0) {
+                const int si = g.stream;
+                if (!h->side[si]) step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
+                if (!h->ev_join[si]) step(hipEventCreateWithFlags(&h->ev_join[si], hipEventDisableTiming));
+                if (e != hipSuccess) return e;
+                if (!used_stream[si]) step(hipStreamWaitEvent(h->side[si], h->ev_fork, 0));
+                used_stream[si] = true;
+                st = h->side[si];
+            }
+            // the side streams' kernels first: hold this stream for a moment before the primary takes the chip (mvhdp_launch_delay)
+            if (c == p.pc && st == s) {
+                bool side = false;
+                for (int si = 1; si < PLAN_N_STREAMS; si++) side = side || used_stream[si];
+                if (side) step(mvhdp_launch_delay(h->tu.fork_delay_us, s));
+            }
+            SweepLaunch sc = sl;
+            sc.doc_counter = ctl.qheads + c;
+            sc.wave_bytes = g.wave_bytes; sc.waves_per_block = g.wpb; sc.S_cap = g.S_cap;
+            sc.walk = g.walk; sc.narrow = g.narrow;
+            for (int m = 0; m < MVHDP_MAXM; m++) sc.walk_theta[m] = g.theta[m];
+            int64_t n_c;
+            if (c == p.pc) {
+                // the primary: the routed entities that fit it, then everything too short to exceed it
+                if (p.route && H_seg > 0) { sc.q_list = ca.lists[c]; sc.q_list_count = class_counts + c; }
+                sc.q_order = h->d_doc_order; sc.q_order_start = seg + H_seg * nseg; sc.q_order_stride = nseg; sc.q_order_count = n_seg - H_seg;
+                n_c = n_seg;
+            } else {
+                sc.q_list = ca.lists[c]; sc.q_list_count = class_counts + c;
+                sc.q_order = nullptr; sc.q_order_start = 0; sc.q_order_count = 0;
+                // entities this class can receive: those the plan's histogram puts there (and into classes mapped onto it), doubled
+                // for the unevenness of a segment; everything of the prefix when the sizes are not known
+                n_c = H_seg;
+                if (sizes_known) {
+                    unsigned long long cnt = 0;
+                    for (int q = 0; q < MVHDP_N_CLASSES; q++) if (p.class_map[q] == c) cnt += h->last_ent[q];
+                    n_c = std::min<int64_t>(H_seg, (int64_t)(2 * cnt / (unsigned)nseg) + 64);
+                }
+            }
+            if (g.fast) step(mvhdp_launch_sweep_fast(mk, sc, g.r, blocks_for(n_c, g), p.debug, st));
+            else step(mvhdp_launch_sweep(mk, sc, blocks_for(n_c, g), p.debug, st));
+        }
+        for (int si = 1; si < PLAN_N_STREAMS; si++) if (used_stream[si]) step(hipEventRecord(h->ev_join[si], h->side[si]));
+        for (int si = 1; si < PLAN_N_STREAMS; si++) if (used_stream[si]) step(hipStreamWaitEvent(s, h->ev_join[si], 0));
+    }
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Overlapped segments: two segments of a sweep in flight, so that no segment border idles the chip (a segment's kernels end with
+// a tail of one entity's time per wave, and the updater's pass and the tree rebuild used to run alone between two segments).
+//
+//   MVHDP_SWEEP_SEGMENT_APPLY | SEGMENT_OVERLAP (deterministic, the oracle follows it)
+//     The model is kept twice (B0/B1: counts, mirror, descent tables) and the deltas in three buffers used in turn.  Segment s
+//     samples against the copy that holds the deltas of every segment up to s-2 and writes its own deltas into buffer s mod 3; when
+//     its kernels are done the updater's kernel A(s) -- on a stream of its own, beside the kernels of segment s+1 -- adds the deltas
+//     of segments s-1 and s to the OTHER copy and rebuilds that copy's trees; segment s+2 waits for A(s).  At the end the copy that
+//     missed the last segment takes it, and both copies are the model again.
+//         K(0) K(1)        K(2)        K(3)     ...        two streams, alternating
+//              A(0)        A(1)        A(2)     ...        a third stream; A(s) after K(s), K(s+2) after A(s)
+//   MVHDP_SWEEP_LIVE (racy by design, like the reference's updater)
+//     One copy of the counts, updated in place; only the descent tables exist twice.  The trees of segment s+1 are rebuilt from the
+//     live counts when segment s is about four fifths through (a one-wave gate kernel watches its work-queue head), into the tables
+//     segment s-1 has finished with, and segment s+1's kernels follow at once: its first blocks fill in as segment s drains.
+// The class kernels' grids leave one block per CU free (SweepPlan::overlap): the updater / tree kernels and the next segment's first
+// blocks always find room.  No kernel ever waits for another one on the device (dependencies are stream events; the gate watches a
+// kernel that itself waits for nothing), so nothing here can deadlock.
+// ---------------------------------------------------------------------------------------------------------------
+static int ensure_overlap_buffers(mvhdp_ctx* h, const SweepPlan& p)
+{
+    MvModel& mm = h->mm;
+    const int64_t nrows = mm.rowbase[mm.M];
+    const size_t cbytes = (size_t)(counts_len(h) + MVHDP_TAIL_WORDS) * sizeof(int32_t);
+    auto& ov = h->ov;
+    if (!ov.x1) HIPC(h, hipStreamCreateWithFlags(&ov.x1, hipStreamNonBlocking));
+    if (!ov.xa) HIPC(h, hipStreamCreateWithFlags(&ov.xa, hipStreamNonBlocking));
+    if (!ov.ev_start) HIPC(h, hipEventCreateWithFlags(&ov.ev_start, hipEventDisableTiming));
+    while (ov.ev_seg.size() < (size_t)3 * p.nseg) { hipEvent_t ev; HIPC(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); ov.ev_seg.push_back(ev); }
+    if (!ov.dtab2) HIPC(h, hipMalloc(&ov.dtab2, (size_t)nrows * mm.dt_nblk * 8 * sizeof(double)));
+    if (!ov.root2) HIPC(h, hipMalloc(&ov.root2, (size_t)nrows * sizeof(double)));
+    if (p.need_full && !ov.trees2) HIPC(h, hipMalloc(&ov.trees2, (size_t)nrows * 2 * mm.K * sizeof(double)));
+    if (!ov.ctl2) { HIPC(h, hipMalloc(&ov.ctl2, 16 * sizeof(unsigned long long))); HIPC(h, hipMemset(ov.ctl2, 0, 16 * sizeof(unsigned long long))); }
+    if (p.route && !ov.lists2 && mm.D > 0) HIPC(h, hipMalloc(&ov.lists2, (size_t)MVHDP_N_CLASSES * mm.D * sizeof(int32_t)));
+    if (p.seg_apply) {
+        if (!ov.counts2) HIPC(h, hipMalloc(&ov.counts2, cbytes));
+        if (!ov.counts16_2) HIPC(h, hipMalloc(&ov.counts16_2, (size_t)nrows * mm.K * sizeof(uint16_t)));
+        if (!ov.delta2) { HIPC(h, hipMalloc(&ov.delta2, cbytes)); HIPC(h, hipMemset(ov.delta2, 0, cbytes)); }
+        if (!ov.delta3) { HIPC(h, hipMalloc(&ov.delta3, cbytes)); HIPC(h, hipMemset(ov.delta3, 0, cbytes)); }
+    }
+    return MVHDP_OK;
+}
+
+static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, uint64_t seed, const double* p_override,
+                              unsigned long long* d_stats, hipEvent_t ev_k0, hipEvent_t ev_k1)
+{
+    MvModel& mm = h->mm;
+    const int M = mm.M, nseg = p.nseg;
+    const uint32_t flags = p.flags;
+    int rc = ensure_overlap_buffers(h, p); if (rc) return rc;
+    auto& ov = h->ov;
+    hipStream_t X[2] = {h->stream, ov.x1};
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    const int64_t clen = counts_len(h), nrows = mm.rowbase[M];
+    const size_t cbytes = (size_t)clen * sizeof(int32_t);
+
+    SweepLaunch sl{};
+    sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
+    sl.flags = flags & 0x7fffu; sl.S_cap = p.S_cap;
+    sl.q_order_stride = 1;
+    sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
+    sl.live16 = p.live16 ? 1 : 0;
+    sl.stats = d_stats;
+    sl.act_key = h->d_act_key;
+    sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;
+
+    if (M > 1) {
+        if (!mm.p && mm.D > 0) step(hipMalloc(&mm.p, (size_t)mm.D * M * M * sizeof(double)));
+        if (e == hipSuccess) {
+            if (p_override) step(hipMemcpyAsync(mm.p, p_override, (size_t)mm.D * M * M * sizeof(double), hipMemcpyHostToDevice, X[0]));
+            else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, X[0]));
+        }
+    }
+    h->last_need_full = p.need_full;
+    bool use_mirror = false;
+    for (int c = 0; c < MVHDP_N_CLASSES; c++) use_mirror = use_mirror || (p.cls[c].used && p.cls[c].narrow);
+    // the trees (and the mirror) of the sweep-start counts: what segments 0 and 1 sample from
+    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) {
+        step(mvhdp_launch_build_trees(mm, false, p.need_full, X[0]));
+        h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
+    } else if (p.need_full && !h->full_trees) {
+        step(mvhdp_launch_build_trees(mm, h->trees_inference, true, X[0]));
+        h->full_trees = true;
+    }
+    // the two copies of the model
+    MvModel B[2] = {mm, mm};
+    B[1].dtab = ov.dtab2; B[1].root = ov.root2;
+    if (ov.trees2) B[1].trees = ov.trees2;
+    int32_t* D3[3] = {mm.delta, ov.delta2, ov.delta3};
+    if (p.seg_apply) {
+        B[1].counts = ov.counts2; B[1].counts16 = ov.counts16_2;
+        step(hipMemcpyAsync(ov.counts2, mm.counts, cbytes, hipMemcpyDeviceToDevice, X[0]));
+        step(hipMemcpyAsync(ov.counts16_2, mm.counts16, (size_t)nrows * mm.K * sizeof(uint16_t), hipMemcpyDeviceToDevice, X[0]));
+        if (!h->delta_clean) step(hipMemsetAsync(mm.delta, 0, cbytes, X[0]));
+        h->delta_clean = false;
+        if (ov.deltas_dirty) { step(hipMemsetAsync(ov.delta2, 0, cbytes, X[0])); step(hipMemsetAsync(ov.delta3, 0, cbytes, X[0])); }
+        ov.deltas_dirty = true;                                    // (cleared by mvhdp_sweep_finish / the batch's read-back when the sweep is seen to have finished)
+    } else if (flags & MVHDP_SWEEP_NO_APPLY) {                     // (live, document shards: the caller wants after - before)
+        step(mvhdp_launch_live_helper(mm, 0, d_stats, X[0])); h->delta_clean = false;
+    }
+    SegCtl ctl[2] = {{h->d_ovf_meta + META_CLASS_COUNTS, h->d_doc_counter, nullptr}, {(unsigned int*)(ov.ctl2 + 8), ov.ctl2, ov.lists2}};
+    step(mvhdp_launch_ctl_reset(d_stats, ST_COUNT, h->d_act_key, (unsigned long long*)h->d_ovf_meta, META_WORDS64, nullptr, nullptr, X[0]));
+    step(hipEventRecord(ev_k0, X[0]));
+    step(hipEventRecord(ov.ev_start, X[0]));
+    step(hipStreamWaitEvent(X[1], ov.ev_start, 0));
+    step(hipStreamWaitEvent(ov.xa, ov.ev_start, 0));
+    auto ev_done = [&](int s) { return ov.ev_seg[(size_t)3 * s]; };
+    auto ev_applied = [&](int s) { return ov.ev_seg[(size_t)3 * s + 1]; };
+    auto ev_reset = [&](int s) { return ov.ev_seg[(size_t)3 * s + 2]; };
+    auto share_of = [&](int seg, int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
+
+    for (int seg = 0; seg < nseg && e == hipSuccess && mm.D > 0; seg++) {
+        hipStream_t xs = X[seg & 1];
+        const SegCtl& cs = ctl[seg & 1];
+        MvModel mk;
+        if (p.seg_apply) {
+            // segment s reads the copy updated by A(s-2): copy 0 for segments 0 and 1, then (s-1) mod 2; its deltas go to buffer s mod 3
+            if (seg >= 2) step(hipStreamWaitEvent(xs, ev_applied(seg - 2), 0));
+            mk = B[seg == 0 ? 0 : (seg - 1) & 1];
+            mk.delta = D3[seg % 3];
+        } else {
+            // live: the counts are one; the trees of segment s are rebuilt, from the live counts, when segment s-1 is nearly through
+            mk = mm;
+            mk.delta = mm.counts;
+            mk.dtab = B[seg & 1].dtab; mk.root = B[seg & 1].root; mk.trees = B[seg & 1].trees;
+            if (seg >= 1 && !(flags & MVHDP_SWEEP_REUSE_TREES)) {
+                step(hipStreamWaitEvent(xs, ev_reset(seg - 1), 0));          // (the head the gate watches has been reset for segment s-1)
+                const int64_t n_prev = share_of(seg - 1, mm.D), H_prev = p.route ? share_of(seg - 1, p.H) : 0;
+                const unsigned long long thr = (unsigned long long)((n_prev - H_prev) * 4 / 5);
+                step(mvhdp_launch_gate(ctl[(seg - 1) & 1].qheads + p.pc, thr, xs));
+                MvModel tm = mm;
+                tm.dtab = mk.dtab; tm.root = mk.root; tm.trees = mk.trees;
+                if (p.live16) step(mvhdp_launch_build_trees_from_mirror(tm, p.need_full, xs));
+                else step(mvhdp_launch_build_trees(tm, false, p.need_full, xs));
+            } else if (seg >= 1) {
+                mk.dtab = mm.dtab; mk.root = mm.root; mk.trees = mm.trees;     // REUSE_TREES: the host's trees, for every segment
+            }
+        }
+        step(mvhdp_launch_ctl_reset(nullptr, 0, nullptr, nullptr, 0, cs.class_counts, cs.qheads, xs));
+        step(hipEventRecord(ev_reset(seg), xs));
+        step(launch_segment_kernels(h, p, mk, sl, seg, xs, cs, d_stats));
+        step(hipEventRecord(ev_done(seg), xs));
+        if (p.seg_apply) {
+            // A(seg), beside the kernels of segment seg + 1: the other copy += deltas of seg - 1 and seg; its trees
+            step(hipStreamWaitEvent(ov.xa, ev_done(seg), 0));
+            const MvModel& dst = B[(seg + 1) & 1];
+            step(mvhdp_launch_apply2(dst, D3[seg % 3], seg >= 1 ? D3[(seg - 1) % 3] : nullptr, use_mirror, p.need_full, d_stats + ST_NEGATIVE, 0, ov.xa));
+            step(hipEventRecord(ev_applied(seg), ov.xa));
+        }
+    }
+    // everything back onto the handle's stream
+    if (mm.D > 0 && e == hipSuccess) {
+        if (p.seg_apply) {
+            step(hipStreamWaitEvent(X[0], ev_applied(nseg - 1), 0));
+            if (nseg >= 2) step(hipStreamWaitEvent(X[0], ev_done(nseg - 2), 0));
+            // the copy A(nseg-1) did not write lacks the last segment's deltas
+            const MvModel& last = B[(nseg + 1) & 1];
+            step(mvhdp_launch_apply_sparse(last, D3[(nseg - 1) % 3], use_mirror, X[0]));
+            h->have_trees = false;
+            // (both copies equal now; copy 0 = mm is the model, every delta buffer is zero again)
+        } else {
+            step(hipStreamWaitEvent(X[0], ev_done(nseg - 1), 0));
+            if (nseg >= 2) step(hipStreamWaitEvent(X[0], ev_done(nseg - 2), 0));
+        }
+    }
+    if (p.live) {
+        if (p.live16 && mm.D > 0) { step(mvhdp_launch_widen_mirror(mm, X[0])); h->have_trees = false; }
+        if (flags & MVHDP_SWEEP_NO_APPLY) {
+            step(mvhdp_launch_live_helper(mm, 1, d_stats, X[0]));
+            if (!(flags & MVHDP_SWEEP_REUSE_TREES)) h->have_trees = false;
+        } else step(mvhdp_launch_live_helper(mm, 2, d_stats, X[0]));
+        if (!(flags & MVHDP_SWEEP_REUSE_TREES)) h->have_trees = false;     // (the last segments' trees sit in either table set)
+    }
+    step(hipEventRecord(ev_k1, X[0]));
+    if (e != hipSuccess) HIPC(h, e);
+    return MVHDP_OK;
+}
+
 // Everything one sweep puts on the device, in stream order; returns without waiting (except at the segment borders of a live /
 // segmented sweep over a model with inactive topics, where the host performs the activation UPD:263-270).
 // d_stats: [ST_COUNT] counters of THIS sweep; ev_k0/ev_k1: recorded around the sweep kernels.
 static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, uint64_t seed, const double* p_override,
                          const DebugBufs* db, unsigned long long* d_stats, hipEvent_t ev_k0, hipEvent_t ev_k1, SweepOutcome& oc)
 {
+    if (p.overlap && !db) return enqueue_overlapped(h, p, sweep_idx, seed, p_override, d_stats, ev_k0, ev_k1);
     MvModel& mm = h->mm;
     const int M = mm.M;
     const uint32_t flags = p.flags;
@@ -764,14 +1053,6 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
     step(mvhdp_launch_ctl_reset(d_stats, ST_COUNT, h->d_act_key, (unsigned long long*)h->d_ovf_meta, META_WORDS64, nullptr, h->d_doc_counter, s));
     step(hipEventRecord(ev_k0, s));
 
-    // entities a class kernel of this segment is sized for (an upper bound is enough: the queue is dynamic)
-    double tok_tot = 0;
-    for (int b = 0; b < MVHDP_HIST_BINS; b++) tok_tot += (double)h->last_hist[b];
-    const bool sizes_known = h->last_ent[MVHDP_N_CLASSES] == 0 && tok_tot > 0;
-    auto blocks_for = [&](int64_t n, const ClassLaunch& g) {
-        const int64_t need = (n + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
-        return (int)std::max<int64_t>(1, std::min<int64_t>(need, g.grid));
-    };
     const int seg_lo = p.only_seg >= 0 ? p.only_seg : 0, seg_hi = p.only_seg >= 0 ? p.only_seg + 1 : nseg;
     for (int seg = seg_lo; seg < seg_hi && e == hipSuccess && mm.D > 0; seg++) {
         // segment seg = positions seg, seg + nseg, ... of the order; a prefix [0, P) of the order holds share(P) of them
@@ -809,73 +1090,7 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
             step(mvhdp_launch_ctl_reset(nullptr, 0, nullptr, nullptr, 0, class_counts, h->d_doc_counter, s));
         }
         if (e != hipSuccess) break;
-        const int64_t H_seg = p.route ? share(p.H) : 0;
-        ClassifyArgs ca{};
-        bool used_stream[PLAN_N_STREAMS] = {};
-        if (p.route && H_seg > 0) {
-            if (!h->d_lists) step(hipMalloc(&h->d_lists, (size_t)MVHDP_N_CLASSES * mm.D * sizeof(int32_t)));
-            if (!h->ev_fork) step(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            if (e != hipSuccess) break;
-            ca.order = h->d_doc_order; ca.n = H_seg; ca.start = seg; ca.stride = nseg;
-            for (int c = 0; c < MVHDP_N_CLASSES; c++) { ca.class_map[c] = p.class_map[c]; ca.lists[c] = h->d_lists + (size_t)c * mm.D; }
-            ca.check_views = compute_max_doc_tokens(h) > 65535 ? 1 : 0;
-            ca.counts = class_counts;
-            // (counted with this sweep's own counters: in a batch -- mvhdp_sweep_many -- every sweep resets the shared control block,
-            // its statistics slot survives to the read-back at the end)
-            ca.misrouted = d_stats + ST_MISCLASS;
-            step(mvhdp_launch_classify(mm, ca, s));
-            step(hipEventRecord(h->ev_fork, s));
-        }
-        // every class kernel of the segment, the widest (longest entities: the sweep's critical path) first; the plan says on which
-        // stream (the widest on the handle's own, the primary on a side stream behind the fork event, see mvhdp_plan.h)
-        for (int c = MVHDP_N_CLASSES - 1; c >= p.pc && e == hipSuccess; c--) {
-            const ClassLaunch& g = p.cls[c];
-            if (!g.used) continue;
-            if (c != p.pc && !(p.route && H_seg > 0)) continue;   // nothing was routed in this segment: the primary alone
-            hipStream_t st = s;
-            if (g.stream != PLAN_STREAM_MAIN && p.route && H_seg > 0) {
-                const int si = g.stream;
-                if (!h->side[si]) step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
-                if (!h->ev_join[si]) step(hipEventCreateWithFlags(&h->ev_join[si], hipEventDisableTiming));
-                if (e != hipSuccess) break;
-                if (!used_stream[si]) step(hipStreamWaitEvent(h->side[si], h->ev_fork, 0));
-                used_stream[si] = true;
-                st = h->side[si];
-            }
-            // the side streams' kernels first: hold this stream for a moment before the primary takes the chip (mvhdp_launch_delay)
-            if (c == p.pc && st == s) {
-                bool side = false;
-                for (int si = 1; si < PLAN_N_STREAMS; si++) side = side || used_stream[si];
-                if (side) step(mvhdp_launch_delay(h->tu.fork_delay_us, s));
-            }
-            SweepLaunch sc = sl;
-            sc.doc_counter = h->d_doc_counter + c;
-            sc.wave_bytes = g.wave_bytes; sc.waves_per_block = g.wpb; sc.S_cap = g.S_cap;
-            sc.walk = g.walk; sc.narrow = g.narrow;
-            for (int m = 0; m < MVHDP_MAXM; m++) sc.walk_theta[m] = g.theta[m];
-            int64_t n_c;
-            if (c == p.pc) {
-                // the primary: the routed entities that fit it, then everything too short to exceed it
-                if (p.route && H_seg > 0) { sc.q_list = ca.lists[c]; sc.q_list_count = class_counts + c; }
-                sc.q_order = h->d_doc_order; sc.q_order_start = seg + H_seg * nseg; sc.q_order_stride = nseg; sc.q_order_count = n_seg - H_seg;
-                n_c = n_seg;
-            } else {
-                sc.q_list = ca.lists[c]; sc.q_list_count = class_counts + c;
-                sc.q_order = nullptr; sc.q_order_start = 0; sc.q_order_count = 0;
-                // entities this class can receive: those the plan's histogram puts there (and into classes mapped onto it), doubled
-                // for the unevenness of a segment; everything of the prefix when the sizes are not known
-                n_c = H_seg;
-                if (sizes_known) {
-                    unsigned long long cnt = 0;
-                    for (int q = 0; q < MVHDP_N_CLASSES; q++) if (p.class_map[q] == c) cnt += h->last_ent[q];
-                    n_c = std::min<int64_t>(H_seg, (int64_t)(2 * cnt / (unsigned)nseg) + 64);
-                }
-            }
-            if (g.fast) step(mvhdp_launch_sweep_fast(mk, sc, g.r, blocks_for(n_c, g), p.debug, st));
-            else step(mvhdp_launch_sweep(mk, sc, blocks_for(n_c, g), p.debug, st));
-        }
-        for (int si = 1; si < PLAN_N_STREAMS; si++) if (used_stream[si]) step(hipEventRecord(h->ev_join[si], h->side[si]));
-        for (int si = 1; si < PLAN_N_STREAMS; si++) if (used_stream[si]) step(hipStreamWaitEvent(s, h->ev_join[si], 0));
+        step(launch_segment_kernels(h, p, mk, sl, seg, s, SegCtl{class_counts, h->d_doc_counter, nullptr}, d_stats));
     }
     if (p.seg_apply && mm.D > 0) {                               // the last segment's deltas (the trees are rebuilt by whoever needs them next)
         step(mvhdp_launch_apply_delta(mm, d_stats, s));
@@ -1052,6 +1267,7 @@ int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats)
         // the counts are already updated; what is left of the updater's work is the topic activation of the last segment
         h->have_trees = false;
         if (p.seg_apply) h->delta_clean = true;                      // apply_delta_kernel zeroed what it added
+        if (p.seg_apply && p.overlap) h->ov.deltas_dirty = false;
         ret = apply_activation(h, st.activated_topic, st.activated_modality);
         if (st.activated_topic >= 0) n_activations++;
         if (ps.oc.first_act != LLONG_MAX) {                          // report the sweep's first activation
@@ -1144,6 +1360,7 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
     HIPC(h, hipMemcpyAsync(hs.data(), h->d_stats_many, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPC(h, hipMemcpyAsync(meta, h->d_ovf_meta, sizeof meta, hipMemcpyDeviceToHost, s));
     HIPC(h, hipStreamSynchronize(s));
+    if (p.seg_apply && p.overlap) h->ov.deltas_dirty = false;
     float ms_t = 0;
     hipEventElapsedTime(&ms_t, h->ev[0], h->ev[3]);
     int ret = MVHDP_OK;
@@ -1179,7 +1396,7 @@ extern "C" int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t)
     memset(t, 0, sizeof *t);
     t->force_primary = h->tu.force_primary; t->narrow = h->tu.narrow; t->walk_fixed = h->tu.walk_fixed;
     t->single_stream = h->tu.single_stream; t->primary_min_share = h->tu.primary_min_share; t->live16 = h->tu.live16;
-    t->single_wave = h->tu.single_wave;
+    t->single_wave = h->tu.single_wave; t->live_overlap = h->tu.live_overlap;
     for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) { t->walk_theta[m] = h->tu.walk_theta[m]; t->tree_branch_share[m] = h->wt.walk_f[m]; }
     for (int g = 0; g < WALK_GROUPS; g++) t->learnt_walk_step[g] = g == h->wt.walk_cls ? h->wt.walk_i : h->wt.walk_i_by[g];
     t->learnt_walk_step[3] = -1;
@@ -1198,6 +1415,7 @@ extern "C" int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t)
     h->tu.single_stream = t->single_stream ? 1 : 0;
     h->tu.live16 = t->live16 < 0 ? -1 : (t->live16 ? 1 : 0);
     h->tu.single_wave = t->single_wave ? 1 : 0;
+    h->tu.live_overlap = t->live_overlap < 0 ? -1 : (t->live_overlap ? 1 : 0);
     h->tu.primary_min_share = t->primary_min_share > 0.0 ? t->primary_min_share : 0.10;
     for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) h->tu.walk_theta[m] = t->walk_theta[m];
     if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) h->wt.restore(t->learnt_walk_step, t->tree_branch_share, h->mm.M);
@@ -1224,7 +1442,7 @@ extern "C" int mvhdp_plan_probe(const mvhdp_plan_input* pi, const mvhdp_tuning* 
     wt.init_defaults(in.K);
     if (t) {
         tu.force_primary = t->force_primary; tu.narrow = t->narrow; tu.walk_fixed = t->walk_fixed; tu.single_stream = t->single_stream;
-        tu.live16 = t->live16; tu.single_wave = t->single_wave ? 1 : 0;
+        tu.live16 = t->live16; tu.single_wave = t->single_wave ? 1 : 0; tu.live_overlap = t->live_overlap;
         if (t->primary_min_share > 0) tu.primary_min_share = t->primary_min_share;
         for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) tu.walk_theta[m] = t->walk_theta[m];
         if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) wt.restore(t->learnt_walk_step, t->tree_branch_share, in.M);

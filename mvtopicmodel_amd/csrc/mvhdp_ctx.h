@@ -78,6 +78,18 @@ struct mvhdp_ctx {
     // unassigned token only adds to its row, so while this is set live sweeps stay on the 32-bit table.
     bool unassigned[MVHDP_MAXM]{};
     bool counts_stale = false;               // assignments were replaced (set_assignments / init_from_trees) and the counts not rebuilt since
+    // overlapped segments (MVHDP_SWEEP_SEGMENT_OVERLAP, live sweeps with live_overlap): the second copy of what two segments in flight
+    // must not share, allocated on first use
+    struct Overlap {
+        int32_t* counts2 = nullptr; uint16_t* counts16_2 = nullptr; double* dtab2 = nullptr; double* root2 = nullptr; double* trees2 = nullptr;
+        int32_t* delta2 = nullptr; int32_t* delta3 = nullptr;
+        unsigned long long* ctl2 = nullptr;  // [8] queue heads, then [8 x u32] class list lengths
+        int32_t* lists2 = nullptr;
+        hipStream_t x1 = nullptr, xa = nullptr;
+        hipEvent_t ev_start = nullptr;
+        bool deltas_dirty = false;           // an overlapped segmented sweep was enqueued and has not been seen to finish: delta2 / delta3 may hold leftovers
+        std::vector<hipEvent_t> ev_seg;      // per segment: [3 * s] kernels done, [3 * s + 1] update done, [3 * s + 2] queue heads reset
+    } ov;
     PlanRegs regs{};                         // register counts of the compiled kernels (occupancy)
     PlanTuning tu;                           // what the host pinned (mvhdp_set_tuning; environment read once at create)
     WalkTuner wt;                            // the walk-threshold search

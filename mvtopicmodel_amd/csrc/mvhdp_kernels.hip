@@ -16,6 +16,7 @@
 #include "../../include/mvhdp.h"
 
 #include "mvhdp_wave.h"
+#include <algorithm>
 
 // ---------------------------------------------------------------------------
 // build_counts: PTM:600-652.  One thread per token, int32 atomics.
@@ -66,6 +67,51 @@ hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens,
 // by level (children always have larger indices, so descending depth is safe)
 // and written out whole, coalesced.
 // ---------------------------------------------------------------------------
+// The tree of one (view, type) row from its K leaves in t[K .. 2K): FT:96-109 level by level (children before parents), then the
+// same numbers once more grouped for the descent (MvModel::dtab) and tree[1] by itself.  One wave (a block of 64 threads) per row.
+__device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row, double* t, int lane, bool write_full)
+{
+    const int K = mm.K;
+    if (lane == 0) t[0] = 0.0;
+    __syncthreads();
+    if (K > 1) {
+        int dmax = 31 - __clz(K - 1);                          // depth of node K-1
+        for (int d = dmax; d >= 0; d--) {
+            int lo = 1 << d, hi = min(2 << d, K);
+            for (int i = lo + lane; i < hi; i += WAVE) t[i] = t[2 * i] + t[2 * i + 1];   // FT:105
+            __syncthreads();
+        }
+    }
+    if (write_full) {                                      // FTree.tree itself: generic kernel, get_tree, init_from_trees
+        double* out = mm.trees + row * 2 * K;
+        for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
+    }
+    if (lane == 0) mm.root[row] = t[1];                    // tree[1] by itself: 8 bytes a type, L2-resident (WRK:519 without the walk)
+    // the same numbers once more, grouped for the descent (see MvModel::dtab)
+    double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
+    for (int x = lane; x < mm.dt_nblk; x += WAVE) {
+        // block x of the row: block 0 is rooted at depth 0, then 2^dep blocks for dep = dt_f, dt_f+3, ... (arithmetic, not the
+        // dt_base / dt_depth arrays: a lane-varying index into a kernel-argument array would go through scratch memory)
+        int base = 0, dep = 0;
+        if (x >= 1) {
+            base = 1; dep = mm.dt_f;
+            while (x >= base + (1 << dep)) { base += 1 << dep; dep += 3; }
+        }
+        const int b = (1 << dep) + (x - base);
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int node = (q == 0) ? b : (q < 3) ? 2 * b + (q - 1) : 4 * b + (q - 3);
+            v[q] = (node < K) ? t[2 * node] : 0.0;
+        }
+        v[7] = (x == 0) ? t[1] : 0.0;
+        double2* o = (double2*)(dt + (int64_t)x * 8);
+        o[0] = make_double2(v[0], v[1]); o[1] = make_double2(v[2], v[3]);
+        o[2] = make_double2(v[4], v[5]); o[3] = make_double2(v[6], v[7]);
+    }
+    __syncthreads();
+}
+
 // apply_first: the multi-GPU pipeline's form (mvhdp_apply_delta_rows): the row's all-reduced deltas are added to the
 // counts (UPD:197-207) on the way in -- counts += delta, delta = 0 -- and the tree is built from the updated row; the
 // tokensPerTopic part has been applied before (mvhdp_apply_delta_begin), every tree needs all of it.
@@ -127,44 +173,7 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
             }
             t[K + k] = leaf;
         }
-        if (lane == 0) t[0] = 0.0;
-        __syncthreads();
-        if (K > 1) {
-            int dmax = 31 - __clz(K - 1);                          // depth of node K-1
-            for (int d = dmax; d >= 0; d--) {
-                int lo = 1 << d, hi = min(2 << d, K);
-                for (int i = lo + lane; i < hi; i += WAVE) t[i] = t[2 * i] + t[2 * i + 1];   // FT:105
-                __syncthreads();
-            }
-        }
-        if (write_full) {                                      // FTree.tree itself: generic kernel, get_tree, init_from_trees
-            double* out = mm.trees + row * 2 * K;
-            for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
-        }
-        if (lane == 0) mm.root[row] = t[1];                    // tree[1] by itself: 8 bytes a type, L2-resident (WRK:519 without the walk)
-        // the same numbers once more, grouped for the descent (see MvModel::dtab)
-        double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
-        for (int x = lane; x < mm.dt_nblk; x += WAVE) {
-            // block x of the row: block 0 is rooted at depth 0, then 2^dep blocks for dep = dt_f, dt_f+3, ... (arithmetic, not the
-            // dt_base / dt_depth arrays: a lane-varying index into a kernel-argument array would go through scratch memory)
-            int base = 0, dep = 0;
-            if (x >= 1) {
-                base = 1; dep = mm.dt_f;
-                while (x >= base + (1 << dep)) { base += 1 << dep; dep += 3; }
-            }
-            const int b = (1 << dep) + (x - base);
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 7; q++) {
-                const int node = (q == 0) ? b : (q < 3) ? 2 * b + (q - 1) : 4 * b + (q - 3);
-                v[q] = (node < K) ? t[2 * node] : 0.0;
-            }
-            v[7] = (x == 0) ? t[1] : 0.0;
-            double2* o = (double2*)(dt + (int64_t)x * 8);
-            o[0] = make_double2(v[0], v[1]); o[1] = make_double2(v[2], v[3]);
-            o[2] = make_double2(v[4], v[5]); o[3] = make_double2(v[6], v[7]);
-        }
-        __syncthreads();
+        tree_from_leaves(mm, row, t, lane, write_full);
     }
     if (apply_first && negatives) {
 #pragma unroll
@@ -196,6 +205,131 @@ hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_fu
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, write_full,
                        (int64_t)0, nrows, false, (unsigned long long*)nullptr, true);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Overlapped segments (MVHDP_SWEEP_SEGMENT_OVERLAP, mvhdp_api.hip enqueue_overlapped): the updater's catch-up for one
+// segment runs BESIDE the sampling of the next.  The model is kept twice (counts, mirror, descent tables); this kernel
+// brings the copy that segment s + 2 will read up to date from the deltas of segments s - 1 and s:
+//     dst += dA (+ dB), dB = 0, the row's tree built from the updated row
+// with memory-side atomics for the count cells -- another kernel (segment s + 1's samplers) is running on the same chip,
+// and an atomic is what every L2 sees at once (tools/microbench/live_staleness.hip) -- and only where a delta is not zero.
+// The row's weight class does not change (a row's total is constant while every token is assigned: the plan refuses
+// the mode otherwise), so a light row's mirror cells take the same delta, packed (+-d << 16 for the upper cell: no
+// cell of a light row can leave [0, 65534]); a heavy row's mirror cells stay 65535.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void apply2_trees_kernel(MvModel mm, const int32_t* __restrict__ dA, int32_t* __restrict__ dB, bool use_mirror,
+                                                          bool write_full, unsigned long long* negatives)
+{
+    extern __shared__ double t[];                  // 2K doubles
+    const int K = mm.K, lane = threadIdx.x;
+    const int64_t nrows = mm.rowbase[mm.M];
+    const int32_t* nk_all = mm.counts + nrows * K;
+    int neg = 0;
+    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        int m = 0;
+        while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
+        int32_t* cnt = mm.counts + row * K;
+        const int32_t* a = dA + row * K;
+        int32_t* b = dB ? dB + row * K : nullptr;
+        unsigned int* m32 = (unsigned int*)mm.counts16;
+        const bool light = use_mirror && !mm.heavy[row];
+        const int32_t* nk = nk_all + (int64_t)m * K;
+        const double* al = mm.alpha + (int64_t)m * (K + 1);
+        const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
+        for (int k = lane; k < K; k += WAVE) {
+            int c = cnt[k];
+            int d = a[k];
+            if (b) { const int d2 = b[k]; if (d2) { d += d2; b[k] = 0; } }
+            if (d) {
+                __hip_atomic_fetch_add(&cnt[k], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c += d;
+                neg += c < 0;                                          // UPD:202-215 logs a negative count; here it is reported
+                if (light) { const int64_t cell = row * K + k; __hip_atomic_fetch_add(&m32[cell >> 1], (unsigned int)d << ((cell & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            double leaf;
+            if (mm.inactive[k]) leaf = 0.0;                            // PTM:2670-2671
+            else {
+                double p_wt = ((double)c + beta) / ((double)nk[k] + beta_sum);   // PTM:2676
+                leaf = gamma * al[k] * p_wt;                            // PTM:2678
+            }
+            t[K + k] = leaf;
+        }
+        tree_from_leaves(mm, row, t, lane, write_full);
+    }
+    if (negatives) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) neg += __shfl_xor(neg, sft, WAVE);
+        if (lane == 0 && neg) atomicAdd(negatives, (unsigned long long)neg);
+    }
+}
+
+// tokensPerTopic of the same update (M*K words, before the rows: every leaf needs all of it)
+__global__ __launch_bounds__(256) void apply2_nk_kernel(int32_t* nk_dst, const int32_t* __restrict__ dA, int32_t* __restrict__ dB, int n, unsigned long long* negatives)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int d = dA[i];
+    if (dB) { const int d2 = dB[i]; if (d2) { d += d2; dB[i] = 0; } }
+    if (d) { const int c = nk_dst[i] + d; nk_dst[i] = c; if (c < 0 && negatives) atomicAdd(negatives, 1ull); }
+}
+
+hipError_t mvhdp_launch_apply2(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, bool write_full, unsigned long long* negatives, int max_blocks, hipStream_t s)
+{
+    const int64_t nrows = dst.rowbase[dst.M];
+    const int n = dst.M * dst.K;
+    const int64_t off = nrows * dst.K;
+    hipLaunchKernelGGL(apply2_nk_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst.counts + off, dA + off, dB ? dB + off : nullptr, n, negatives);
+    if (nrows <= 0) return hipGetLastError();
+    int grid = (int)(nrows < 65536 ? nrows : 65536);
+    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+    hipLaunchKernelGGL(apply2_trees_kernel, dim3(grid), dim3(64), (size_t)2 * dst.K * sizeof(double), s, dst, dA, dB, use_mirror, write_full, negatives);
+    return hipGetLastError();
+}
+
+// The copy that missed the last segment's deltas takes them (no trees: nothing samples from it before the next rebuild); d = 0.
+// Nothing else runs on the chip by then: plain read-modify-write, the packed mirror cells by atomics (two cells share a word).
+__global__ __launch_bounds__(256) void apply_sparse_kernel(MvModel mm, int32_t* __restrict__ d, bool use_mirror, int64_t n_cells, int64_t n_all)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int* m32 = (unsigned int*)mm.counts16;
+    const int K = mm.K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += stride) {
+        const int dl = d[i];
+        if (!dl) continue;
+        mm.counts[i] += dl;
+        d[i] = 0;
+        if (use_mirror && i < n_cells && !mm.heavy[i / K]) __hip_atomic_fetch_add(&m32[i >> 1], (unsigned int)dl << ((i & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+hipError_t mvhdp_launch_apply_sparse(const MvModel& dst, int32_t* d, bool use_mirror, hipStream_t s)
+{
+    const int64_t cells = dst.rowbase[dst.M] * dst.K, all = cells + (int64_t)dst.M * dst.K;
+    int grid = (int)std::min<int64_t>((all + 255) / 256, 8192);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(apply_sparse_kernel, dim3(grid), dim3(256), 0, s, dst, d, use_mirror, cells, all);
+    return hipGetLastError();
+}
+
+// Holds a stream until the work-queue head `*qhead` of a running sweep kernel has passed `threshold` entities (a live sweep's next
+// segment is prepared -- trees rebuilt from the live counts -- when the current one is nearly through, not when it starts).  One wave;
+// it always terminates (about two seconds at the latest): the kernel it watches never waits for anything.
+__global__ __launch_bounds__(64) void gate_kernel(const unsigned long long* qhead, unsigned long long threshold)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 4000000; i++) {
+        const unsigned long long v = __hip_atomic_load(qhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= threshold) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;     // 2 s of the 100 MHz counter
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+hipError_t mvhdp_launch_gate(const unsigned long long* qhead, unsigned long long threshold, hipStream_t s)
+{
+    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, qhead, threshold);
     return hipGetLastError();
 }
 

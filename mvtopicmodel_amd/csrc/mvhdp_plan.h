@@ -70,6 +70,7 @@ struct SweepPlan {
     const char* msg = "";
     uint32_t flags = 0;
     bool live = false, seg_apply = false, frozen = false, debug = false;
+    bool overlap = false;                       // two segments in flight (SEGMENT_OVERLAP, or a live sweep with live_overlap): the grids leave one block per CU free
     int nseg = 1;
     int only_seg = -1;                          // >= 0: only this segment is swept (MVHDP_SWEEP_ONLY_SEGMENT)
     int S_cap = 0;
@@ -127,6 +128,7 @@ struct PlanTuning {
     int narrow_wide = 1;                        // 1: deferred sweeps gather from the mirror in the wider variants too (0: the 1-round variant only)
     int fork_delay_us = 0;                      // microseconds the handle's stream is held between the fork event and the primary kernel (0: none)
     int widest_on_main = 0;                     // 1: the widest class on the handle's stream, the primary on a side stream (diagnostics)
+    int live_overlap = -1;                      // live sweeps: segments overlapped (two in flight); 0: one after the other
     int single_wave = 0;                        // diagnostics: every sweep kernel as one wavefront, class kernels one after another, live sweeps strictly ordered
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
 };
@@ -298,7 +300,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     uint32_t flags = in.flags;
     if (flags & MVHDP_SWEEP_FROZEN) flags |= MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY;   // nut == 0: the model is read-only
     if (flags & ~(MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_EXACT_CHAIN | MVHDP_SWEEP_GENERIC_KERNEL | MVHDP_SWEEP_FROZEN |
-                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff) | MVHDP_SWEEP_SEGMENT_APPLY | 0xff000000u)) return fail(MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
+                  MVHDP_SWEEP_LIVE | MVHDP_SWEEP_LIVE_SEGMENTS(0xff) | MVHDP_SWEEP_SEGMENT_APPLY | MVHDP_SWEEP_SEGMENT_OVERLAP | 0xff000000u)) return fail(MVHDP_ERR_INVALID_ARG, "sweep: unknown flag");
     p.flags = flags;
     p.live = (flags & MVHDP_SWEEP_LIVE) != 0;
     p.seg_apply = (flags & MVHDP_SWEEP_SEGMENT_APPLY) != 0;
@@ -307,6 +309,9 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     if (p.seg_apply && (flags & (MVHDP_SWEEP_LIVE | MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_REUSE_TREES)))
         return fail(MVHDP_ERR_INVALID_ARG, "sweep: SEGMENT_APPLY excludes LIVE, NO_APPLY, FROZEN and REUSE_TREES");
     if (p.live && p.frozen) return fail(MVHDP_ERR_INVALID_ARG, "sweep: LIVE and FROZEN exclude each other");
+    if ((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) && !p.seg_apply) return fail(MVHDP_ERR_INVALID_ARG, "sweep: SEGMENT_OVERLAP goes with SEGMENT_APPLY");
+    if ((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) && in.first_inactive >= 0) return fail(MVHDP_ERR_UNSUPPORTED, "sweep: SEGMENT_OVERLAP with inactive topics (the activation needs the host between segments)");
+    if ((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) && in.debug) return fail(MVHDP_ERR_UNSUPPORTED, "sweep: SEGMENT_OVERLAP with debug outputs");
     // live / segmented sweeps: the entities are cut into nseg interleaved segments of the longest-first order
     // (a deferred sweep accepts a segment count too: same integers as one segment, the trees being those of the snapshot)
     int nseg = (int)((flags >> 16) & 0xffu);
@@ -376,14 +381,16 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
         const int regs = is_fast ? in.regs.regs[c][in.debug ? 2 : (walk ? 1 : 0)] : in.regs.regs[5][in.debug ? 2 : 0];
         const int bpc = plan_blocks_per_cu(regs, 64 * g.wpb, g.lds);
         const int64_t need = (in.D + (int64_t)g.wpb * MVHDP_DOC_BATCH - 1) / ((int64_t)g.wpb * MVHDP_DOC_BATCH);
-        g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)in.num_cus * bpc));
+        // (two segments in flight: one block per CU stays free for the updater's kernels and the next segment's first blocks)
+        g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)in.num_cus * ((p.overlap && bpc > 1) ? bpc - 1 : bpc)));
         if (tu.single_wave) { g.wpb = 1; g.lds = p.block_shared_bytes + g.wave_bytes; g.grid = 1; }
         return true;
     };
 
     // ---- walk thresholds of this sweep and the kernel flavours that go with them ----
     // which threshold group a class's kernel belongs to: decided by its flavour (below), which for class 0 depends on the mirror
-    const bool mirror_ok = fast && !in.debug && tu.narrow != 0 && (!(flags & MVHDP_SWEEP_REUSE_TREES) || in.trees_current);
+    const bool mirror_ok = fast && !in.debug && tu.narrow != 0 && (!(flags & MVHDP_SWEEP_REUSE_TREES) || in.trees_current) &&
+                           !((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) && in.unassigned);   // (there the mirror follows by deltas: a row's weight class must not move)
     // (not while a token may be unassigned: its first visit only ADDS to its row, so a row classified light when its tree was built
     // could reach 65535 in a cell -- read as "see the 32-bit table" -- or carry into the neighbouring cell of the packed word)
     const bool want_live16 = mirror_ok && p.live && !p.frozen && !in.unassigned && (tu.live16 > 0 || (tu.live16 < 0 && K >= 256));
@@ -469,5 +476,5 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
             for (int c = 0; c < MVHDP_N_CLASSES; c++) if (p.cls[c].used) { p.cls[c].walk = 1; p.cls[c].narrow = 1; }
         }
     }
-    p.walk_cfg = (p.fast ? (1 << p.dominant) : 32) * 2 + (p.route ? 1 : 0) + 64 * nseg + (p.live ? 1 << 16 : 0) + (p.seg_apply ? 1 << 17 : 0) + (p.live16 ? 1 << 18 : 0);
+    p.walk_cfg = (p.fast ? (1 << p.dominant) : 32) * 2 + (p.route ? 1 : 0) + 64 * nseg + (p.live ? 1 << 16 : 0) + (p.seg_apply ? 1 << 17 : 0) + (p.live16 ? 1 << 18 : 0) + (p.overlap ? 1 << 19 : 0);
 }

@@ -400,6 +400,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nSetTuning(JNI
     std::memset(&t, 0, sizeof t);
     t.force_primary = iv[0]; t.narrow = iv[1]; t.walk_fixed = iv[2]; t.single_stream = iv[3]; t.live16 = iv[4];
     t.learnt_walk_step[0] = iv[5]; t.learnt_walk_step[1] = iv[6]; t.learnt_walk_step[2] = iv[7]; t.learnt_walk_step[3] = -1;
+    t.live_overlap = -1;                                     // (the library's default: overlapped segments in live sweeps)
     t.primary_min_share = dv[0];
     for (int m = 0; m < 8; m++) { t.walk_theta[m] = dv[1 + m]; t.tree_branch_share[m] = dv[9 + m]; }
     int rc = mvhdp_set_tuning(s->h, &t);

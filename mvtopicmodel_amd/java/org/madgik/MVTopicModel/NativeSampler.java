@@ -22,6 +22,7 @@ public final class NativeSampler implements AutoCloseable {
     public static final int SWEEP_FROZEN = 0x10;       // the inferencer's call (nst = 1, nut = 0)
     public static final int SWEEP_LIVE = 0x20;         // the updater threads' own discipline: atomics on the shared counts
     public static final int SWEEP_SEGMENT_APPLY = 0x40; // deterministic: segments sampled one after the other, deltas applied in between
+    public static final int SWEEP_SEGMENT_OVERLAP = 0x80; // with SEGMENT_APPLY: the deltas of segment s are applied while segment s+1 samples (s+2 sees them)
     public static int sweepLiveSegments(int n) { return (n & 0xff) << 16; }
     public static int sweepOnlySegment(int s) { return ((s + 1) & 0xff) << 24; }   // only segment s of the n segments
 

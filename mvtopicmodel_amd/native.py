@@ -20,6 +20,7 @@ SWEEP_GENERIC_KERNEL = 0x8
 SWEEP_FROZEN = 0x10
 SWEEP_LIVE = 0x20
 SWEEP_SEGMENT_APPLY = 0x40
+SWEEP_SEGMENT_OVERLAP = 0x80
 
 
 def SWEEP_LIVE_SEGMENTS(n):

@@ -76,7 +76,7 @@ def test_activation_key_layout_is_defined_once():
     key = (123456 << dist.ACT_DOC_SHIFT) | (3 << dist.ACT_VIEW_SHIFT) | (77 << dist.ACT_POS_SHIFT) | 1999
     assert dist.decode_activation(key) == (1999, 3) and dist.decode_activation(dist.KEY_NONE) == (-1, -1)
     # the sweep flags of the Python mirror are the header's
-    for name in ("REUSE_TREES", "NO_APPLY", "EXACT_CHAIN", "GENERIC_KERNEL", "FROZEN", "LIVE", "SEGMENT_APPLY"):
+    for name in ("REUSE_TREES", "NO_APPLY", "EXACT_CHAIN", "GENERIC_KERNEL", "FROZEN", "LIVE", "SEGMENT_APPLY", "SEGMENT_OVERLAP"):
         assert getattr(native, "SWEEP_" + name) == int(re.search(r"#define\s+MVHDP_SWEEP_%s\s+(0x[0-9a-fA-F]+)u" % name, hdr).group(1), 16)
     assert native.SWEEP_LIVE_SEGMENTS(5) == 5 << 16
 

@@ -33,13 +33,16 @@ def _check_counts_are_counts_of_z(c, s, K):
         assert np.array_equal(nk.astype(np.int64), want[m].sum(axis=0)), f"n_k is not the column sum in view {m}"
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
 @pytest.mark.parametrize("live16", ["0", "1"])
 @pytest.mark.parametrize("nseg", [0, 1, 3, 7])
 @pytest.mark.parametrize("K,V,D,lam,cseed", [(20, [300, 40, 50], 200, [30, 4, 6], 31), (200, [3000, 300, 300], 300, [127, 7, 15], 32)])
-def test_live_sweep_invariants(K, V, D, lam, cseed, nseg, live16, monkeypatch):
+def test_live_sweep_invariants(K, V, D, lam, cseed, nseg, live16, overlap, monkeypatch):
     """live16 = 1: the sweep's atomics of the light n_wk rows land in the 16-bit mirror (two cells per word), which every kernel of the
-    sweep gathers from; 0: atomics and gathers on the 32-bit table."""
+    sweep gathers from; 0: atomics and gathers on the 32-bit table.  overlap = 1 (the default): two segments in flight -- the next
+    segment's trees are rebuilt and its kernels launched when the current one is nearly through; 0: one segment after the other."""
     monkeypatch.setenv("MVHDP_LIVE16", live16)
+    monkeypatch.setenv("MVHDP_LIVE_OVERLAP", overlap)
     c = small_corpus(K, V, D, lam, cseed)
     hy = Hyper.defaults(K, V)
     o = make_oracle(c, hy)

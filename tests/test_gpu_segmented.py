@@ -119,3 +119,91 @@ def test_segmented_sweep_activates_a_topic_at_every_segment_border():
         assert np.array_equal(s.get_alpha()[0], o.get_alpha()) and np.array_equal(s.get_alpha()[1], o.get_inactive())
     assert born >= 6 and st.activations >= 2
     s.close()
+
+
+def oracle_overlapped_sweep(o, c, it, seed, nseg):
+    """MVHDP_SWEEP_SEGMENT_OVERLAP: the updater runs beside the samplers -- the deltas of segment s are applied while segment s+1
+    is sampled, so segment s samples against the counts after segment s-2 (segments 0 and 1: the sweep-start counts)."""
+    from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY
+    stats = dict(tokens=0, changed=0, new_mass_cnt=0, topic_doc_mass_cnt=0, word_ftree_mass_cnt=0)
+    pending = []
+    for sidx, docs in enumerate(segment_lists(c, nseg)):
+        if sidx >= 2:
+            r0 = pending.pop(0)
+            o.apply_delta(r0["delta_nwk"], r0["delta_nk"], -1, -1)
+        r = o.sweep_list(it, seed, docs, flags=ORC_NO_APPLY, want_delta=True)
+        pending.append(r)
+        for k in stats:
+            stats[k] += r["stats"][k]
+    for r0 in pending:
+        o.apply_delta(r0["delta_nwk"], r0["delta_nk"], -1, -1)
+    return stats
+
+
+@pytest.mark.parametrize("force,mode", [("", ""), ("1", "serial"), ("2", "streams"), ("8", "serial")])
+@pytest.mark.parametrize("nseg", [2, 3, 5, 8])
+def test_overlapped_segmented_sweep_bit_exact(nseg, force, mode, monkeypatch):
+    """Two segments in flight, the updater's kernel beside the samplers: every integer is the oracle's lag-two schedule's, whatever
+    the segment count (even: the model ends in copy 0; odd: in copy 1 and is carried over), variant or dispatch mode -- and the
+    16-bit mirror, which follows by packed deltas, is the counts' (a deferred sweep afterwards gathers from it)."""
+    from mvtopicmodel_amd.native import SWEEP_SEGMENT_OVERLAP
+    if force:
+        monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
+    if mode:
+        monkeypatch.setenv("MVHDP_FORCE_MODE", mode)
+    K, V = 300, [2000, 200, 150]
+    c = small_corpus(K, V, 157, [200, 9, 12], 33)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    for it in range(4):
+        so = oracle_overlapped_sweep(o, c, it, 5, nseg)
+        st = s.sweep(it, 5, flags=SWEEP_SEGMENT_APPLY | SWEEP_SEGMENT_OVERLAP | SWEEP_LIVE_SEGMENTS(nseg))
+        assert (st.tokens, st.changed, st.topic_doc_mass_cnt, st.word_ftree_mass_cnt) == \
+               (so["tokens"], so["changed"], so["topic_doc_mass_cnt"], so["word_ftree_mass_cnt"])
+        assert_same_state(o, s, c.M)
+    # a plain deferred sweep and a plain segmented one afterwards: the handle is in an ordinary state
+    o.sweep(9, 5); s.sweep(9, 5)
+    assert_same_state(o, s, c.M)
+    oracle_segmented_sweep(o, c, 10, 5, 3); s.sweep(10, 5, flags=SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(3))
+    assert_same_state(o, s, c.M)
+    s.close()
+
+
+def test_overlapped_segmented_sweep_small_shapes_oov_and_batches():
+    """One view, types outside the alphabet, unassigned tokens at the start (the mirror stays out while row totals can grow), more
+    segments than a kernel has waves' worth of entities, and the same sweeps as one mvhdp_sweep_many batch on a twin handle."""
+    from mvtopicmodel_amd.native import SWEEP_SEGMENT_OVERLAP
+    K, V = 24, [120]
+    c = small_corpus(K, V, 70, [18], 61)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(0).copy()]
+    z[0][::7] = -1
+    o.set_assignments(0, z[0]); o.build_counts()
+    a, b = make_native(c, hy, z), make_native(c, hy, z)
+    fl = SWEEP_SEGMENT_APPLY | SWEEP_SEGMENT_OVERLAP | SWEEP_LIVE_SEGMENTS(6)
+    for it in range(3):
+        oracle_overlapped_sweep(o, c, it, 8, 6)
+        a.sweep(it, 8, flags=fl)
+        assert_same_state(o, a, 1)
+    b.sweep_many(0, 3, 8, flags=fl)
+    assert_same_state(o, b, 1)
+    with pytest.raises(MvhdpError):
+        a.sweep(5, 8, flags=SWEEP_SEGMENT_OVERLAP)                          # goes with SEGMENT_APPLY only
+    a.close(); b.close()
+
+
+def test_overlapped_segmented_sweep_refuses_inactive_topics():
+    from mvtopicmodel_amd.native import SWEEP_SEGMENT_OVERLAP
+    K, V = 20, [100]
+    c = small_corpus(K, V, 40, [10], 62)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[18] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(0) % 18]
+    s = make_native(c, hy, z)
+    with pytest.raises(MvhdpError) as ei:
+        s.sweep(0, 1, flags=SWEEP_SEGMENT_APPLY | SWEEP_SEGMENT_OVERLAP | SWEEP_LIVE_SEGMENTS(4))
+    assert ei.value.code == -6
+    s.close()
