@@ -149,7 +149,7 @@ def main():
     import torch.distributed as dist
     from mvtopicmodel_amd import NativeGroup, NativeSampler, synth
     from mvtopicmodel_amd.dist import GpuShard, build_counts_all_reduce, sweep_all_reduce
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
 
     if not torch.cuda.is_available():

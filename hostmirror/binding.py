@@ -9,7 +9,7 @@ import weakref
 
 import numpy as np
 
-from ._lib import SweepStatsC, load_library
+from mvtopicmodel_amd._lib import SweepStatsC, load_library
 
 HOST_SYMBOLS = [
     "mvtm_last_error", "mvtm_model_new", "mvtm_model_delete", "mvtm_model_configure",
@@ -24,7 +24,7 @@ HOST_SYMBOLS = [
     "mvtm_inferencer_doc_topics", "mvtm_inferencer_print_document_topics", "mvtm_inferencer_get_stats",
 ]
 
-HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hostmirror", "lib", "libmvtm_host.so")
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvtm_host.so")
 _host = None
 
 _ready = False

@@ -817,16 +817,19 @@ static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const
 // a tail of one entity's time per wave, and the updater's pass and the tree rebuild used to run alone between two segments).
 //
 //   MVHDP_SWEEP_SEGMENT_APPLY | SEGMENT_OVERLAP (deterministic, the oracle follows it)
-//     The model is kept twice (B0/B1: counts, mirror, descent tables) and the deltas in three buffers used in turn.  Segment s
-//     samples against the copy that holds the deltas of every segment up to s-2 and writes its own deltas into buffer s mod 3; when
-//     its kernels are done the updater's kernel A(s) -- on a stream of its own, beside the kernels of segment s+1 -- adds the deltas
-//     of segments s-1 and s to the OTHER copy and rebuilds that copy's trees; segment s+2 waits for A(s).  At the end the copy that
-//     missed the last segment takes it, and both copies are the model again.
-//         K(0) K(1)        K(2)        K(3)     ...        two streams, alternating
-//              A(0)        A(1)        A(2)     ...        a third stream; A(s) after K(s), K(s+2) after A(s)
+//     The counts (and their 16-bit mirror) are kept twice (B0/B1) and the deltas in three buffers used in turn.  Segment s samples
+//     against the copy that holds the deltas of every segment up to s-2 and writes its own deltas into buffer s mod 3; when its
+//     kernels are done the updater's kernel A(s) -- beside the kernels of segment s+1 -- adds the deltas of segments s-1 and s to the
+//     OTHER copy; segment s+2 waits for A(s).  At the end the copy that missed the last segment takes it, and both copies are the
+//     model again.  The F+trees are those of the sweep start for every segment, as the reference's are between two buildFTrees calls
+//     (PTM:1209; its updater refreshes the touched leaves only, UPD:242-260): rebuilding them per segment beside the samplers took a
+//     whole segment's time in the one block slot per CU the samplers leave (profiles/r04_overlap_timelines.md), which put the
+//     rebuild back on the critical path.
+//         stream 0:  K(0) A(0) K(2) A(2) K(4) ...          A(s) behind K(s) on its stream and behind A(s-1) on the other one;
+//         stream 1:  K(1) A(1) K(3) A(3) ...               K(s+2) behind A(s): while A(s) runs, stream 1 - s mod 2 is sampling
 //   MVHDP_SWEEP_LIVE (racy by design, like the reference's updater)
 //     One copy of the counts, updated in place; only the descent tables exist twice.  The trees of segment s+1 are rebuilt from the
-//     live counts when segment s is about four fifths through (a one-wave gate kernel watches its work-queue head), into the tables
+//     live counts when segment s is about three fifths through (a one-wave gate kernel watches its work-queue head), into the tables
 //     segment s-1 has finished with, and segment s+1's kernels follow at once: its first blocks fill in as segment s drains.
 // The class kernels' grids leave one block per CU free (SweepPlan::overlap): the updater / tree kernels and the next segment's first
 // blocks always find room.  No kernel ever waits for another one on the device (dependencies are stream events; the gate watches a
@@ -839,12 +842,14 @@ static int ensure_overlap_buffers(mvhdp_ctx* h, const SweepPlan& p)
     const size_t cbytes = (size_t)(counts_len(h) + MVHDP_TAIL_WORDS) * sizeof(int32_t);
     auto& ov = h->ov;
     if (!ov.x1) HIPC(h, hipStreamCreateWithFlags(&ov.x1, hipStreamNonBlocking));
-    if (!ov.xa) HIPC(h, hipStreamCreateWithFlags(&ov.xa, hipStreamNonBlocking));
+
     if (!ov.ev_start) HIPC(h, hipEventCreateWithFlags(&ov.ev_start, hipEventDisableTiming));
     while (ov.ev_seg.size() < (size_t)3 * p.nseg) { hipEvent_t ev; HIPC(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); ov.ev_seg.push_back(ev); }
-    if (!ov.dtab2) HIPC(h, hipMalloc(&ov.dtab2, (size_t)nrows * mm.dt_nblk * 8 * sizeof(double)));
-    if (!ov.root2) HIPC(h, hipMalloc(&ov.root2, (size_t)nrows * sizeof(double)));
-    if (p.need_full && !ov.trees2) HIPC(h, hipMalloc(&ov.trees2, (size_t)nrows * 2 * mm.K * sizeof(double)));
+    if (p.live) {                                        // (the trees exist twice for live sweeps only: the segmented sweep keeps the sweep-start trees)
+        if (!ov.dtab2) HIPC(h, hipMalloc(&ov.dtab2, (size_t)nrows * mm.dt_nblk * 8 * sizeof(double)));
+        if (!ov.root2) HIPC(h, hipMalloc(&ov.root2, (size_t)nrows * sizeof(double)));
+        if (p.need_full && !ov.trees2) HIPC(h, hipMalloc(&ov.trees2, (size_t)nrows * 2 * mm.K * sizeof(double)));
+    }
     if (!ov.ctl2) { HIPC(h, hipMalloc(&ov.ctl2, 16 * sizeof(unsigned long long))); HIPC(h, hipMemset(ov.ctl2, 0, 16 * sizeof(unsigned long long))); }
     if (p.route && !ov.lists2 && mm.D > 0) HIPC(h, hipMalloc(&ov.lists2, (size_t)MVHDP_N_CLASSES * mm.D * sizeof(int32_t)));
     if (p.seg_apply) {
@@ -865,6 +870,7 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
     int rc = ensure_overlap_buffers(h, p); if (rc) return rc;
     auto& ov = h->ov;
     hipStream_t X[2] = {h->stream, ov.x1};
+    if (getenv("MVHDP_OVERLAP_SERIAL")) X[1] = h->stream;                          // (diagnostics: the same schedule on one stream)
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     const int64_t clen = counts_len(h), nrows = mm.rowbase[M];
@@ -900,8 +906,7 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
     }
     // the two copies of the model
     MvModel B[2] = {mm, mm};
-    B[1].dtab = ov.dtab2; B[1].root = ov.root2;
-    if (ov.trees2) B[1].trees = ov.trees2;
+    if (p.live) { B[1].dtab = ov.dtab2; B[1].root = ov.root2; if (ov.trees2) B[1].trees = ov.trees2; }
     int32_t* D3[3] = {mm.delta, ov.delta2, ov.delta3};
     if (p.seg_apply) {
         B[1].counts = ov.counts2; B[1].counts16 = ov.counts16_2;
@@ -919,7 +924,6 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
     step(hipEventRecord(ev_k0, X[0]));
     step(hipEventRecord(ov.ev_start, X[0]));
     step(hipStreamWaitEvent(X[1], ov.ev_start, 0));
-    step(hipStreamWaitEvent(ov.xa, ov.ev_start, 0));
     auto ev_done = [&](int s) { return ov.ev_seg[(size_t)3 * s]; };
     auto ev_applied = [&](int s) { return ov.ev_seg[(size_t)3 * s + 1]; };
     auto ev_reset = [&](int s) { return ov.ev_seg[(size_t)3 * s + 2]; };
@@ -931,7 +935,7 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
         MvModel mk;
         if (p.seg_apply) {
             // segment s reads the copy updated by A(s-2): copy 0 for segments 0 and 1, then (s-1) mod 2; its deltas go to buffer s mod 3
-            if (seg >= 2) step(hipStreamWaitEvent(xs, ev_applied(seg - 2), 0));
+            // (A(seg - 2) sits in front of this segment on the same stream)
             mk = B[seg == 0 ? 0 : (seg - 1) & 1];
             mk.delta = D3[seg % 3];
         } else {
@@ -942,7 +946,9 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
             if (seg >= 1 && !(flags & MVHDP_SWEEP_REUSE_TREES)) {
                 step(hipStreamWaitEvent(xs, ev_reset(seg - 1), 0));          // (the head the gate watches has been reset for segment s-1)
                 const int64_t n_prev = share_of(seg - 1, mm.D), H_prev = p.route ? share_of(seg - 1, p.H) : 0;
-                const unsigned long long thr = (unsigned long long)((n_prev - H_prev) * 4 / 5);
+                // (three fifths through: the rebuild takes about a millisecond beside the samplers, and the next segment's first blocks
+                // should be waiting when the current segment's queue runs dry)
+                const unsigned long long thr = (unsigned long long)((n_prev - H_prev) * 3 / 5);
                 step(mvhdp_launch_gate(ctl[(seg - 1) & 1].qheads + p.pc, thr, xs));
                 MvModel tm = mm;
                 tm.dtab = mk.dtab; tm.root = mk.root; tm.trees = mk.trees;
@@ -957,11 +963,13 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
         step(launch_segment_kernels(h, p, mk, sl, seg, xs, cs, d_stats));
         step(hipEventRecord(ev_done(seg), xs));
         if (p.seg_apply) {
-            // A(seg), beside the kernels of segment seg + 1: the other copy += deltas of seg - 1 and seg; its trees
-            step(hipStreamWaitEvent(ov.xa, ev_done(seg), 0));
+            // A(seg), beside the kernels of segment seg + 1: the other copy += deltas of seg - 1 and seg; its trees.  On this segment's
+            // own stream, between K(seg) and K(seg + 2) -- which needs it anyway --, behind A(seg - 1) on the other stream.  (A stream
+            // of its own shared a hardware queue with the side stream of the wider class kernels: the runtime has four.)
+            if (seg >= 1) step(hipStreamWaitEvent(xs, ev_applied(seg - 1), 0));
             const MvModel& dst = B[(seg + 1) & 1];
-            step(mvhdp_launch_apply2(dst, D3[seg % 3], seg >= 1 ? D3[(seg - 1) % 3] : nullptr, use_mirror, p.need_full, d_stats + ST_NEGATIVE, 0, ov.xa));
-            step(hipEventRecord(ev_applied(seg), ov.xa));
+            step(mvhdp_launch_apply2_counts(dst, D3[seg % 3], seg >= 1 ? D3[(seg - 1) % 3] : nullptr, use_mirror, d_stats + ST_NEGATIVE, xs));
+            step(hipEventRecord(ev_applied(seg), xs));
         }
     }
     // everything back onto the handle's stream

@@ -123,6 +123,7 @@ hipError_t mvhdp_launch_widen_mirror(const MvModel& mm, hipStream_t s);
 hipError_t mvhdp_launch_apply_nk(const MvModel& mm, unsigned long long* negatives, hipStream_t s);
 // overlapped segments: dst (counts / mirror / descent tables of the copy segment s + 2 reads) += dA (+ dB, zeroed), trees rebuilt; see the kernel
 hipError_t mvhdp_launch_apply2(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, bool write_full, unsigned long long* negatives, int max_blocks, hipStream_t s);
+hipError_t mvhdp_launch_apply2_counts(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, unsigned long long* negatives, hipStream_t s);
 hipError_t mvhdp_launch_apply_sparse(const MvModel& dst, int32_t* d, bool use_mirror, hipStream_t s);
 hipError_t mvhdp_launch_gate(const unsigned long long* qhead, unsigned long long threshold, hipStream_t s);
 hipError_t mvhdp_launch_init_from_trees(const MvModel& mm, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
     const int64_t nrows = mm.rowbase[mm.M];
     const int32_t* nk_all = mm.counts + nrows * K;
     int neg = 0;
+    __builtin_amdgcn_s_setprio(3);                 // (a live sweep rebuilds the next segment's trees beside the current segment's samplers)
     for (int64_t row = row_begin + blockIdx.x; row < row_end; row += gridDim.x) {
         int m = 0;
         while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
@@ -227,6 +228,9 @@ __global__ __launch_bounds__(64) void apply2_trees_kernel(MvModel mm, const int3
     const int64_t nrows = mm.rowbase[mm.M];
     const int32_t* nk_all = mm.counts + nrows * K;
     int neg = 0;
+    // this kernel runs beside the next segment's samplers, in the one block slot per CU they leave free, and the segment after that
+    // waits for it: let its waves win the instruction arbiter
+    __builtin_amdgcn_s_setprio(3);
     for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
         int m = 0;
         while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
@@ -285,6 +289,37 @@ hipError_t mvhdp_launch_apply2(const MvModel& dst, const int32_t* dA, int32_t* d
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
     hipLaunchKernelGGL(apply2_trees_kernel, dim3(grid), dim3(64), (size_t)2 * dst.K * sizeof(double), s, dst, dA, dB, use_mirror, write_full, negatives);
+    return hipGetLastError();
+}
+
+// The same update without the trees (MVHDP_SWEEP_SEGMENT_OVERLAP keeps the sweep-start trees for every segment, as the reference keeps
+// its trees between two buildFTrees calls, PTM:1209): dst += dA (+ dB), dB = 0, cell by cell, atomics where a delta is not zero.
+// Reads two delta buffers and touches what changed: a tenth of a millisecond of the whole chip at C4, a few tenths beside the samplers.
+__global__ __launch_bounds__(256) void apply2_counts_kernel(MvModel mm, const int32_t* __restrict__ dA, int32_t* __restrict__ dB, bool use_mirror,
+                                                           int64_t n_cells, int64_t n_all, unsigned long long* negatives)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int* m32 = (unsigned int*)mm.counts16;
+    const int K = mm.K;
+    int neg = 0;
+    __builtin_amdgcn_s_setprio(3);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += stride) {
+        int d = dA[i];
+        if (dB) { const int d2 = dB[i]; if (d2) { d += d2; dB[i] = 0; } }
+        if (!d) continue;
+        const int old = __hip_atomic_fetch_add(&mm.counts[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        neg += old + d < 0;
+        if (use_mirror && i < n_cells && !mm.heavy[i / K]) __hip_atomic_fetch_add(&m32[i >> 1], (unsigned int)d << ((i & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (neg && negatives) atomicAdd(negatives, (unsigned long long)neg);
+}
+
+hipError_t mvhdp_launch_apply2_counts(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, unsigned long long* negatives, hipStream_t s)
+{
+    const int64_t cells = dst.rowbase[dst.M] * dst.K, all = cells + (int64_t)dst.M * dst.K;
+    int grid = (int)std::min<int64_t>((all + 255) / 256, 4096);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(apply2_counts_kernel, dim3(grid), dim3(256), 0, s, dst, dA, dB, use_mirror, cells, all, negatives);
     return hipGetLastError();
 }
 
@@ -1180,10 +1215,12 @@ hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, h
 // One thread per entity; a wave appends its entities of a class with ONE atomic (ballot + rank), so the lists keep
 // the longest-first order up to the interleaving of waves.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void route_kernel(MvModel mm, ClassifyArgs ca)
+__global__ __launch_bounds__(256) void route_kernel(MvModel mm, ClassifyArgs ca)
 {
-    // one atomic per class and BLOCK of 1024 entities (per wave it was 0.29 ms for a million entities: 31 k atomics on two words)
-    __shared__ unsigned int wave_cnt[16][MVHDP_N_CLASSES], wave_base[16][MVHDP_N_CLASSES];
+    // one atomic per class and BLOCK of 256 entities (per wave it was 0.29 ms for a million entities: 31 k atomics on two words).  Blocks
+    // of four waves, not sixteen: with overlapped segments this kernel starts while the previous segment's kernels hold all but one block
+    // slot per CU, and a block that needs four waves on every SIMD at once waited for them to drain (1.4 - 5 ms in the kernel trace).
+    __shared__ unsigned int wave_cnt[4][MVHDP_N_CLASSES], wave_base[4][MVHDP_N_CLASSES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int c = -1;
@@ -1221,8 +1258,8 @@ __global__ __launch_bounds__(1024) void route_kernel(MvModel mm, ClassifyArgs ca
 hipError_t mvhdp_launch_classify(const MvModel& mm, const ClassifyArgs& ca, hipStream_t s)
 {
     if (ca.n <= 0) return hipSuccess;
-    const int64_t blocks = (ca.n + 1023) / 1024;
-    hipLaunchKernelGGL(route_kernel, dim3((unsigned int)blocks), dim3(1024), 0, s, mm, ca);
+    const int64_t blocks = (ca.n + 255) / 256;
+    hipLaunchKernelGGL(route_kernel, dim3((unsigned int)blocks), dim3(256), 0, s, mm, ca);
     return hipGetLastError();
 }
 

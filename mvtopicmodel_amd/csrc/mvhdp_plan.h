@@ -321,6 +321,10 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // last entity are empty -- so that document shards of different sizes walk through the same number of exchanges)
     if ((int64_t)nseg > in.D && p.only_seg < 0) nseg = (int)std::max<int64_t>(1, in.D);
     p.nseg = nseg;
+    // two segments in flight (mvhdp_api.hip enqueue_overlapped): asked for (SEGMENT_OVERLAP), or a live sweep of several segments
+    // whose borders need no host (no inactive topic waiting for its activation, no debug output)
+    p.overlap = nseg > 1 && p.only_seg < 0 &&
+                ((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) || (p.live && !tu.single_wave && tu.live_overlap != 0 && in.first_inactive < 0 && !in.debug));
     if (p.only_seg >= 0) {
         if (p.live || p.seg_apply) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT excludes LIVE and SEGMENT_APPLY");
         if (p.only_seg >= nseg) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT beyond the segment count");

@@ -11,7 +11,7 @@ from oracle import dp_samplers as orc
 
 
 def test_cokus_stream_is_mt19937_with_the_1998_seeding():
-    from mvtopicmodel_amd.host import cokus_stream
+    from hostmirror.binding import cokus_stream
     n = 2000                                                       # crosses three state reloads
     got = cokus_stream(n)
     # independent generator: numpy's MT19937 primed with the 69069-LCG state of seed 4357
@@ -44,7 +44,7 @@ def test_stirling_rows_and_first_antoniak_call_follow_the_exact_law():
 
 
 def test_rand_antoniak_sequences_match_including_the_cache_corruption_quirk():
-    from mvtopicmodel_amd.host import rand_antoniak_seq
+    from hostmirror.binding import rand_antoniak_seq
     rng = np.random.RandomState(4)
     n = rng.randint(2, 60, 400).astype(np.int32)
     n[::50] = 200                                                   # extends the cache from already modified rows
@@ -68,7 +68,7 @@ def test_rand_antoniak_sequences_match_including_the_cache_corruption_quirk():
 @pytest.mark.parametrize("kind,a,b", [("gamma", 0.3, 0), ("gamma", 1.0, 0), ("gamma", 7.5, 0), ("gamma_scale", 2.5, 0.25),
                                       ("beta", 2.0, 5.0), ("beta", 11.0, 0.0), ("bernoulli", 0.3, 0)])
 def test_random_samplers_streams_match_oracle_and_moments(kind, a, b):
-    from mvtopicmodel_amd.host import random_samplers_stream
+    from hostmirror.binding import random_samplers_stream
     n = 4000
     got = random_samplers_stream(12345, kind, a, b, n)
     samp = orc.RandomSamplers(orc.JavaRandom(12345))
@@ -83,7 +83,7 @@ def test_random_samplers_streams_match_oracle_and_moments(kind, a, b):
 
 @pytest.mark.parametrize("alpha,beta", [(0.05, 1.0), (0.5, 1.0), (1.0, 2.0), (3.7, 1.0), (250.0, 1.0)])
 def test_mallet_next_gamma_matches_oracle_and_moments(alpha, beta):
-    from mvtopicmodel_amd.host import mallet_next_gamma_stream
+    from hostmirror.binding import mallet_next_gamma_stream
     n = 4000
     got = mallet_next_gamma_stream(99, alpha, beta, n)
     r = orc.JavaRandom(99)

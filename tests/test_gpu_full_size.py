@@ -52,7 +52,7 @@ def test_config_at_full_size(name):
     from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY
     from mvtopicmodel_amd import NativeSampler, synth
     from mvtopicmodel_amd.dist import KEY_NONE, GpuShard, decode_activation
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     cfg = synth.CONFIGS[name]
     K, V = cfg["K"], cfg["V"]
     M = len(V)
@@ -197,7 +197,7 @@ def test_the_kernels_that_carry_the_number_at_full_size(name):
       (c) the live sweep (light rows on the 16-bit mirror): the counts are exactly the recount of z, nothing negative, sums right."""
     from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY
     from mvtopicmodel_amd import NativeSampler, synth
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     from mvtopicmodel_amd.native import SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_ONLY_SEGMENT, SWEEP_SEGMENT_APPLY
     cfg = synth.CONFIGS[name]
     K, V = cfg["K"], cfg["V"]
@@ -274,7 +274,7 @@ def test_c4_driver_command_fingerprint():
     fingerprint of the final counts has been the same in every round's driver record (BENCH_r01.json, BENCH_r02.json) although the
     kernels changed completely in between: a result must not depend on the build, the kernel variants or the walk thresholds."""
     from mvtopicmodel_amd import NativeSampler, synth
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     cfg = synth.CONFIGS["C4"]
     K, V = cfg["K"], cfg["V"]
     c = synth.make_config("C4")

@@ -21,7 +21,7 @@ def _instance_lists(rng, V):
 
 
 def test_add_instances_and_estimate_match_the_oracle():
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from hostmirror.binding import FastQMVWVParallelTopicModel
     from oracle.binding import Oracle
     K, V = 25, [300, 40, 30]
     rng = np.random.RandomState(3)
@@ -76,7 +76,8 @@ def test_add_instances_and_estimate_match_the_oracle():
 
 def test_single_view_is_plain_lda_path():
     """BASELINE config 1/2 shape: M=1 (no view weights are drawn, p[0][0]=1, KAT-6)."""
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, init_assignments
+    from hostmirror.binding import FastQMVWVParallelTopicModel
+    from mvtopicmodel_amd.java_init import init_assignments
     K, V = 20, [500]
     rng = np.random.RandomState(4)
     lens = rng.poisson(20, 80) + 1
@@ -100,7 +101,7 @@ def _run_schedule(K, V, D, lam, cseed, seed, iters, burnin, interval, alpha=0.1,
     """estimate() of the host mirror against the same schedule replayed on the oracle (C sweep + the Python restatement
     of the two randomised steps under the same injected streams).  Returns (model, oracle, hyper state) after `iters`."""
     import math
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from hostmirror.binding import FastQMVWVParallelTopicModel
     from oracle.binding import Oracle
     from oracle import dp_samplers as dps
     from mvtopicmodel_amd import synth
@@ -257,7 +258,7 @@ def test_estimate_schedule_on_more_shapes(K, V, D, lam, iters, burnin, interval)
 def test_print_state_format(tmp_path):
     """SURVEY §8f #4: the text state of printState (PTM:3276-3320), plain and gzipped."""
     import gzip
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, java_double_to_string
+    from hostmirror.binding import FastQMVWVParallelTopicModel, java_double_to_string
     K, V = 7, [30, 9]
     rng = np.random.RandomState(8)
     lens0, lens1 = [3, 2, 4], [1, 2, 1]
@@ -299,7 +300,7 @@ def test_print_state_round_trip(tmp_path):
     back by mvtopicmodel_amd.state_io (the reference's commented-out initializeFromState, PTM:534-573): identical assignments,
     the header's gamma*alpha, and -- pushed through the C ABI into a fresh handle -- identical counts and the same next sweep."""
     from mvtopicmodel_amd import NativeSampler
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from hostmirror.binding import FastQMVWVParallelTopicModel
     from mvtopicmodel_amd.state_io import read_state
     K, V, D = 12, [80, 20, 15], 40
     c = small_corpus(K, V, D, [18, 3, 4], 77)
@@ -343,7 +344,7 @@ def test_number_format_and_display_top_words():
     """displayTopWords PTM:1852-1890: per topic and view `topic<TAB>alpha<TAB>` then the numWords-1 most frequent types,
     ordered as MALLET's IDSorter orders them (count descending, equal counts by descending type id), alpha through
     NumberFormat with at most five fraction digits."""
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, number_format5
+    from hostmirror.binding import FastQMVWVParallelTopicModel, number_format5
     for v, want in [(0.1, "0.1"), (1234567.891234, "1,234,567.89123"), (0.000004, "0"), (0.000005, "0.00001"), (2.5e-6, "0"),
                     (12.0, "12"), (1000.0, "1,000"), (-0.5, "-0.5"), (999999.999999, "1,000,000"),
                     (0.123455, "0.12345")]:      # the double below 0.123455: JDK >= 8 rounds the exact binary value (JDK-7131459)
@@ -379,7 +380,7 @@ def test_inferencer_entry_matches_the_oracle_sequence():
     out-of-vocabulary tokens stay 0), 10 sweeps with nst = 1 / nut = 0 under p_a = 0.2 (INF:216-219), then the topic
     proportions and text of printDocumentTopics(out, 0.03, -1) (INF:326-329, incl. the carried-over counts of a missing
     view, INF:371-386) -- against the same sequence on the oracle."""
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, java_double_to_string
+    from hostmirror.binding import FastQMVWVParallelTopicModel, java_double_to_string
     from mvtopicmodel_amd import synth
     from mvtopicmodel_amd.native import Hyper
     from oracle import doc_topics as dto
@@ -455,7 +456,7 @@ def test_inferencer_entry_matches_the_oracle_sequence():
 
 
 def test_estimate_with_live_updates_keeps_the_counts_consistent():
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from hostmirror.binding import FastQMVWVParallelTopicModel
     from mvtopicmodel_amd import synth
     K, V = 20, [300, 40, 50]
     c = synth.generate(K, V, 120, [30, 4, 6], seed=91, chunk_docs=4096)

@@ -123,15 +123,17 @@ def test_segmented_sweep_activates_a_topic_at_every_segment_border():
 
 def oracle_overlapped_sweep(o, c, it, seed, nseg):
     """MVHDP_SWEEP_SEGMENT_OVERLAP: the updater runs beside the samplers -- the deltas of segment s are applied while segment s+1
-    is sampled, so segment s samples against the counts after segment s-2 (segments 0 and 1: the sweep-start counts)."""
-    from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY
+    is sampled, so segment s samples against the counts after segment s-2 (segments 0 and 1: the sweep-start counts); the F+trees are
+    those of the sweep start for every segment (PTM:1209: built in buildFTrees, not per delta)."""
+    from oracle.binding import SWEEP_NO_APPLY as ORC_NO_APPLY, SWEEP_REUSE_TREES as ORC_REUSE_TREES
     stats = dict(tokens=0, changed=0, new_mass_cnt=0, topic_doc_mass_cnt=0, word_ftree_mass_cnt=0)
     pending = []
+    o.build_trees()
     for sidx, docs in enumerate(segment_lists(c, nseg)):
         if sidx >= 2:
             r0 = pending.pop(0)
             o.apply_delta(r0["delta_nwk"], r0["delta_nk"], -1, -1)
-        r = o.sweep_list(it, seed, docs, flags=ORC_NO_APPLY, want_delta=True)
+        r = o.sweep_list(it, seed, docs, flags=ORC_NO_APPLY | ORC_REUSE_TREES, want_delta=True)
         pending.append(r)
         for k in stats:
             stats[k] += r["stats"][k]

@@ -155,7 +155,7 @@ def test_doc_topic_proportions_and_print_document_topics(tmp_path):
     """printDocumentTopics PTM:2820-2960 (text half): device proportions bit-exact against the numpy restatement, and the
     host mirror's text -- descending weight, ties by descending topic id (IDSorter.compareTo), cut at threshold/max, the growing line printed once per
     retained topic -- against the same text assembled in Python."""
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel, java_double_to_string
+    from hostmirror.binding import FastQMVWVParallelTopicModel, java_double_to_string
     from mvtopicmodel_amd import synth
     from oracle import doc_topics as dto
     K, V = 12, [150, 30]

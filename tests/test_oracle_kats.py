@@ -352,3 +352,24 @@ def test_kat8_view_weights_from_the_mallet_stream_independent_restatement():
         assert np.array_equal(got, want), (pa, clamp)
         if clamp:
             assert np.all(got[:, 2, 2] == 0) and np.all(got[:, 0, 2] == 0) and np.any(got[:, 2, 0] > 0)
+
+
+def test_numpy_java_random_init_equals_the_host_mirror_and_the_jdk_known_answers():
+    """mvtopicmodel_amd/java_init.py (what bench.py, the tools and the full-size tests draw the initial assignments with) against the
+    documented java.util.Random answers and against the C++ restatement inside the host mirror, which does it draw by draw:
+    bounds that are powers of two, bounds that are not, entities without a text view, and a bound large enough for the rejection
+    loop of nextInt to run thousands of times."""
+    from mvtopicmodel_amd import java_init
+    from hostmirror.binding import init_assignments as ref
+    assert java_init.java_next_ints(42, np.full(5, 10)).tolist() == [0, 3, 8, 4, 0]
+    rng = np.random.default_rng(0)
+    for K in (7, 64, 400):
+        D = 1500
+        lens = [rng.integers(0, 40, D), rng.integers(0, 5, D), rng.integers(0, 9, D)]
+        lens[0][::5] = 0
+        offs = [np.concatenate([[0], np.cumsum(l)]).astype(np.int64) for l in lens]
+        for a, b in zip(ref(K, offs, seed=1), java_init.init_assignments(K, offs, 1)):
+            assert np.array_equal(a, b)
+    off = [np.array([0, 200000], dtype=np.int64)]
+    big = (1 << 30) + 12345
+    assert np.array_equal(ref(big, off, 5)[0], java_init.init_assignments(big, off, 5)[0])

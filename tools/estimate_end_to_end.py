@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--device-gamma", action="store_true", help="optimizeGamma's per-entity sums on the device")
     args = ap.parse_args()
     from mvtopicmodel_amd import synth
-    from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+    from hostmirror.binding import FastQMVWVParallelTopicModel
     cfg = synth.CONFIGS[args.workload]
     K, V = cfg["K"], cfg["V"]
     M = len(V)

@@ -2,7 +2,7 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np
 from mvtopicmodel_amd import NativeSampler, synth
-from mvtopicmodel_amd.host import init_assignments
+from mvtopicmodel_amd.java_init import init_assignments
 from mvtopicmodel_amd.native import Hyper
 for V in ([50000, 5000, 5000], [5000, 500, 500], [500, 50, 50]):
     K, D = 400, 300000

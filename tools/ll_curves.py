@@ -46,7 +46,7 @@ def run_cpu(args):
     if K_init == c.K:
         o.init_assignments(1)
     else:
-        from mvtopicmodel_amd.host import init_assignments
+        from mvtopicmodel_amd.java_init import init_assignments
         z0 = init_assignments(K_init, c.doc_off, seed=1)
         for m in range(c.M):
             o.set_assignments(m, z0[m])
@@ -71,8 +71,8 @@ def run_cpu(args):
 
 def run_gpu(args):
     from mvtopicmodel_amd import NativeSampler
-    from mvtopicmodel_amd.host import init_assignments
-    from mvtopicmodel_amd.native import SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
+    from mvtopicmodel_amd.java_init import init_assignments
+    from mvtopicmodel_amd.native import SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_REUSE_TREES, SWEEP_SEGMENT_APPLY, SWEEP_SEGMENT_OVERLAP
     c, hy, K_init = load(args.workload, args.docs)
     z0 = init_assignments(K_init, c.doc_off, seed=1)
     ntok = np.array([int(c.doc_off[m][-1]) for m in range(c.M)], dtype=np.float64)
@@ -82,6 +82,11 @@ def run_gpu(args):
         modes.append((f"gpu live, {n} tree rebuild(s) per sweep", SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(n)))
     for n in args.segmented:
         modes.append((f"gpu deferred in {n} segments, applied in between", SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(n)))
+    for n in args.overlapped:
+        modes.append((f"gpu deferred in {n} overlapped segments (counts two segments behind, trees of the sweep start)",
+                      SWEEP_SEGMENT_APPLY | SWEEP_SEGMENT_OVERLAP | SWEEP_LIVE_SEGMENTS(n)))
+    for n in args.live_trees_once:
+        modes.append((f"gpu live, {n} segments, trees once per sweep", SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(n) | SWEEP_REUSE_TREES))
     if args.only:
         modes = [mo for mo in modes if any(o in mo[0] for o in args.only)]
     # every mode, for every pinned live16 setting and every seed asked for (several seeds of one mode = the noise band of a chain)
@@ -108,6 +113,8 @@ def run_gpu(args):
             curve = [{"sweep": 0, "ll_per_token": (s.model_log_likelihood() / ntok).tolist()}]
             ms = 0.0
             for it in range(1, args.sweeps + 1):
+                if flags & SWEEP_REUSE_TREES:
+                    s.build_trees()
                 st = s.sweep(it, seed, flags=flags)
                 ms += st.total_ms
                 if it % args.every == 0 or it == args.sweeps:
@@ -186,6 +193,8 @@ def main():
         else:
             p.add_argument("--live-segments", type=int, nargs="*", default=[1, 4, 16])
             p.add_argument("--segmented", type=int, nargs="*", default=[], help="also run SEGMENT_APPLY sweeps with these segment counts")
+            p.add_argument("--overlapped", type=int, nargs="*", default=[], help="also run SEGMENT_APPLY | SEGMENT_OVERLAP sweeps with these segment counts")
+            p.add_argument("--live-trees-once", type=int, nargs="*", default=[], help="also run live sweeps of n segments whose trees are built once per sweep")
             p.add_argument("--only", nargs="*", default=[], help="keep only the modes whose name contains one of these strings")
             p.add_argument("--live16", type=int, nargs="*", default=[], help="pin mvhdp_tuning.live16 (1: live sweeps keep the light n_wk rows in the 16-bit mirror); several values = one run each")
             p.add_argument("--seeds", type=int, nargs="*", default=[], help="one run per seed of every mode (the noise band of a chain)")

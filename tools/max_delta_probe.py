@@ -2,7 +2,7 @@ import sys; sys.path.insert(0,'.')
 import numpy as np, torch
 from mvtopicmodel_amd import NativeSampler, synth
 from mvtopicmodel_amd.dist import GpuShard
-from mvtopicmodel_amd.host import init_assignments
+from mvtopicmodel_amd.java_init import init_assignments
 from mvtopicmodel_amd.native import Hyper
 N=int(sys.argv[1]); name=sys.argv[2] if len(sys.argv)>2 else "C4"
 cfg=synth.CONFIGS[name]; K,V=cfg["K"],cfg["V"]; M=len(V)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel / total ms per sweep of one chain in the three update modes, for A/B runs of two library builds on one box.
 
-  python tools/mode_times.py --workload C4 --mode seg8 --sweeps 40        (mode: deferred | live4 | live1 | seg8 | seg4)
+  python tools/mode_times.py --workload C4 --mode seg8 --sweeps 40        (mode: deferred | live4 | live1 | seg8 | seg4 | oseg8: overlapped segments)
 """
 import argparse
 import json
@@ -18,13 +18,20 @@ def main():
     ap.add_argument("--sweeps", type=int, default=40)
     a = ap.parse_args()
     from mvtopicmodel_amd import NativeSampler, synth
-    from mvtopicmodel_amd.host import init_assignments
-    from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
+    from mvtopicmodel_amd.java_init import init_assignments
+    from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY, SWEEP_SEGMENT_OVERLAP
     flags = 0
-    if a.mode.startswith("live"):
+    reuse = False
+    if a.mode.startswith("liveR"):
+        from mvtopicmodel_amd.native import SWEEP_REUSE_TREES
+        flags = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(int(a.mode[5:])) | SWEEP_REUSE_TREES
+        reuse = True
+    elif a.mode.startswith("live"):
         flags = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(int(a.mode[4:]))
     elif a.mode.startswith("seg"):
         flags = SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(int(a.mode[3:]))
+    elif a.mode.startswith("oseg"):
+        flags = SWEEP_SEGMENT_APPLY | SWEEP_SEGMENT_OVERLAP | SWEEP_LIVE_SEGMENTS(int(a.mode[4:]))
     c = synth.make_config(a.workload)
     inactive, K_init = synth.config_inactive(a.workload)
     z0 = init_assignments(K_init, c.doc_off, seed=1)
@@ -34,8 +41,12 @@ def main():
     s.set_hyper(Hyper.defaults(c.K, c.V, inactive=inactive)); s.build_counts()
     ks, ts = [], []
     for it in range(a.sweeps):
+        extra = 0.0
+        if reuse:                                   # the trees of the whole sweep, built by the host's call (timed with the sweep)
+            import time
+            t0 = time.perf_counter(); s.build_trees(); extra = (time.perf_counter() - t0) * 1e3
         st = s.sweep(it, 20260101, flags=flags)
-        ks.append(round(st.sweep_kernel_ms, 3)); ts.append(round(st.total_ms, 3))
+        ks.append(round(st.sweep_kernel_ms, 3)); ts.append(round(st.total_ms + extra, 3))
     h = len(ts) // 2
     print(json.dumps({"workload": a.workload, "mode": a.mode, "total_ms_sweeps_5_24": round(sum(ts[5:25]) / 20, 3),
                       "total_ms_last_half": round(sum(ts[h:]) / (len(ts) - h), 3), "total_ms": ts, "kernel_ms": ks}))

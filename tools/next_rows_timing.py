@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     from mvtopicmodel_amd import NativeSampler, synth
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     from mvtopicmodel_amd.native import Hyper, SWEEP_FROZEN
     name = sys.argv[1] if len(sys.argv) > 1 else "C4"
     cfg = synth.CONFIGS[name]

@@ -2,7 +2,7 @@ import sys, time, json
 sys.path.insert(0, '.')
 import numpy as np
 from mvtopicmodel_amd import synth
-from mvtopicmodel_amd.host import FastQMVWVParallelTopicModel
+from hostmirror.binding import FastQMVWVParallelTopicModel
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 cfg = synth.CONFIGS[name]; K, V = cfg["K"], cfg["V"]; M = len(V)
 c = synth.make_config(name)

@@ -22,7 +22,7 @@ def exact(args):
     import torch
     from mvtopicmodel_amd import NativeSampler, synth
     from mvtopicmodel_amd.dist import PIPELINE_CHUNKS, GpuShard
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     from mvtopicmodel_amd.native import Hyper, SWEEP_REUSE_TREES
     cfg = synth.CONFIGS[args.workload]
     K, V = cfg["K"], cfg["V"]
@@ -70,12 +70,15 @@ def exact(args):
         for g in shards:
             g.delta.copy_(total)
         torch.cuda.synchronize()
+        # UPD:263-270 across the shards: the first activating delta in (entity, view, position) order wins on every replica
+        from mvtopicmodel_amd.dist import decode_activation
+        topic, view = decode_activation(min(int(st.activation_key) for st in sts))
         for r, g in enumerate(shards):
             t0 = time.perf_counter()
             g.s.apply_delta_begin()
             for r0, r1 in chunks:
                 g.s.apply_delta_rows(r0, r1)
-            g.s.apply_delta_end(-1, -1)
+            g.s.apply_delta_end(topic, view)
             if r == 0 and it >= args.warmup:
                 ph["apply_and_trees_host"] += (time.perf_counter() - t0) * 1e3
     out = {k: v / args.steps for k, v in ph.items()}
@@ -102,7 +105,7 @@ def main():
     import torch
     from mvtopicmodel_amd import NativeSampler, synth
     from mvtopicmodel_amd.dist import GpuShard
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     from mvtopicmodel_amd.native import Hyper, SWEEP_LIVE
 
     if args.exact:

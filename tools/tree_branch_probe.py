@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     from mvtopicmodel_amd import NativeSampler, synth
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     from mvtopicmodel_amd.native import Hyper
     c = synth.make_config(a.workload, D=a.docs)
     inactive, K_init = synth.config_inactive(a.workload)

@@ -23,7 +23,7 @@ def main():
                     help="each one a threshold for view 0 (other views 0) or a comma list per view, or 'auto'")
     a = ap.parse_args()
     from mvtopicmodel_amd import NativeSampler, synth
-    from mvtopicmodel_amd.host import init_assignments
+    from mvtopicmodel_amd.java_init import init_assignments
     from mvtopicmodel_amd.native import Hyper
     c = synth.make_config(a.workload, D=a.docs)
     inactive, K_init = synth.config_inactive(a.workload)
