@@ -65,6 +65,19 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
     return physical, issue
 
 
+def sweep_equivalents(K):
+    """GPU sweeps per sweep of the CPU restatement of the reference (view 0, CPU sweeps 5..100), by update mode; profiles/r04_ll_curves.md."""
+    if K >= 256:
+        return {"source": "profiles/r04_ll_curves.md, section C4 (200k-entity slice, K = 400): profiles/r04_ll_cpu_c4_200k.json against "
+                          "r04_ll_gpu_c4_200k_live16_vs_live32.json (two seeds) and r04_ll_gpu_c4_200k_modes.json",
+                "gpu_sweeps_per_reference_sweep": {"deferred": [1.5, 3.2], "live": [0.98, 1.18], "live_8_segments": [0.93, 1.03], "segmented": [1.02, 1.12]},
+                "note": "deferred: not reached within 120 sweeps beyond CPU sweep 40; live = the library's default of 4 segments"}
+    return {"source": "profiles/r04_ll_curves.md, section C3 (K = 200): profiles/r02_ll_cpu.json against r04_ll_gpu_c3_live16_vs_live32.json "
+                      "(two seeds) and r04_ll_gpu_c3_modes.json",
+            "gpu_sweeps_per_reference_sweep": {"deferred": [1.4, 2.3], "live": [0.92, 1.05], "live_8_segments": [0.92, 1.0], "segmented": [0.94, 1.07]},
+            "note": "deferred: not reached within 100 sweeps beyond CPU sweep 45; live = the library's default of 4 segments"}
+
+
 def algorithmic_bytes_per_token(K):
     """one int32 n_wk row + token id + old assignment."""
     return 4 * K + 8
@@ -357,18 +370,18 @@ def main():
         "exchange": exchange,
         "update_mode": ("live, %d tree rebuilds per sweep" % (args.live_segments or 4)) if args.live else "deferred (snapshot sweep, bit-reproducible)",
         "step_calls": "one mvhdp_sweep_many call for the K steps" if (args.batch and world == 1) else "one call per step",
-        # What a sweep of each update mode is worth, in sweeps of the CPU restatement of the reference's thread topology, from the
-        # log-likelihood curves of profiles/r02_ll_curves.md (C3, same corpus / start / hyper-parameters): GPU sweeps needed to
-        # reach the log-likelihood the reference reaches in one.  Tokens/s of different modes are comparable only after dividing by it.
-        "reference_sweep_equivalent": {
-            "source": "profiles/r02_ll_curves.md",
-            "gpu_sweeps_per_reference_sweep": {"deferred": [1.4, 2.3], "live": [0.92, 1.0], "segmented": [0.94, 1.07]},
-        },
+        # What a sweep of each update mode is worth, in sweeps of the CPU restatement of the reference's thread topology: GPU sweeps
+        # needed to reach the log-likelihood the reference reaches in one, from the curves of the configuration that is timed -- the
+        # 200k-entity slice of C4 (K = 400: where live sweeps run on the 16-bit mirror) for K >= 256, C3 (K = 200) below; two seeds per
+        # live form (profiles/r04_ll_curves.md).  Tokens/s of different modes are comparable only after dividing by it.
+        "reference_sweep_equivalent": sweep_equivalents(K),
     }
     # order-independent fingerprint of the final global counts: must not depend on the number of shards
     nk_fp = [int(np.asarray(s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]
     out["final_nk_fingerprint"] = nk_fp
-    out["value_in_reference_sweeps"] = {"deferred": [value / 2.3, value / 1.4]} if not args.live else {"live": [value / 1.0, value / 0.92]}
+    eq = out["reference_sweep_equivalent"]["gpu_sweeps_per_reference_sweep"]
+    main_mode = "live" if args.live else "deferred"
+    out["value_in_reference_sweeps"] = {main_mode: [value / eq[main_mode][1], value / eq[main_mode][0]]}
     if args.live_steps is None:
         args.live_steps = 10 if world == 1 else 0
     sec_warm = 3                                    # warm-up sweeps of a secondary mode (its kernels' flavours and thresholds settle)
@@ -393,9 +406,9 @@ def main():
             v = total_tokens * args.live_steps / dl
             out["live"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm,
                            "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
-                           "note": "MVHDP_SWEEP_LIVE, timed after the K deferred steps; sweep for sweep equal to the CPU reference "
-                                   "(profiles/r02_ll_curves.md), not bit-reproducible"}
-            out["value_in_reference_sweeps"]["live"] = [v / 1.0, v / 0.92]
+                           "note": "MVHDP_SWEEP_LIVE (on the 16-bit mirror where K >= 256, segments overlapped), timed after the K deferred "
+                                   "steps; not bit-reproducible; what a sweep of it is worth: reference_sweep_equivalent"}
+            out["value_in_reference_sweeps"]["live"] = [v / eq["live"][1], v / eq["live"][0]]
         except Exception as e:                      # the secondary measurement must never cost the primary one
             out["live"] = {"error": repr(e)}
     if world == 1 and not args.live and args.live_steps > 0:
@@ -409,7 +422,7 @@ def main():
                                 "ms_per_step": dsg / args.live_steps * 1e3, "segments": 8,
                                 "note": "MVHDP_SWEEP_SEGMENT_APPLY: deferred sweep in 8 segments, deltas applied and trees rebuilt in "
                                         "between; deterministic (oracle-checked), about one reference sweep per sweep"}
-            out["value_in_reference_sweeps"]["segmented"] = [v / 1.07, v / 0.94]
+            out["value_in_reference_sweeps"]["segmented"] = [v / eq["segmented"][1], v / eq["segmented"][0]]
         except Exception as e:
             out["segmented"] = {"error": repr(e)}
     if group is not None:

@@ -363,6 +363,15 @@ int mvhdp_group_build_counts(mvhdp_group g);
  * (the failing rank its own, the others MVHDP_ERR_STATE) and none waits inside a collective for a rank that has given up.  After such
  * an error call mvhdp_group_build_counts on every rank (a recount from the assignments) before the next sweep. */
 int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats);
+/* The collective off the critical path, for LIVE sweeps of a group (opt-in).  A live sweep across shards is AD-LDA already: a replica
+ * is live for its own entities and stale for the others'.  With this flag sweep t keeps its own changes in place, puts its deltas on
+ * the wire at once -- the all-reduce runs on a stream of its own BESIDE sweep t+1 -- and the other shards' share of them is added when
+ * sweep t+1 has been sampled: the step costs max(sampling, collective) instead of their sum, the chain sees the other shards' tokens
+ * one to two sweeps late instead of zero to one.  Between such sweeps the replicas differ (each lacks the others' last sweep):
+ * mvhdp_group_drain lands what is in flight and makes every replica the global model (the group's statistics, build_counts and any
+ * sweep without the flag drain by themselves).  A failure shows one sweep late, on every rank together.  Not with inactive topics. */
+#define MVHDP_SWEEP_ASYNC_EXCHANGE 0x100u
+int mvhdp_group_drain(mvhdp_group g);
 /* A host whose rank cannot go on calls this before its next mvhdp_group_sweep: that sweep samples nothing here and fails on every rank
  * together (see above) instead of leaving the others inside an all-reduce. */
 int mvhdp_group_abort(mvhdp_group g);

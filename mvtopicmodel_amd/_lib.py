@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "mvhdp_trees_current", "mvhdp_get_view_weights",
     "mvhdp_device_buffer", "mvhdp_counts_written", "mvhdp_set_stream", "mvhdp_synchronize",
     "mvhdp_group_create", "mvhdp_group_unique_id", "mvhdp_group_create_rank", "mvhdp_group_destroy", "mvhdp_group_last_error",
-    "mvhdp_group_get_info", "mvhdp_group_set_exchange_chunks", "mvhdp_group_build_counts", "mvhdp_group_sweep", "mvhdp_group_abort",
+    "mvhdp_group_get_info", "mvhdp_group_set_exchange_chunks", "mvhdp_group_build_counts", "mvhdp_group_sweep", "mvhdp_group_abort", "mvhdp_group_drain",
     "mvhdp_group_set_hyper", "mvhdp_group_log_likelihood", "mvhdp_group_doc_topic_hist", "mvhdp_group_count_histogram",
     "mvhdp_group_view_overlap_sums", "mvhdp_group_gamma_doc_statistics",
 ]
@@ -229,6 +229,7 @@ def load_library():
     L.mvhdp_group_build_counts.argtypes = [vp]
     L.mvhdp_group_sweep.argtypes = [vp, u32, u64, u32, vp]
     L.mvhdp_group_abort.argtypes = [vp]
+    L.mvhdp_group_drain.argtypes = [vp]
     L.mvhdp_group_set_hyper.argtypes = [vp, C.POINTER(HyperC)]
     L.mvhdp_group_log_likelihood.argtypes = [vp, vp]
     L.mvhdp_group_doc_topic_hist.argtypes = [vp, i32, vp, i32, vp, i32]

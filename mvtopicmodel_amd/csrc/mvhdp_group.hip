@@ -87,6 +87,13 @@ hipError_t launch_add_into(int32_t* dst, const int32_t* src, int64_t n, hipStrea
 
 __global__ void set_word_kernel(int32_t* p, int32_t v) { *p = v; }
 
+// counts += sum - own  (the other shards' share of an exchanged delta buffer)
+__global__ __launch_bounds__(256) void add_remote_kernel(int32_t* __restrict__ counts, const int32_t* __restrict__ sum, const int32_t* __restrict__ own, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const int d = sum[i] - own[i]; if (d) counts[i] += d; }
+}
+
 // the caller's current device, put back when a group call returns (a group call visits the devices of all its members)
 struct DeviceGuard {
     int prev = -1;
@@ -112,6 +119,11 @@ struct mvhdp_group_ctx {
     int chunks = 4;                           // row ranges of one exchange: the apply + tree rebuild of range i runs while range i+1 is on the wire
     double last_exchange_ms = 0.0;
     long long sweeps = 0;
+    // MVHDP_SWEEP_ASYNC_EXCHANGE (live sweeps): the all-reduce of sweep t's deltas runs beside sweep t+1 on a stream of its own
+    std::vector<int32_t*> xbuf, sbuf;         // per member: the deltas on the wire (summed in place) and this member's own share of them
+    std::vector<hipStream_t> comm;            // per leader: the stream of the collective
+    std::vector<hipEvent_t> ev_xfer;          // per leader: the sum has arrived (and been handed to the co-located members)
+    bool async_pending = false;               // an exchange is in flight: the replicas lack each other's last sweep
     bool abort_raised = false;                // mvhdp_group_abort: the next sweep of this rank contributes nothing and fails on every rank
     std::vector<int> by_entity;               // member indices by ascending doc_id_base: the order of the "in entity order" statistics
     std::string err;
@@ -211,6 +223,11 @@ static void group_release(mvhdp_group_ctx* g)
     for (size_t i = 0; i < g->ev_swept.size(); i++) if (g->ev_swept[i]) hipEventDestroy(g->ev_swept[i]);
     for (size_t l = 0; l < g->ev_reduced.size(); l++) if (g->ev_reduced[l]) hipEventDestroy(g->ev_reduced[l]);
     for (size_t l = 0; l < g->d_key.size(); l++) if (g->d_key[l]) hipFree(g->d_key[l]);
+    for (int32_t* b : g->xbuf) if (b) hipFree(b);
+    for (int32_t* b : g->sbuf) if (b) hipFree(b);
+    for (hipStream_t st : g->comm) if (st) hipStreamDestroy(st);
+    for (hipEvent_t ev : g->ev_xfer) if (ev) hipEventDestroy(ev);
+    g->xbuf.clear(); g->sbuf.clear(); g->comm.clear(); g->ev_xfer.clear();
     if (g->ev_x0) hipEventDestroy(g->ev_x0);
     if (g->ev_x1) hipEventDestroy(g->ev_x1);
 }
@@ -390,6 +407,10 @@ extern "C" int mvhdp_group_build_counts(mvhdp_group g)
 {
     CHECK_G(g);
     DeviceGuard dg;
+    if (g->async_pending) {                               // (what is on the wire is dropped: the recount below starts from the assignments)
+        for (size_t l = 0; l < g->leaders.size(); l++) { hipSetDevice(g->members[g->leaders[l]]->device); hipStreamSynchronize(g->comm[l]); }
+        g->async_pending = false;
+    }
     const int n = (int)g->members.size();
     for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_build_counts(g->members[i]));
     for (int i = 0; i < n; i++) { GHIP(g, hipSetDevice(g->members[i]->device)); GHIP(g, hipEventRecord(g->ev_swept[i], g->members[i]->stream)); }
@@ -532,6 +553,149 @@ static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uin
     return MVHDP_OK;
 }
 
+// ---- MVHDP_SWEEP_ASYNC_EXCHANGE: the collective off the critical path (live sweeps only) ----
+// A live sweep across shards is AD-LDA anyway: every replica is live for its own entities and stale for the others'.  Here the
+// other shards' deltas arrive one sweep later still: sweep t keeps its own changes in place, its deltas go on the wire at once --
+// on a stream of their own, beside sweep t+1 -- and are added to the replica when sweep t+1 has been sampled.  The step is then
+// max(sampling, collective) instead of their sum; the chain sees the other shards' tokens one to two sweeps late instead of zero
+// to one (measured from members on one device: profiles/r04_ll_curves.md).  mvhdp_group_drain waits for what is in flight and makes
+// every replica the global model again; the statistics and mvhdp_group_build_counts drain by themselves.
+static int async_buffers(mvhdp_group_ctx* g)
+{
+    if (!g->xbuf.empty()) return MVHDP_OK;
+    const size_t bytes = (size_t)(counts_len_of(g->members[0]) + MVHDP_TAIL_WORDS) * sizeof(int32_t);
+    for (mvhdp_ctx* h : g->members) {
+        int32_t *x = nullptr, *o = nullptr;
+        GHIP(g, hipSetDevice(h->device));
+        GHIP(g, hipMalloc(&x, bytes)); g->xbuf.push_back(x);
+        GHIP(g, hipMalloc(&o, bytes)); g->sbuf.push_back(o);
+        GHIP(g, hipMemset(x, 0, bytes)); GHIP(g, hipMemset(o, 0, bytes));
+    }
+    for (int l : g->leaders) {
+        hipStream_t st; hipEvent_t ev;
+        GHIP(g, hipSetDevice(g->members[l]->device));
+        GHIP(g, hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); g->comm.push_back(st);
+        GHIP(g, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); g->ev_xfer.push_back(ev);
+    }
+    return MVHDP_OK;
+}
+
+// what is in flight lands: every member adds the other shards' share of the exchanged deltas; *failed: ranks whose sweep had failed
+static int async_land(mvhdp_group_ctx* g, int32_t* failed)
+{
+    *failed = 0;
+    if (!g->async_pending) return MVHDP_OK;
+    const int64_t len = counts_len_of(g->members[0]);
+    for (size_t i = 0; i < g->members.size(); i++) {
+        mvhdp_ctx* h = g->members[i];
+        size_t l = 0; while (g->leaders[l] != g->leader_of[i]) l++;
+        GHIP(g, hipSetDevice(h->device));
+        GHIP(g, hipStreamWaitEvent(h->stream, g->ev_xfer[l], 0));
+        const int grid = (int)std::min<int64_t>((len + 255) / 256, 8192);
+        hipLaunchKernelGGL(add_remote_kernel, dim3(grid), dim3(256), 0, h->stream, h->mm.counts, g->xbuf[i], g->sbuf[i], len);
+        GHIP(g, hipGetLastError());
+        h->have_trees = false;
+    }
+    mvhdp_ctx* L0 = g->members[g->leaders[0]];
+    GHIP(g, hipSetDevice(L0->device));
+    GHIP(g, hipMemcpyAsync(failed, g->xbuf[g->leaders[0]] + len, sizeof(int32_t), hipMemcpyDeviceToHost, L0->stream));
+    for (mvhdp_ctx* h : g->members) { GHIP(g, hipSetDevice(h->device)); GHIP(g, hipStreamSynchronize(h->stream)); }
+    g->async_pending = false;
+    return MVHDP_OK;
+}
+
+extern "C" int mvhdp_group_drain(mvhdp_group g)
+{
+    CHECK_G(g);
+    DeviceGuard dg;
+    int32_t failed = 0;
+    int rc = async_land(g, &failed); if (rc) return rc;
+    if (failed > 0) {
+        for (mvhdp_ctx* h : g->members) h->counts_stale = true;
+        GFAIL(g, MVHDP_ERR_STATE, "a sweep whose deltas were still on the wire had failed on " + std::to_string(failed) + " rank(s): call mvhdp_group_build_counts on every rank");
+    }
+    return MVHDP_OK;
+}
+
+static int group_step_async(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, std::vector<mvhdp_sweep_stats>& st)
+{
+    const int n = (int)g->members.size();
+    if (g->members[0]->mm.first_inactive >= 0) GFAIL(g, MVHDP_ERR_UNSUPPORTED, "group_sweep: ASYNC_EXCHANGE with inactive topics (their activation has to be agreed on before the next sweep)");
+    int rc = async_buffers(g); if (rc) return rc;
+    const int64_t len = counts_len_of(g->members[0]);
+    const size_t bytes = (size_t)len * sizeof(int32_t);
+    std::vector<PendingSweep> ps((size_t)n);
+    int local_err = MVHDP_OK;
+    auto note = [&](int r, const std::string& what) { if (r != MVHDP_OK && local_err == MVHDP_OK) { local_err = r; g->err = what; } };
+    if (g->abort_raised) { note(MVHDP_ERR_STATE, "the host raised mvhdp_group_abort on this rank"); g->abort_raised = false; }
+    // 1. this sweep, live on every member's own replica (which lacks the other shards' previous sweep: still on the wire)
+    for (int i = 0; i < n && local_err == MVHDP_OK; i++) {
+        const int r = mvhdp_sweep_begin(g->members[i], sweep_idx, seed, (flags & ~MVHDP_SWEEP_ASYNC_EXCHANGE) | MVHDP_SWEEP_NO_APPLY, nullptr, nullptr, ps[i]);
+        if (r != MVHDP_OK) note(r, "member " + std::to_string(i) + ": " + g->members[i]->err);
+    }
+    for (int i = 0; i < n; i++) {
+        if (!ps[i].open) continue;
+        const int r = mvhdp_sweep_finish(g->members[i], ps[i], &st[i]);
+        if (r != MVHDP_OK) note(r, "member " + std::to_string(i) + ": " + g->members[i]->err);
+    }
+    // 2. the previous sweep's exchange has had this sweep's time: it lands now (counts were restored to the sweep-start snapshot by
+    //    the NO_APPLY form: first this sweep's own deltas go back in, then the other shards' share of the previous one)
+    for (int i = 0; i < n; i++) {
+        mvhdp_ctx* h = g->members[i];
+        if (local_err != MVHDP_OK) { hipSetDevice(h->device); hipMemsetAsync(h->mm.delta, 0, bytes, h->stream); h->counts_stale = true; }
+        else { hipSetDevice(h->device); launch_add_into(h->mm.counts, h->mm.delta, len, h->stream); }
+    }
+    int32_t failed = 0;
+    rc = async_land(g, &failed); if (rc) return rc;
+    // 3. this sweep's deltas go on the wire (a copy: the delta buffer is the next sweep's), the collective on its own stream
+    for (int i = 0; i < n; i++) {
+        mvhdp_ctx* h = g->members[i];
+        GHIP(g, hipSetDevice(h->device));
+        GHIP(g, hipMemcpyAsync(g->xbuf[i], h->mm.delta, bytes, hipMemcpyDeviceToDevice, h->stream));
+        GHIP(g, hipMemcpyAsync(g->sbuf[i], h->mm.delta, bytes, hipMemcpyDeviceToDevice, h->stream));
+        GHIP(g, hipMemsetAsync(h->mm.delta, 0, bytes, h->stream));
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, h->stream, g->xbuf[i] + len, (g->leader_of[i] == i && local_err != MVHDP_OK) ? 1 : 0);
+        GHIP(g, hipEventRecord(g->ev_swept[i], h->stream));
+        h->delta_pending = false; h->delta_clean = true; h->have_trees = false;
+    }
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        const int li = g->leaders[l];
+        mvhdp_ctx* L = g->members[li];
+        GHIP(g, hipSetDevice(L->device));
+        for (int i = 0; i < n; i++) {
+            if (g->leader_of[i] != li) continue;
+            GHIP(g, hipStreamWaitEvent(g->comm[l], g->ev_swept[i], 0));
+            if (i != li) GHIP(g, launch_add_into(g->xbuf[li], g->xbuf[i], len, g->comm[l]));
+        }
+    }
+    if (!g->comms.empty()) {
+        Rccl* r = &g_rccl;
+        if (g->comms.size() > 1) GNCCL(g, r->GroupStart());
+        for (size_t l = 0; l < g->leaders.size(); l++) {
+            mvhdp_ctx* L = g->members[g->leaders[l]];
+            GHIP(g, hipSetDevice(L->device));
+            int32_t* buf = g->xbuf[g->leaders[l]];
+            GNCCL(g, r->AllReduce(buf, buf, (size_t)(len + 1), ncclInt32, ncclSum, g->comms[l], g->comm[l]));
+        }
+        if (g->comms.size() > 1) GNCCL(g, r->GroupEnd());
+    }
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        const int li = g->leaders[l];
+        GHIP(g, hipSetDevice(g->members[li]->device));
+        for (int i = 0; i < n; i++)
+            if (g->leader_of[i] == li && i != li) GHIP(g, hipMemcpyAsync(g->xbuf[i], g->xbuf[li], (size_t)(len + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, g->comm[l]));
+        GHIP(g, hipEventRecord(g->ev_xfer[l], g->comm[l]));
+    }
+    g->async_pending = true;
+    for (int i = 0; i < n; i++) { st[i].activation_key = LLONG_MAX; st[i].activated_topic = -1; st[i].activated_modality = -1; st[i].activations = 0; }
+    if (local_err != MVHDP_OK) return local_err;
+    if (failed > 0) {
+        for (mvhdp_ctx* h : g->members) h->counts_stale = true;
+        GFAIL(g, MVHDP_ERR_STATE, "the previous sweep failed on " + std::to_string(failed) + " other rank(s) of the group: call mvhdp_group_build_counts on every rank");
+    }
+    return MVHDP_OK;
+}
+
 // A host whose rank cannot go on (an exception outside the library, a signal it handles) calls this BEFORE its next mvhdp_group_sweep:
 // that sweep then samples nothing here, enters the collectives with zero deltas and fails on every rank together -- nobody is left
 // waiting inside an all-reduce for a rank that will never arrive.
@@ -553,15 +717,19 @@ extern "C" int mvhdp_group_abort(mvhdp_group g)
 extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, mvhdp_sweep_stats* stats)
 {
     CHECK_G(g);
-    if (flags & (MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_FROZEN | 0xff000000u))
+    if (flags & (MVHDP_SWEEP_NO_APPLY | MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_FROZEN | MVHDP_SWEEP_SEGMENT_OVERLAP | 0xff000000u))
         GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: NO_APPLY, REUSE_TREES and ONLY_SEGMENT are set by the group itself; FROZEN is a single-handle mode");
     if ((flags & MVHDP_SWEEP_SEGMENT_APPLY) && (flags & MVHDP_SWEEP_LIVE)) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: SEGMENT_APPLY excludes LIVE");
+    if ((flags & MVHDP_SWEEP_ASYNC_EXCHANGE) && !(flags & MVHDP_SWEEP_LIVE)) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_sweep: ASYNC_EXCHANGE goes with LIVE (a deferred sweep is the parity contract: every replica must hold the global counts)");
     DeviceGuard dg;
     const int n = (int)g->members.size();
     std::vector<mvhdp_sweep_stats> total((size_t)n), st((size_t)n);
     g->last_exchange_ms = 0.0;
     int ret = MVHDP_OK;
-    if (flags & MVHDP_SWEEP_SEGMENT_APPLY) {
+    if (!(flags & MVHDP_SWEEP_ASYNC_EXCHANGE) && g->async_pending) { ret = mvhdp_group_drain(g); if (ret) return ret; }
+    if (flags & MVHDP_SWEEP_ASYNC_EXCHANGE) {
+        ret = group_step_async(g, sweep_idx, seed, flags, total);
+    } else if (flags & MVHDP_SWEEP_SEGMENT_APPLY) {
         int nseg = (int)((flags >> 16) & 0xffu);
         if (nseg == 0) nseg = 4;
         // (the segment count comes from the flags alone -- every rank issues the same number of exchanges; a member with fewer entities
@@ -661,6 +829,7 @@ extern "C" int mvhdp_group_log_likelihood(mvhdp_group g, double* out)
     CHECK_G(g);
     if (!out) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_log_likelihood: null");
     DeviceGuard dg;
+    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
     const int M = g->members[0]->mm.M;
     for (int m = 0; m < M; m++) {
         double ll = 0;
@@ -684,6 +853,7 @@ extern "C" int mvhdp_group_doc_topic_hist(mvhdp_group g, int32_t m, int32_t* his
 {
     CHECK_G(g);
     DeviceGuard dg;
+    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
     const int K = g->members[0]->mm.K;
     const size_t nh = hist ? (size_t)K * (size_t)std::max(hist_len, 0) : 0, nl = doc_len_counts ? (size_t)std::max(len_len, 0) : 0;
     std::vector<int32_t> th(nh), tl(nl);
@@ -703,6 +873,7 @@ extern "C" int mvhdp_group_count_histogram(mvhdp_group g, int32_t m, int32_t* hi
 {
     CHECK_G(g);
     DeviceGuard dg;
+    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
     GMEM(g, 0, mvhdp_get_count_histogram(g->members[0], m, hist, len));
     return MVHDP_OK;
 }
@@ -713,6 +884,7 @@ extern "C" int mvhdp_group_view_overlap_sums(mvhdp_group g, double* sums)
     CHECK_G(g);
     if (!sums) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_view_overlap_sums: null");
     DeviceGuard dg;
+    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
     const int M = g->members[0]->mm.M;
     for (int i = 0; i < M * M; i++) sums[i] = 0.0;
     for (int i : g->by_entity) GMEM(g, i, mvhdp_view_overlap_accumulate(g->members[i], sums));
@@ -731,6 +903,7 @@ extern "C" int mvhdp_group_gamma_doc_statistics(mvhdp_group g, int32_t m, double
     CHECK_G(g);
     if (!qs || !qw) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_gamma_doc_statistics: null");
     DeviceGuard dg;
+    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
     double a = 0, b = 0;
     for (int i : g->by_entity) {
         double x = 0, y = 0;

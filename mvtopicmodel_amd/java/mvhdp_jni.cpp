@@ -533,6 +533,14 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGammaDocStati
     env->SetDoubleArrayRegion(out, 0, 2, v);
 }
 
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupDrain(JNIEnv* env, jclass, jlong p)
+{
+    GroupPin gpin_(p); Group* gr = gpin_.s;
+    if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    int rc = mvhdp_group_drain(gr->g);
+    if (rc) throw_group(env, gr->g, rc, "mvhdp_group_drain");
+}
+
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupAbort(JNIEnv* env, jclass, jlong p)
 {
     GroupPin gpin_(p); Group* gr = gpin_.s;

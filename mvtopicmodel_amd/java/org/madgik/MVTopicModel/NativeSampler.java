@@ -22,6 +22,7 @@ public final class NativeSampler implements AutoCloseable {
     public static final int SWEEP_FROZEN = 0x10;       // the inferencer's call (nst = 1, nut = 0)
     public static final int SWEEP_LIVE = 0x20;         // the updater threads' own discipline: atomics on the shared counts
     public static final int SWEEP_SEGMENT_APPLY = 0x40; // deterministic: segments sampled one after the other, deltas applied in between
+    public static final int SWEEP_ASYNC_EXCHANGE = 0x100;  // Group.sweep with SWEEP_LIVE: the all-reduce of sweep t beside sweep t+1 (then Group.drain())
     public static final int SWEEP_SEGMENT_OVERLAP = 0x80; // with SEGMENT_APPLY: the deltas of segment s are applied while segment s+1 samples (s+2 sees them)
     public static int sweepLiveSegments(int n) { return (n & 0xff) << 16; }
     public static int sweepOnlySegment(int s) { return ((s + 1) & 0xff) << 24; }   // only segment s of the n segments
@@ -169,6 +170,9 @@ public final class NativeSampler implements AutoCloseable {
             return out;
         }
 
+        /** After SWEEP_ASYNC_EXCHANGE sweeps: lands what is on the wire, every replica is the global model again. */
+        public void drain() { nGroupDrain(g); }
+
         /** This rank cannot go on: its next sweep contributes nothing and fails on EVERY rank together (nobody waits in a collective). */
         public void abort() { nGroupAbort(g); }
 
@@ -223,6 +227,7 @@ public final class NativeSampler implements AutoCloseable {
     private static native void nViewOverlapSums(long h, double[] sums);
     private static native void nGammaDocStatistics(long h, int m, double gammaM, long seed, int round, double[] out);
     private static native void nGroupAbort(long g);
+    private static native void nGroupDrain(long g);
     private static native void nGroupModelLogLikelihood(long g, double[] out);
     private static native void nGroupGetDocTopicHist(long g, int m, int[] histFlat, int histLen, int[] docLengthCounts);
     private static native void nGroupGetCountHistogram(long g, int m, int[] hist);

@@ -21,6 +21,7 @@ SWEEP_FROZEN = 0x10
 SWEEP_LIVE = 0x20
 SWEEP_SEGMENT_APPLY = 0x40
 SWEEP_SEGMENT_OVERLAP = 0x80
+SWEEP_ASYNC_EXCHANGE = 0x100
 
 
 def SWEEP_LIVE_SEGMENTS(n):
@@ -438,6 +439,10 @@ class NativeGroup:
 
     def build_counts(self):
         self._ck(self.L.mvhdp_group_build_counts(self.g))
+
+    def drain(self):
+        """Lands the exchange a SWEEP_ASYNC_EXCHANGE sweep left on the wire: every replica is the global model again."""
+        self._ck(self.L.mvhdp_group_drain(self.g))
 
     def abort(self):
         """This rank cannot go on: its next sweep contributes nothing and fails on every rank together."""

@@ -324,3 +324,49 @@ def test_segmented_group_sweep_with_a_member_shorter_than_the_segment_count():
             _assert_group_equals_oracle(o, shards, c)
     for sh in shards:
         sh.close()
+
+
+def test_async_exchange_keeps_the_global_counts_after_a_drain():
+    """MVHDP_SWEEP_ASYNC_EXCHANGE: the all-reduce of a live sweep's deltas runs beside the next sweep.  Between sweeps the replicas
+    differ (each lacks the others' last sweep); after mvhdp_group_drain -- or by themselves, the group's statistics -- every replica
+    holds exactly the counts of the concatenated assignments.  A sweep without the flag drains first; a deferred sweep refuses it."""
+    from mvtopicmodel_amd.native import SWEEP_ASYNC_EXCHANGE
+    K, V = 40, [500, 60]
+    c = small_corpus(K, V, 160, [50, 6], 99)
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(2)]
+    shards = _shards(c, hy, z, 3)
+
+    def check_global():
+        for m in range(2):
+            zc = np.concatenate([s.get_assignments(m) for s in shards])
+            ref = np.zeros((V[m], K), dtype=np.int32); np.add.at(ref, (c.tokens[m], zc), 1)
+            for s in shards:
+                a, b = s.get_counts(m)
+                assert a.min() >= 0 and np.array_equal(a, ref) and np.array_equal(b, ref.sum(axis=0))
+
+    with NativeGroup(shards) as g:
+        g.build_counts()
+        fl = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2) | SWEEP_ASYNC_EXCHANGE
+        for it in range(4):
+            sts = g.sweep(it, 3, flags=fl)
+            assert sum(st.tokens for st in sts) == c.total_tokens
+        # in flight: the replicas differ from each other now (each has its own last sweep, not the others')
+        a0, a1 = shards[0].get_counts(0)[0], shards[1].get_counts(0)[0]
+        assert not np.array_equal(a0, a1)
+        g.drain()
+        check_global()
+        g.sweep(4, 3, flags=fl); g.sweep(5, 3, flags=fl)
+        ll = g.model_log_likelihood()                                       # drains by itself
+        check_global()
+        assert np.all(np.isfinite(ll))
+        g.sweep(6, 3, flags=fl)
+        g.sweep(7, 3, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2))            # a synchronous live sweep: drains first, exchanges at once
+        check_global()
+        g.sweep(8, 3)                                                       # and a deferred one
+        check_global()
+        with pytest.raises(MvhdpError):
+            g.sweep(9, 3, flags=SWEEP_ASYNC_EXCHANGE)                       # goes with LIVE only
+    for s in shards:
+        s.close()

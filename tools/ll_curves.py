@@ -126,6 +126,42 @@ def run_gpu(args):
     json.dump({"runs": runs, "workload": args.workload, "docs": c.D, "tokens": c.total_tokens}, open(args.out, "w"), indent=1)
 
 
+def run_group(args):
+    """LL curve of a live chain over N document shards on ONE device, synchronous exchange against MVHDP_SWEEP_ASYNC_EXCHANGE."""
+    from mvtopicmodel_amd import NativeGroup, NativeSampler, synth
+    from mvtopicmodel_amd.java_init import init_assignments
+    from mvtopicmodel_amd.native import SWEEP_ASYNC_EXCHANGE, SWEEP_LIVE, SWEEP_LIVE_SEGMENTS
+    c, hy, K_init = load(args.workload, args.docs)
+    z0 = init_assignments(K_init, c.doc_off, seed=1)
+    ntok = np.array([int(c.doc_off[m][-1]) for m in range(c.M)], dtype=np.float64)
+    tot = sum(np.diff(c.doc_off[m]) for m in range(c.M))
+    runs = {}
+    for asyn in (0, 1):
+        shards = []
+        for lo, hi in synth.shard_bounds(tot, args.shards):
+            sub = c.slice_docs(lo, hi)
+            s = NativeSampler(c.K, c.V, doc_id_base=lo)
+            for m in range(c.M):
+                s.set_corpus(m, sub.doc_off[m], sub.tokens[m]); s.set_assignments(m, z0[m][c.doc_off[m][lo]:c.doc_off[m][hi]])
+            s.set_hyper(hy); s.build_counts()
+            shards.append(s)
+        g = NativeGroup(shards)
+        g.build_counts()
+        flags = SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(args.segments) | (SWEEP_ASYNC_EXCHANGE if asyn else 0)
+        name = f"gpu live over {args.shards} shards, {args.segments} segments, " + ("exchange one sweep behind (ASYNC_EXCHANGE)" if asyn else "exchange after every sweep")
+        curve = [{"sweep": 0, "ll_per_token": (g.model_log_likelihood() / ntok).tolist()}]
+        for it in range(1, args.sweeps + 1):
+            g.sweep(it, args.seed, flags=flags)
+            if it % args.every == 0 or it == args.sweeps:
+                curve.append({"sweep": it, "ll_per_token": (g.model_log_likelihood() / ntok).tolist()})
+        print(f"{name}: final LL/token {curve[-1]['ll_per_token']}", flush=True)
+        runs[name] = curve
+        g.close()
+        for s in shards:
+            s.close()
+    json.dump({"runs": runs, "workload": args.workload, "docs": c.D, "tokens": c.total_tokens}, open(args.out, "w"), indent=1)
+
+
 def table(args):
     runs = {}
     meta = None
@@ -199,10 +235,15 @@ def main():
             p.add_argument("--live16", type=int, nargs="*", default=[], help="pin mvhdp_tuning.live16 (1: live sweeps keep the light n_wk rows in the 16-bit mirror); several values = one run each")
             p.add_argument("--seeds", type=int, nargs="*", default=[], help="one run per seed of every mode (the noise band of a chain)")
             p.add_argument("--tag", default="", help="appended to the run names (which library build this was)")
+    p = sub.add_parser("group")
+    p.add_argument("--workload", default="C3"); p.add_argument("--docs", type=int, default=200000)
+    p.add_argument("--sweeps", type=int, default=100); p.add_argument("--every", type=int, default=5)
+    p.add_argument("--seed", type=int, default=20260101); p.add_argument("--out", required=True)
+    p.add_argument("--shards", type=int, default=8); p.add_argument("--segments", type=int, default=4)
     p = sub.add_parser("table")
     p.add_argument("files", nargs="+")
     args = ap.parse_args()
-    {"cpu": run_cpu, "gpu": run_gpu, "table": table}[args.cmd](args)
+    {"cpu": run_cpu, "gpu": run_gpu, "group": run_group, "table": table}[args.cmd](args)
 
 
 if __name__ == "__main__":
