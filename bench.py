@@ -51,7 +51,7 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
     tok_s = tokens_per_launch / avg_kernel_s
     bpt = w["fabric_read_bytes_per_token"] + w["write_bytes_per_token"]
     gbs = tok_s * bpt / 1e9
-    ceil = prof.get("gather_ceiling_GBs")
+    ceil = prof.get("gather_ceiling_GBs") if prof.get("gather_ceiling_workload", workload) == workload else None   # (measured for C4's rows)
     physical = {"bytes_per_token": bpt, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                 "gather_ceiling": ceil, "frac_of_gather_ceiling": (gbs / ceil) if ceil else None,
                 "source": w.get("pmc_source"), "gather_ceiling_source": prof.get("gather_ceiling_source")}
@@ -337,8 +337,9 @@ def main():
                         "this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits included; PMC passes of "
                         "profiles/profile_r04.sh over the timed sweeps of this very command (a rocprofv3 run of its own, same build), the rate is this run's")
     binding = None
-    if physical and issue and physical.get("frac_of_gather_ceiling"):
-        binding = "issue (vector ALU)" if issue["frac"] >= physical["frac_of_gather_ceiling"] else "gather ceiling of the fabric"
+    if physical and issue:
+        fabric = physical.get("frac_of_gather_ceiling") or physical["frac"]
+        binding = "instruction issue (vector ALU)" if issue["frac"] >= fabric else "the fabric (gather of the count rows)"
     out = {
         "metric": "gibbs_tokens_per_sec", "value": value, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--optimize-interval", type=int, default=50)
     ap.add_argument("--live", action="store_true")
     ap.add_argument("--device-gamma", action="store_true", help="optimizeGamma's per-entity sums on the device")
+    ap.add_argument("--shards", type=int, default=1, help="keep the model as n document shards behind an mvhdp_group (all on this GPU)")
     args = ap.parse_args()
     from mvtopicmodel_amd import synth
     from hostmirror.binding import FastQMVWVParallelTopicModel
@@ -47,6 +48,7 @@ def main():
     model.setOptimizeInterval(args.optimize_interval); model.setRandomSeed(1)
     model.setLiveUpdates(args.live)
     model.setDeviceGammaStatistics(args.device_gamma)
+    model.setNumShards(args.shards)
     t0 = time.perf_counter()
     model.addInstances(training)
     t_add = time.perf_counter() - t0
@@ -61,7 +63,7 @@ def main():
     plain = ~opt & ~ll
     kern = np.array([x[1]["sweep_kernel_ms"] for x in log])
     out = {
-        "workload": args.workload, "entities": model.num_entities(), "tokens": c.total_tokens, "update_mode": "live" if args.live else "deferred", "optimizeGamma_document_sums": "device" if args.device_gamma else "host loop (reference)",
+        "workload": args.workload, "entities": model.num_entities(), "tokens": c.total_tokens, "update_mode": "live" if args.live else "deferred", "optimizeGamma_document_sums": "device" if args.device_gamma else "host loop (reference)", "shards": args.shards,
         "iterations": args.iterations, "burnin": args.burnin, "optimize_interval": args.optimize_interval,
         "addInstances_s": round(t_add, 3), "estimate_s": round(t_est, 3),
         "ms_per_plain_iteration_median": round(float(np.median(ms[plain])), 3),
