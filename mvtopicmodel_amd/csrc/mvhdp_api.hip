@@ -48,6 +48,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_FORCE_RMAX")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) h->tu.force_primary = v; }
     if (const char* f = getenv("MVHDP_NARROW")) h->tu.narrow = atoi(f) != 0 ? -1 : 0;
     if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_SIDE_PRIORITY")) h->side_priority = atoi(f) != 0;      // 0: every side stream at normal priority (diagnostics)
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
@@ -767,7 +768,13 @@ static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const
             hipStream_t st = s;
             if (g.stream != PLAN_STREAM_MAIN && p.route && H_seg > 0) {
                 const int si = g.stream;
-                if (!h->side[si]) step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
+                if (!h->side[si]) {
+                    // A and B (the widest classes): high priority = a hardware-queue pool of their own (mvhdp_plan.h)
+                    int least = 0, greatest = 0;
+                    if ((si == PLAN_STREAM_A || si == PLAN_STREAM_B) && h->side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+                        step(hipStreamCreateWithPriority(&h->side[si], hipStreamNonBlocking, greatest));
+                    else step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
+                }
                 if (!h->ev_join[si]) step(hipEventCreateWithFlags(&h->ev_join[si], hipEventDisableTiming));
                 if (e != hipSuccess) return e;
                 if (!used_stream[si]) step(hipStreamWaitEvent(h->side[si], h->ev_fork, 0));

@@ -18,15 +18,18 @@
 #include "mvhdp_device.h"
 #include "../../include/mvhdp.h"
 
-// Streams of one sweep: the primary variant on the handle's stream, the wider classes beside it (HIP maps streams onto
-// few hardware queues: more than three side streams only serialise behind each other).
-// Never more than three side streams: the runtime maps streams onto four hardware queues.
+// Streams of one sweep: the primary variant on the handle's stream, every wider class on a side stream of its own.  HIP maps the
+// streams of one priority onto at most four hardware queues (GPU_MAX_HW_QUEUES), the null stream's included, and two streams that share
+// a hardware queue run one after the other: the C5 trace of round 4 (profiles/r04_timeline_c5_*.txt) showed the 8-, 4- and 2-round
+// kernels in ONE queue -- 5, 9 and 20 ms in series, the first two at two waves per SIMD with nothing beside them.  So the two widest
+// classes (A, B) are created as HIGH-priority streams -- the runtime keeps a queue pool per priority, and the long entities are the
+// sweep's critical path anyway -- and the other classes get the normal-priority streams C and D: main + C + D + the null stream = four.
 // Measured on C4 (round 3, gpurun_out/r3_m4_*, r3_m5_*): the primary on the handle's stream and the wider classes behind the fork
 // event on side streams is the fastest arrangement (deferred 32.97 ms over sweeps 5-24, segmented 33.9 settled); the widest class on
 // the handle's stream and the primary on a side stream -- so that the long entities are resident first -- loses 1-2 ms per sweep
 // while two classes are populated (34.15 / 34.2: the primary then trickles in behind the wide class's blocks); everything on one
 // stream costs a full kernel boundary per class and segment (32.73 / 35.7).  PlanTuning::widest_on_main / single_stream keep both.
-enum { PLAN_STREAM_MAIN = 0, PLAN_STREAM_A = 1, PLAN_STREAM_B = 2, PLAN_STREAM_C = 3, PLAN_N_STREAMS = 4 };
+enum { PLAN_STREAM_MAIN = 0, PLAN_STREAM_A = 1, PLAN_STREAM_B = 2, PLAN_STREAM_C = 3, PLAN_STREAM_D = 4, PLAN_N_STREAMS = 5 };
 
 // Register counts of the compiled kernels (hipFuncGetAttributes at mvhdp_create; typical values in the CPU tests):
 // [class 0..4][0: plain, 1: walk flavour, 2: debug], [5][0/2]: the generic kernel
@@ -420,7 +423,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     }
     p.fast = fast;
     p.pc = fast ? pc : 5;
-    const int stream_of[MVHDP_N_CLASSES] = {PLAN_STREAM_C, PLAN_STREAM_C, PLAN_STREAM_C, PLAN_STREAM_B, PLAN_STREAM_A, PLAN_STREAM_A};
+    const int stream_of[MVHDP_N_CLASSES] = {PLAN_STREAM_C, PLAN_STREAM_C, PLAN_STREAM_D, PLAN_STREAM_B, PLAN_STREAM_A, PLAN_STREAM_A};
     if (!fast) {
         p.cls[5] = gen; p.cls[5].used = true; p.cls[5].stream = PLAN_STREAM_MAIN;
         for (int c = 0; c < MVHDP_N_CLASSES; c++) p.class_map[c] = 5;
@@ -447,7 +450,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
         if (!tu.single_stream && !tu.single_wave && tu.widest_on_main) {
             // widest first: the handle's stream, then side streams A, B, C in turn (the last one shared by whatever is left)
             int next = PLAN_STREAM_MAIN;
-            for (int c = MVHDP_N_CLASSES - 1; c >= pc; c--) if (p.cls[c].used) { p.cls[c].stream = next; next = std::min(next + 1, (int)PLAN_STREAM_C); }
+            for (int c = MVHDP_N_CLASSES - 1; c >= pc; c--) if (p.cls[c].used) { p.cls[c].stream = next; next = std::min(next + 1, (int)PLAN_STREAM_D); }
         }
         // a list of a class nobody launched goes to the next wider launched class (a wider variant holds narrower lists); the widest
         // reachable class is always launched when the sizes are not all known

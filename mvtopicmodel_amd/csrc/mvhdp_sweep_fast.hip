@@ -168,8 +168,24 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     unsigned long long t_last = t_begin;
 #define MVHDP_TSEG(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - t_last; t_last = now_; } while (0)
+#if defined(MVHDP_TSPLIT) && MVHDP_TSPLIT == 1   /* the prologue alone, cut in four (reported as prologue / view setup / chunk head / tokens), the rest as chunk end */
+#define MVHDP_TSUB(acc) MVHDP_TSEG(acc)
+#define MVHDP_TSUB2(acc) do { } while (0)
+#define MVHDP_TMAIN(acc, s1, s2) MVHDP_TSEG(s1)
+#elif defined(MVHDP_TSPLIT) && MVHDP_TSPLIT == 2 /* the chunk head alone, cut in four, the rest as chunk end */
+#define MVHDP_TSUB(acc) do { } while (0)
+#define MVHDP_TSUB2(acc) MVHDP_TSEG(acc)
+#define MVHDP_TMAIN(acc, s1, s2) MVHDP_TSEG(s2)
+#else
+#define MVHDP_TSUB(acc) do { } while (0)
+#define MVHDP_TSUB2(acc) do { } while (0)
+#define MVHDP_TMAIN(acc, s1, s2) MVHDP_TSEG(acc)
+#endif
 #else
 #define MVHDP_TSEG(acc) do { } while (0)
+#define MVHDP_TSUB(acc) do { } while (0)
+#define MVHDP_TSUB2(acc) do { } while (0)
+#define MVHDP_TMAIN(acc, s1, s2) do { } while (0)
 #endif
     // (the last pulls of the queue take one entity at a time: the launch ends within one entity's time of its last pull)
     const long long q_single = q_total - 2LL * gridDim.x * (blockDim.x >> 6);
@@ -209,6 +225,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             }
         }
         LDS_FENCE();
+        MVHDP_TSUB(tp);
         int S_used;
         {
             uint32_t wbits = (lane < NW) ? bitmap[lane] : 0u;
@@ -237,6 +254,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         for (int m = 0; m < M; m++)
             for (int i = lane; i < S_used; i += WAVE) sn_set(m * S + i, 0);
         LDS_FENCE();
+        MVHDP_TSUB(tv);
         for (int m = 0; m < M; m++) {
             const int64_t b = mm.doc_off[m][d], e = mm.doc_off[m][d + 1];
             for (int64_t i = b + lane; i < e; i += WAVE) {
@@ -250,6 +268,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             }
         }
         LDS_FENCE();
+        MVHDP_TSUB(th);
         int koff[RMAX];
         unsigned long long live_m[RMAX];
 #pragma unroll
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             wsh[lane] = (pj != pm && wlen[pj] != 0) ? (float)(pmj / dd) : 0.0f;
         }
         LDS_FENCE();
-        MVHDP_TSEG(tp);
+        MVHDP_TMAIN(tp, tt, te);
         bool aborted = false;
 
         for (int m = 0; m < M && !aborted; m++) {                         // WRK:393
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             const unsigned int v_tok0 = n_tok, v_tree0 = c_tree;
             unsigned int whist_l = 0;                                        // lane b < MVHDP_WALK_BINS: tree-branch tokens of this view with u1 in bin b
 
-            MVHDP_TSEG(tv);
+            MVHDP_TMAIN(tv, te, te);
             for (int c0 = 0; c0 < lenm && !aborted; c0 += WAVE) {
                 // one lane per token of the chunk: token id, old topic, its slot, RNG, tree root
                 const int ti = c0 + lane;
@@ -381,6 +400,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     u1_l = bits_to_unit(x[0], x[1]);
                     u2_l = bits_to_unit(x[2], x[3]);
                 }
+                MVHDP_TSUB2(tp);                                             // (split 2: token / z loads, the slot lookup, Philox)
                 if (w_l >= Vm) w_l = -1;                                     // WRK:427-428 marks OOV
                 // NARROW: the row's weight class rides in bit 30 of the type id (a light row's counts are in the 16-bit mirror, a heavy row's
                 // only in the 32-bit table, MvModel::heavy), so that the gather of a token's row knows the table to read from a scalar of
@@ -438,8 +458,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
 
+                MVHDP_TSUB2(tv);                                             // (split 2: heavy flags, roots, the tree walk, the sampled topic's slot)
                 const float root32_l = (float)root_l;
-                MVHDP_TSEG(th);
+                MVHDP_TMAIN(th, te, tt);
                 // software pipeline: the n_wk values of the listed topics are gathered NB tokens ahead, into NB
                 // register buffers used in turn (the token loop is unrolled NB times so that no buffer is ever
                 // copied while its load is in flight).  Two buffers where few waves share a SIMD and a wave's
@@ -489,7 +510,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     }
                 }
 
-                MVHDP_TSEG(tt);
+                MVHDP_TMAIN(tt, te, te);
                 // WRK:587-589 + UPD:197-218 for the whole chunk at once: lane t owns token t (old topic z_l,
                 // new topic znew_l), so the FastQDelta records of up to 64 tokens become two wave-wide
                 // atomic instructions on the delta rows plus two on the block's n_k table.  Issued after
@@ -526,7 +547,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
-                MVHDP_TSEG(te);
+                MVHDP_TMAIN(te, te, te);
             }
 
             // the view's counts go back to LDS: later views read them (WRK:404) and test them (WRK:445)
