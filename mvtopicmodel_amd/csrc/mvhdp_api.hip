@@ -53,6 +53,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_DELTA16")) h->tu.delta16 = atoi(f) != 0;                   // 0: every n_wk delta in the 32-bit table (diagnostics)
     if (const char* f = getenv("MVHDP_FORK_DELAY_US")) h->tu.fork_delay_us = std::max(0, std::min(1000, atoi(f)));
     if (const char* f = getenv("MVHDP_FORCE_MODE")) { if (!strcmp(f, "serial")) h->tu.single_stream = 1; }   // "streams" (default): class kernels side by side
     if (const char* f = getenv("MVHDP_PRIMARY_MIN_SHARE")) { const double v = atof(f); if (v > 0.0 && v <= 1.0) h->tu.primary_min_share = v; }
@@ -83,7 +84,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
         return MVHDP_ERR_INVALID_ARG;
     }
     for (int m = 0; m < M; m++) if (cfg->num_types[m] < 1) { g_create_error = "num_types[m] must be >= 1"; return MVHDP_ERR_INVALID_ARG; }
-    for (int m = 0; m < M; m++) if (cfg->num_types[m] >= (1 << 30)) { g_create_error = "num_types[m] must be below 2^30"; return MVHDP_ERR_INVALID_ARG; }
+    for (int m = 0; m < M; m++) if (cfg->num_types[m] >= (1 << 29)) { g_create_error = "num_types[m] must be below 2^29"; return MVHDP_ERR_INVALID_ARG; }
     if (cfg->doc_id_base < 0 || cfg->doc_id_base >= (1LL << 29)) { g_create_error = "doc_id_base out of range"; return MVHDP_ERR_INVALID_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
@@ -124,6 +125,8 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMemset(mm.counts, 0, cbytes));
     CREATE_HIP(hipMalloc(&mm.counts16, (size_t)nrows * K * sizeof(uint16_t)));
     CREATE_HIP(hipMemset(mm.counts16, 0, (size_t)nrows * K * sizeof(uint16_t)));
+    CREATE_HIP(hipMalloc(&mm.delta16, (size_t)(nrows * K + 2) * sizeof(uint16_t)));
+    CREATE_HIP(hipMemsetD16(mm.delta16, (unsigned short)0x8000, (size_t)(nrows * K + 2)));       // (the bias: see SweepLaunch::delta16)
     CREATE_HIP(hipMalloc(&mm.heavy, (size_t)nrows));
     CREATE_HIP(hipMemset(mm.heavy, 1, (size_t)nrows));
     CREATE_HIP(hipMemset(mm.delta, 0, cbytes));
@@ -173,7 +176,7 @@ static void release_device_resources(mvhdp_ctx* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
     for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); fr(h->d_present[m]); }
-    fr(h->mm.counts); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
+    fr(h->mm.counts); fr(h->mm.delta16); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
     fr(h->d_alpha); fr(h->d_inactive); fr(h->d_ctl);
     if (h->h_ctl) { hipHostFree(h->h_ctl); h->h_ctl = nullptr; }
     h->d_stats = nullptr; h->d_act_key = nullptr; h->d_doc_counter = nullptr; h->d_ovf_meta = nullptr;
@@ -389,6 +392,8 @@ extern "C" int mvhdp_build_counts(mvhdp_handle h)
         // a NO_APPLY sweep's deltas were never applied: z already holds its assignments, so the recount above includes
         // them -- drop the deltas instead of leaving them to be added on top
         HIPC(h, hipMemsetAsync(h->mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), h->stream));
+        if (h->delta16_used) HIPC(h, hipMemsetD16Async(h->mm.delta16, (unsigned short)0x8000, (size_t)(h->mm.rowbase[h->mm.M] * h->mm.K), h->stream));
+        h->delta16_used = false;
         h->delta_pending = false; h->delta_clean = true;
     }
     HIPC(h, hipStreamSynchronize(h->stream));
@@ -568,7 +573,8 @@ extern "C" int mvhdp_apply_delta(mvhdp_handle h, int32_t activated_topic, int32_
     MvModel& mm = h->mm;
     HIPC(h, hipSetDevice(h->device));
     HIPC(h, hipMemsetAsync(h->d_stats + ST_NEGATIVE, 0, sizeof(unsigned long long), h->stream));
-    HIPC(h, mvhdp_launch_apply_delta(mm, h->d_stats, h->stream));
+    HIPC(h, mvhdp_launch_apply_delta(mm, h->d_stats, h->stream, h->delta16_used));
+    h->delta16_used = false;
     unsigned long long neg = 0;
     HIPC(h, hipMemcpyAsync(&neg, h->d_stats + ST_NEGATIVE, sizeof neg, hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
@@ -889,6 +895,7 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
     sl.q_order_stride = 1;
     sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
     sl.live16 = p.live16 ? 1 : 0;
+    sl.delta16 = p.delta16 ? 1 : 0;
     sl.stats = d_stats;
     sl.act_key = h->d_act_key;
     sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;
@@ -1026,9 +1033,13 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
     sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
     sl.flags = flags & 0x7fffu; sl.S_cap = p.S_cap;
     if (h->tu.single_wave && p.live) sl.flags |= MVHDP_SL_STRICT_LIVE;
+#ifdef MVHDP_PROBE
+    if (const char* f = getenv("MVHDP_ATOMIC_PROBE")) sl.flags |= ((unsigned)atoi(f) & 7u) << 16;     // measurement build only (mvhdp_sweep_fast.hip)
+#endif
     sl.q_order_stride = 1;
     sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
     sl.live16 = p.live16 ? 1 : 0;
+    sl.delta16 = p.delta16 ? 1 : 0;
     sl.stats = d_stats;
     sl.act_key = h->d_act_key;
     sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;
@@ -1061,8 +1072,13 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         mk.delta = mm.counts;
         if (flags & MVHDP_SWEEP_NO_APPLY) { step(mvhdp_launch_live_helper(mm, 0, d_stats, s)); h->delta_clean = false; }
     } else if (!p.frozen) {                                      // a frozen sweep queues nothing (WRK:587) and leaves the buffer alone
-        if (!h->delta_clean) step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
+        if (!h->delta_clean) {
+            step(hipMemsetAsync(mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), s));
+            if (h->delta16_used) step(hipMemsetD16Async(mm.delta16, (unsigned short)0x8000, (size_t)(mm.rowbase[M] * mm.K), s));   // (a sweep that failed before its apply pass)
+            h->delta16_used = false;
+        }
         h->delta_clean = false;
+        if (p.delta16) h->delta16_used = true;                   // (cleared by the apply pass, which folds the 16-bit cells in and re-biases them)
     }
     // this sweep's counters, "no activation yet", the histograms for the next plan, the class list lengths, the queue heads: one launch
     step(mvhdp_launch_ctl_reset(d_stats, ST_COUNT, h->d_act_key, (unsigned long long*)h->d_ovf_meta, META_WORDS64, nullptr, h->d_doc_counter, s));
@@ -1362,7 +1378,8 @@ extern "C" int mvhdp_sweep_many(mvhdp_handle h, uint32_t first_idx, int32_t n, u
         if (rc) return rc;
         if (!p.frozen && !p.live && !p.seg_apply) {
             // the updater's pass (UPD:197-218) in stream order; negative counts are counted into this sweep's counters
-            HIPC(h, mvhdp_launch_apply_delta(mm, d_st, s));
+            HIPC(h, mvhdp_launch_apply_delta(mm, d_st, s, h->delta16_used));
+            h->delta16_used = false;
             h->have_trees = false; h->delta_clean = true;
         } else if (p.live || p.seg_apply) {
             h->have_trees = false;
@@ -1475,6 +1492,7 @@ extern "C" int mvhdp_plan_probe(const mvhdp_plan_input* pi, const mvhdp_tuning* 
         po->class_walk[c] = p.cls[c].walk; po->class_narrow[c] = p.cls[c].narrow; po->class_register_resident[c] = p.cls[c].fast ? 1 : 0;
         po->class_theta0[c] = p.cls[c].theta[0];
     }
+    po->delta16 = p.delta16 ? 1 : 0;
     return MVHDP_OK;
 }
 

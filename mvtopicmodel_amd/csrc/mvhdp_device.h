@@ -31,9 +31,11 @@ struct MvModel {
     uint16_t* nslots;
     // model: counts = [sumV*K n_wk | M*K n_k], delta same layout
     int32_t* counts;
+    uint16_t* delta16;                 // [sumV*K] the sweep's n_wk deltas of the rows that cannot overflow 16 bits (MVHDP_ROW_BIG clear), biased by 0x8000,
+                                       //   two cells a word: the chunk-end atomics of a deferred sweep land in HALF the table (SweepLaunch::delta16)
     uint16_t* counts16;                // [sumV*K] min(n_wk, 65535): written row by row whenever the row's tree is built (build_trees_kernel),
                                        //   so it is the sweep-start n_wk of every sweep that starts with the trees; read by the NARROW kernel flavour
-    uint8_t* heavy;                    // [sumV] 1: the row's type holds more than 65534 tokens in all: its mirror cells are all 65535 and its
+    uint8_t* heavy;                    // [sumV] MVHDP_ROW_HEAVY (1): the row's type holds more than 65534 tokens in all: its mirror cells are all 65535 and its
                                        //   counts live in the 32-bit table only.  A LIGHT row's cells can never reach 65535, so a live sweep may keep
                                        //   them current IN the mirror (two cells per 32-bit word, +-1 / +-65536 atomics, no carry) -- SweepLaunch::live16
     int32_t* delta;
@@ -58,6 +60,11 @@ struct MvModel {
 // SweepLaunch::flags, internal: a live sweep waits for its chunk-end atomics and invalidates the CU's L1 before it goes on (with one
 // resident wave the sweep is then the sequential algorithm: mvhdp_tuning.single_wave)
 #define MVHDP_SL_STRICT_LIVE 0x8000u
+// MvModel::heavy values: 0 = light and small, MVHDP_ROW_HEAVY = more than 65534 tokens (not in the mirror), MVHDP_ROW_BIG = light, but
+// more than 32767 tokens (mirror yes, 16-bit deltas no).  Written by build_trees_kernel from the row's sum.
+#define MVHDP_ROW_HEAVY 1
+#define MVHDP_ROW_BIG 2
+
 struct SweepLaunch {
     uint32_t sweep_idx;
     uint32_t seed_lo, seed_hi;
@@ -85,6 +92,7 @@ struct SweepLaunch {
     double walk_theta[MVHDP_MAXM];
     int32_t walk;                      // 1: launch the kernel flavour that knows about thresholds (and counts the per-view statistics)
     int32_t narrow;                    // 1: the flavour that gathers n_wk from the 16-bit mirror
+    int32_t delta16;                   // 1 (deferred sweep, narrow flavour): the n_wk deltas of rows without MVHDP_ROW_BIG go to MvModel::delta16
     int32_t live16;                    // 1 (MVHDP_SWEEP_LIVE with narrow): the sweep's n_wk atomics of LIGHT rows go to the mirror itself, which is then the
                                        //   authoritative copy of those rows until the next tree build / widen pass; heavy rows: the 32-bit table as ever
     unsigned long long* slot_hist;     // [MVHDP_HIST_BINS] tokens of the entities whose NEW topic list has ceil(size/64) = 1..16, >16, then
@@ -129,7 +137,7 @@ hipError_t mvhdp_launch_gate(const unsigned long long* qhead, unsigned long long
 hipError_t mvhdp_launch_init_from_trees(const MvModel& mm, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s);
-hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s);
+hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s, bool with_delta16 = false);
 hipError_t mvhdp_launch_delay(int microseconds, hipStream_t s);
 // zeroes the given counter arrays (any may be null) and sets *act_key to "none", in one launch
 hipError_t mvhdp_launch_ctl_reset(unsigned long long* stats, int n_stats, long long* act_key, unsigned long long* meta, int n_meta,

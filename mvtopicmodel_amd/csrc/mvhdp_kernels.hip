@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         const double* al = mm.alpha + (int64_t)m * (K + 1);
         const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
         uint16_t* c16 = mm.counts16 + row * K;
-        const bool light_src = from_mirror && !mm.heavy[row];
+        const bool light_src = from_mirror && mm.heavy[row] != MVHDP_ROW_HEAVY;
         bool hv = false;
         // first pass over the row: the updater's catch-up (apply_first), the row's weight class, the mirror
         if (!from_mirror) {
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, WAVE);
             hv = sum > 65534;
-            if (lane == 0) mm.heavy[row] = hv ? 1 : 0;
+            // (between the two: a light row whose deltas of one sweep may pass +-32767 -- they stay in the 32-bit delta table, SweepLaunch::delta16)
+            if (lane == 0) mm.heavy[row] = hv ? MVHDP_ROW_HEAVY : (sum > 32767 ? MVHDP_ROW_BIG : 0);
         }
         for (int k = lane; k < K; k += WAVE) {
             int c;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64) void apply2_trees_kernel(MvModel mm, const int3
         const int32_t* a = dA + row * K;
         int32_t* b = dB ? dB + row * K : nullptr;
         unsigned int* m32 = (unsigned int*)mm.counts16;
-        const bool light = use_mirror && !mm.heavy[row];
+        const bool light = use_mirror && mm.heavy[row] != MVHDP_ROW_HEAVY;
         const int32_t* nk = nk_all + (int64_t)m * K;
         const double* al = mm.alpha + (int64_t)m * (K + 1);
         const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void apply2_counts_kernel(MvModel mm, const in
         if (!d) continue;
         const int old = __hip_atomic_fetch_add(&mm.counts[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         neg += old + d < 0;
-        if (use_mirror && i < n_cells && !mm.heavy[i / K]) __hip_atomic_fetch_add(&m32[i >> 1], (unsigned int)d << ((i & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (use_mirror && i < n_cells && mm.heavy[i / K] != MVHDP_ROW_HEAVY) __hip_atomic_fetch_add(&m32[i >> 1], (unsigned int)d << ((i & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (neg && negatives) atomicAdd(negatives, (unsigned long long)neg);
 }
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void apply_sparse_kernel(MvModel mm, int32_t* 
         if (!dl) continue;
         mm.counts[i] += dl;
         d[i] = 0;
-        if (use_mirror && i < n_cells && !mm.heavy[i / K]) __hip_atomic_fetch_add(&m32[i >> 1], (unsigned int)dl << ((i & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (use_mirror && i < n_cells && mm.heavy[i / K] != MVHDP_ROW_HEAVY) __hip_atomic_fetch_add(&m32[i >> 1], (unsigned int)dl << ((i & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void widen_mirror_kernel(MvModel mm)
     const int lane = threadIdx.x & 63;
     const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nrows; row += wstride) {
-        if (mm.heavy[row]) continue;
+        if (mm.heavy[row] == MVHDP_ROW_HEAVY) continue;
         const uint16_t* c16 = mm.counts16 + row * K;
         int32_t* cnt = mm.counts + row * K;
         for (int k = lane; k < K; k += WAVE) cnt[k] = (int)c16[k];
@@ -951,12 +952,18 @@ hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid
 // apply_delta: counts += delta; delta = 0 (the updater's effect, UPD:197-218,
 // after the optional cross-GPU all-reduce of the delta buffer).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void apply_delta_kernel(int32_t* counts, int32_t* delta, int64_t n, unsigned long long* stats)
+// delta16 (or null): the n_wk deltas the sweep kept in 16-bit cells biased by 0x8000 (SweepLaunch::delta16), n16 cells: added on top and
+// set back to the bias.
+__global__ __launch_bounds__(256) void apply_delta_kernel(int32_t* counts, int32_t* delta, int64_t n, unsigned long long* stats, uint16_t* delta16, int64_t n16)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int neg = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         int dl = delta[i];
+        if (delta16 && i < n16) {
+            const int v = (int)delta16[i];
+            if (v != 0x8000) { dl += v - 0x8000; delta16[i] = (uint16_t)0x8000; if (!dl) delta[i] = 0; }
+        }
         if (dl) {
             int c = counts[i] + dl;
             counts[i] = c;
@@ -1004,13 +1011,13 @@ hipError_t mvhdp_launch_delay(int microseconds, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s)
+hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s, bool with_delta16)
 {
     int64_t n = mm.rowbase[mm.M] * mm.K + (int64_t)mm.M * mm.K;
     int grid = (int)((n + 255) / 256);
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(apply_delta_kernel, dim3(grid), dim3(256), 0, s, mm.counts, mm.delta, n, stats);
+    hipLaunchKernelGGL(apply_delta_kernel, dim3(grid), dim3(256), 0, s, mm.counts, mm.delta, n, stats, with_delta16 ? mm.delta16 : nullptr, mm.rowbase[mm.M] * mm.K);
     return hipGetLastError();
 }
 

@@ -86,6 +86,7 @@ struct SweepPlan {
     bool need_full = false;                     // FTree.tree itself is read (generic kernel, debug trace)
     int nk_global = 0;
     uint32_t block_shared_bytes = 0;
+    bool delta16 = false;                       // a deferred sweep whose narrow kernels keep the deltas of the small rows in 16-bit cells (SweepLaunch::delta16)
     bool live16 = false;                        // a live sweep whose light rows are kept current in the 16-bit mirror (every kernel the NARROW flavour)
     int dominant = 0;                           // class holding most tokens (its group's walk threshold is the one being searched)
     int walk_cfg = 0;                           // key of the configuration the walk search compares sweeps within
@@ -128,6 +129,7 @@ struct PlanTuning {
     double walk_theta[MVHDP_MAXM] = {0};
     double primary_min_share = 0.10;            // the narrowest class holding at least this share of the tokens gets its own (primary) kernel
     int single_stream = 0;                      // 1: every class kernel on the handle's stream, one after another (diagnostics)
+    int delta16 = 1;                            // 1: 16-bit delta cells for the rows that cannot overflow them (plain deferred sweeps); 0: never
     int narrow_wide = 1;                        // 1: deferred sweeps gather from the mirror in the wider variants too (0: the 1-round variant only)
     int fork_delay_us = 0;                      // microseconds the handle's stream is held between the fork event and the primary kernel (0: none)
     int widest_on_main = 0;                     // 1: the widest class on the handle's stream, the primary on a side stream (diagnostics)
@@ -475,6 +477,11 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
         for (int c = 1; c < 5; c++) if (p.cls[c].used && p.cls[c].fast && p.cls[c].walk) p.cls[c].narrow = 1;
     // A live sweep updates n_wk while it samples: the mirror stays usable only if the sweep's own atomics keep it current, which takes
     // every kernel of the sweep in the NARROW (hence walk) flavour -- no generic kernel among them.
+    // The deltas of a plain deferred sweep (one segment, applied by this call) in 16-bit cells where the row allows it: the kernels of the
+    // NARROW flavour know the row's class; whatever else runs in the sweep writes the 32-bit table as ever, the apply pass adds both.
+    // Not while a token may be unassigned: the row's class is taken from its counts, and first visits only add.
+    p.delta16 = tu.delta16 != 0 && mirror_ok && !p.live && !p.frozen && !p.seg_apply && nseg == 1 && p.only_seg < 0 &&
+                !(flags & MVHDP_SWEEP_NO_APPLY) && !in.unassigned;                 // (a group of document shards sweeps with NO_APPLY: 32-bit deltas for the all-reduce)
     if (want_live16) {
         bool all_fast = true;
         for (int c = 0; c < MVHDP_N_CLASSES; c++) if (p.cls[c].used && !p.cls[c].fast) all_fast = false;

@@ -94,8 +94,9 @@ __device__ __forceinline__ int gather_cell(gptr_t p)
     return (int)*q;
 #endif
 }
-#define W_HEAVY 0x40000000                      // bit 30 of a lane's type id: the row is heavy (type ids stay below 2^30: mvhdp_create checks)
-#define W_ROW(w) ((w) & 0x3fffffff)
+#define W_HEAVY 0x40000000                      // bit 30 of a lane's type id: the row is heavy (type ids stay below 2^29: mvhdp_create checks)
+#define W_BIG   0x20000000                      // bit 29: the row's deltas do not fit 16 bits for sure (MVHDP_ROW_BIG or heavy): they go to the 32-bit delta table
+#define W_ROW(w) ((w) & 0x1fffffff)
 // ROOMY (the 2-round variant on the mirror only): the same kernel compiled for 6 waves per SIMD (80 registers, a third of the scratch
 // of the 72-register build): where a row of the mirror is 1 KiB or more (K >= 512; C5: K = 1000) the seventh wave hides less than the
 // spills cost -- C5's 2-round kernel 16.9 ms at 6 waves, 18.4 at 7; C4's (K = 400) gains 2 % at 7.
@@ -405,7 +406,10 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 // NARROW: the row's weight class rides in bit 30 of the type id (a light row's counts are in the 16-bit mirror, a heavy row's
                 // only in the 32-bit table, MvModel::heavy), so that the gather of a token's row knows the table to read from a scalar of
                 // the broadcast it does anyway -- nothing to check or resolve when the values are used.  (W_ROW strips the bit.)
-                if (NARROW && w_l >= 0 && mm.heavy[row0 + w_l]) w_l |= W_HEAVY;
+                if (NARROW && w_l >= 0) {
+                    const int hv = mm.heavy[row0 + w_l];
+                    if (hv) w_l |= (hv == MVHDP_ROW_HEAVY) ? (W_HEAVY | W_BIG) : W_BIG;
+                }
                 const float u1f_l = (float)u1_l;                             // (may round to 1.0f: the screening then hands the token to fp64)
                 int znew_l = z_l;
                 const int nt = min(WAVE, lenm - c0);
@@ -525,9 +529,32 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                             unsigned int* m32 = (unsigned int*)mm.counts16;
                             if (z_l >= 0) { const int64_t c = rowK + z_l; __hip_atomic_fetch_add(&m32[c >> 1], 0u - (1u << ((c & 1) * 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                             { const int64_t c = rowK + znew_l; __hip_atomic_fetch_add(&m32[c >> 1], 1u << ((c & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        } else if (NARROW && sl.delta16 && !(w_l & W_BIG)) {
+                            // a row whose deltas of one sweep stay within +-32767 (its type holds no more tokens than that): 16-bit cells
+                            // biased by 0x8000, two a word -- a cell never reaches 0 or 65536 on the way, so +-1 / +-65536 cannot carry --
+                            // in a table half the size of the 32-bit one: more of it stays in the Infinity Cache, where the memory-side
+                            // atomics are performed (profiles/r04_atomic_cost.md)
+                            unsigned int* d32 = (unsigned int*)mm.delta16;
+                            if (z_l >= 0) { const int64_t c = rowK + z_l; __hip_atomic_fetch_add(&d32[c >> 1], 0u - (1u << ((c & 1) * 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            { const int64_t c = rowK + znew_l; __hip_atomic_fetch_add(&d32[c >> 1], 1u << ((c & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                         } else {
+#ifdef MVHDP_PROBE      /* measurement build (tools/mode_times.py --mode atomic_probe): what about the chunk-end atomics costs -- WRONG counts by design */
+                            const int probe = (int)((sl.flags >> 16) & 7u);
+                            int64_t c_old = rowK + z_l, c_new = rowK + znew_l;
+                            if (probe == 1) { c_old &= 0xffff; c_new &= 0xffff; }                 // a 256 KB table: stays in the caches
+                            if (probe == 7) { c_old &= 0xfffff; c_new &= 0xfffff; }               // 4 MB
+                            if (probe == 5) { c_old &= 0x7fffff; c_new &= 0x7fffff; }             // 32 MB of the delta table
+                            if (probe == 6) { c_old &= 0xffffff; c_new &= 0xffffff; }             // 64 MB
+                            if (probe == 3) { if (z_l >= 0) dnwk[c_old] = -1; dnwk[c_new] = 1; }  // plain stores to the same cells
+                            else if (probe == 4) { if (z_l >= 0) __hip_atomic_fetch_add(&dnwk[c_old], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&dnwk[c_new], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                            else {
+                                if (z_l >= 0) __hip_atomic_fetch_add(&dnwk[c_old], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (probe != 2) __hip_atomic_fetch_add(&dnwk[c_new], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#else
                             if (z_l >= 0) __hip_atomic_fetch_add(&dnwk[rowK + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_fetch_add(&dnwk[rowK + znew_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                         }
                         if (z_l >= 0) {
                             if (sl.nk_global) __hip_atomic_fetch_add(&dnk_g[m * K + z_l], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -119,3 +119,47 @@ def test_16_bit_mirror_of_the_counts_including_saturated_cells(monkeypatch, narr
         assert ro["stats"]["word_ftree_mass_cnt"] == rs.word_ftree_mass_cnt and ro["stats"]["changed"] == rs.changed
         assert_same_state(o, s, 1)
     s.close()
+
+
+@pytest.mark.parametrize("force", ["", "2", "4"])
+@pytest.mark.parametrize("delta16", ["1", "0"])
+def test_16_bit_delta_cells_with_the_three_row_classes(monkeypatch, force, delta16):
+    """A plain deferred sweep of the narrow flavour keeps the n_wk deltas of the rows that cannot overflow them in 16-bit cells biased by
+    0x8000 (MvModel::delta16, SweepLaunch::delta16: half the table its chunk-end atomics land in); the apply pass adds them to the 32-bit
+    deltas and re-biases the cells.  One corpus with the three row classes build_trees_kernel hands out -- a type with more than 65534
+    tokens (HEAVY: 32-bit counts and deltas), one between 32768 and 65534 (mirror counts, 32-bit deltas), the rest small (mirror counts,
+    16-bit deltas) -- swept five times: every state is the oracle's, with the 16-bit cells and without."""
+    monkeypatch.setenv("MVHDP_WALK_THETA", "0.3")           # the walk flavour, hence the mirror and the row classes
+    monkeypatch.setenv("MVHDP_DELTA16", delta16)
+    if force:
+        monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
+    from mvtopicmodel_amd.synth import Corpus
+    K, V, D = 24, [40, 7], 2500
+    rng = np.random.RandomState(12)
+    lens0 = np.full(D, 200, dtype=np.int64); lens1 = rng.randint(0, 5, D).astype(np.int64)
+    off = [np.concatenate([[0], np.cumsum(l)]) for l in (lens0, lens1)]
+    u = rng.rand(off[0][-1])
+    t0 = rng.randint(2, 40, off[0][-1]).astype(np.int32)
+    t0[u < 0.5] = 0                                                    # type 0: 250 k tokens
+    t0[(u >= 0.5) & (u < 0.59)] = 1                                    # type 1: 45 k
+    c = Corpus(K, V, off, [t0, rng.randint(0, 7, off[1][-1]).astype(np.int32)])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    tot = s.get_counts(0)[0].sum(axis=1)
+    assert tot[0] > 65534 and 32767 < tot[1] <= 65534 and tot[2:].max() <= 32767
+    for it in range(5):
+        ro = o.sweep(it, 33)
+        rs = s.sweep(it, 33)
+        assert ro["stats"]["changed"] == rs.changed and rs.tokens == c.total_tokens
+        assert_same_state(o, s, c.M)
+    # a sweep that leaves its deltas for the host (document shards) keeps them all in the 32-bit table
+    from mvtopicmodel_amd.native import SWEEP_NO_APPLY
+    o.sweep(5, 33); s.sweep(5, 33, flags=SWEEP_NO_APPLY); s.apply_delta(-1, -1)
+    assert_same_state(o, s, c.M)
+    # ... and batches (mvhdp_sweep_many) fold the cells in after every sweep of the batch
+    for it in (6, 7, 8):
+        o.sweep(it, 33)
+    s.sweep_many(6, 3, 33)
+    assert_same_state(o, s, c.M)
+    s.close()

@@ -162,3 +162,16 @@ def test_walk_threshold_search_finds_the_minimum_of_a_smooth_cost_curve():
     ns = np.ones(21)
     assert L.mvhdp_tuner_probe(3, f.ctypes.data, u1.ctypes.data, ns.ctypes.data, len(steps), 1, steps.ctypes.data) == 0
     assert steps.max() <= 8
+
+
+def test_sixteen_bit_delta_cells_are_for_plain_deferred_sweeps():
+    """mvhdp_plan_output.delta16: the n_wk deltas of rows that cannot overflow 16 bits go to a table half the size -- when this call
+    applies them itself and in one piece; document shards (NO_APPLY), segments, live and frozen sweeps keep the 32-bit table."""
+    kw = dict(tok=[80_000_000, 66_000_000, 1_000_000], ent=[550_000, 449_000, 1_000, 0, 0, 0, 0, 0])
+    assert probe(**kw).delta16 == 1
+    assert probe(flags=SWEEP_NO_APPLY, **kw).delta16 == 0
+    assert probe(flags=SWEEP_LIVE, **kw).delta16 == 0
+    assert probe(flags=SWEEP_SEGMENT_APPLY | (8 << 8), **kw).delta16 == 0
+    assert probe(flags=SWEEP_FROZEN | SWEEP_REUSE_TREES, trees_current=1, **kw).delta16 == 0
+    assert probe(debug=1, **kw).delta16 == 0                                             # the debug flavour does not read the mirror
+    assert probe(tuning=dict(narrow=0), **kw).delta16 == 0                               # nor a sweep pinned to the 32-bit rows
