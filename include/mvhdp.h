@@ -47,7 +47,7 @@ typedef struct mvhdp_ctx* mvhdp_handle;
 typedef struct {
     int32_t num_topics;                          /* K, PTM:193 */
     int32_t num_modalities;                      /* M, PTM:189 */
-    int32_t num_types[MVHDP_MAX_MODALITIES];     /* V_m = alphabet[m].size(), PTM:413 */
+    int32_t num_types[MVHDP_MAX_MODALITIES];     /* V_m = alphabet[m].size(), PTM:413; below 2^29 (two bits of a type id carry the row's class inside the kernels) */
     int32_t device;                              /* HIP device ordinal */
     int64_t doc_id_base;                         /* global id of local entity 0 (document shards, one per GPU) */
     uint32_t flags;                              /* reserved, 0 */

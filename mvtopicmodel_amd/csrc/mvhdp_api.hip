@@ -189,6 +189,8 @@ static void release_device_resources(mvhdp_ctx* h)
     for (auto& e : h->ev_many) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& e : h->ev) if (e) { hipEventDestroy(e); e = nullptr; }
     if (h->ev_fork) { hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
+    for (auto& e : h->ev_aux) if (e) { hipEventDestroy(e); e = nullptr; }
+    if (h->aux) { hipStreamDestroy(h->aux); h->aux = nullptr; }
     for (auto& e : h->ev_join) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& st : h->side) if (st) { hipStreamDestroy(st); st = nullptr; }
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1049,11 +1051,28 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
     }
     unsigned int* class_counts = h->d_ovf_meta + META_CLASS_COUNTS;
 
+    bool p_beside = false;                                       // the view weights are drawn beside the tree rebuild (neither reads what the other writes)
     if (M > 1) {
         if (!mm.p && mm.D > 0) step(hipMalloc(&mm.p, (size_t)mm.D * M * M * sizeof(double)));
         if (e == hipSuccess) {
             if (p_override) step(hipMemcpyAsync(mm.p, p_override, (size_t)mm.D * M * M * sizeof(double), hipMemcpyHostToDevice, s));
-            else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, s));
+            else if (!(flags & MVHDP_SWEEP_REUSE_TREES) && !h->tu.single_stream && !h->tu.single_wave && !db) {
+                if (!h->aux) {
+                    int least = 0, greatest = 0;                 // (high priority: the queue pool of the wide classes' streams, mvhdp_plan.h)
+                    if (h->side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+                        step(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, greatest));
+                    else step(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+                    step(hipEventCreateWithFlags(&h->ev_aux[0], hipEventDisableTiming));
+                    step(hipEventCreateWithFlags(&h->ev_aux[1], hipEventDisableTiming));
+                }
+                if (e == hipSuccess) {
+                    step(hipEventRecord(h->ev_aux[0], s));
+                    step(hipStreamWaitEvent(h->aux, h->ev_aux[0], 0));
+                    step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, h->aux));
+                    step(hipEventRecord(h->ev_aux[1], h->aux));
+                    p_beside = true;
+                }
+            } else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, s));
         }
     }
     h->last_need_full = p.need_full;
@@ -1066,6 +1085,7 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         step(mvhdp_launch_build_trees(mm, h->trees_inference, true, s));
         h->full_trees = true;
     }
+    if (p_beside) step(hipStreamWaitEvent(s, h->ev_aux[1], 0));
     // where the sweep's atomics land: the delta replica (deferred), or the shared counts themselves (live)
     MvModel mk = mm;
     if (p.live) {
