@@ -48,6 +48,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_FORCE_RMAX")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) h->tu.force_primary = v; }
     if (const char* f = getenv("MVHDP_NARROW")) h->tu.narrow = atoi(f) != 0 ? -1 : 0;
     if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_P_BESIDE")) h->p_beside = atoi(f) != 0;                    // 0: the view weights on the handle's stream, before the tree rebuild
     if (const char* f = getenv("MVHDP_SIDE_PRIORITY")) h->side_priority = atoi(f) != 0;      // 0: every side stream at normal priority (diagnostics)
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
@@ -777,9 +778,9 @@ static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const
             if (g.stream != PLAN_STREAM_MAIN && p.route && H_seg > 0) {
                 const int si = g.stream;
                 if (!h->side[si]) {
-                    // A and B (the widest classes): high priority = a hardware-queue pool of their own (mvhdp_plan.h)
+                    // A, B and D (the classes of 4 and more rounds): high priority = a hardware-queue pool of their own (mvhdp_plan.h)
                     int least = 0, greatest = 0;
-                    if ((si == PLAN_STREAM_A || si == PLAN_STREAM_B) && h->side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+                    if (si != PLAN_STREAM_C && h->side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
                         step(hipStreamCreateWithPriority(&h->side[si], hipStreamNonBlocking, greatest));
                     else step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
                 }
@@ -1056,7 +1057,7 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         if (!mm.p && mm.D > 0) step(hipMalloc(&mm.p, (size_t)mm.D * M * M * sizeof(double)));
         if (e == hipSuccess) {
             if (p_override) step(hipMemcpyAsync(mm.p, p_override, (size_t)mm.D * M * M * sizeof(double), hipMemcpyHostToDevice, s));
-            else if (!(flags & MVHDP_SWEEP_REUSE_TREES) && !h->tu.single_stream && !h->tu.single_wave && !db) {
+            else if (h->p_beside && !(flags & MVHDP_SWEEP_REUSE_TREES) && !h->tu.single_stream && !h->tu.single_wave && !db) {
                 if (!h->aux) {
                     int least = 0, greatest = 0;                 // (high priority: the queue pool of the wide classes' streams, mvhdp_plan.h)
                     if (h->side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)

@@ -21,14 +21,11 @@
 // Streams of one sweep: the primary variant on the handle's stream, every wider class on a side stream of its own.  HIP maps the
 // streams of one priority onto at most four hardware queues (GPU_MAX_HW_QUEUES), the null stream's included, and two streams that share
 // a hardware queue run one after the other: the C5 trace of round 4 (profiles/r04_timeline_c5_*.txt) showed the 8-, 4- and 2-round
-// kernels in ONE queue -- 5, 9 and 20 ms in series, the first two at two waves per SIMD with nothing beside them.  So the two widest
-// classes (A, B) are created as HIGH-priority streams -- the runtime keeps a queue pool per priority, and the long entities are the
-// sweep's critical path anyway -- and the other classes get the normal-priority streams C and D: main + C + D + the null stream = four.
-// Measured on C4 (round 3, gpurun_out/r3_m4_*, r3_m5_*): the primary on the handle's stream and the wider classes behind the fork
-// event on side streams is the fastest arrangement (deferred 32.97 ms over sweeps 5-24, segmented 33.9 settled); the widest class on
-// the handle's stream and the primary on a side stream -- so that the long entities are resident first -- loses 1-2 ms per sweep
-// while two classes are populated (34.15 / 34.2: the primary then trickles in behind the wide class's blocks); everything on one
-// stream costs a full kernel boundary per class and segment (32.73 / 35.7).  PlanTuning::widest_on_main / single_stream keep both.
+// kernels in ONE queue -- 5, 9 and 20 ms in series, the first two at two waves per SIMD with nothing beside them.  So the streams are
+// spread over the runtime's two queue pools, four each:
+//   normal priority   the null stream, the handle's stream, side stream C (the 2-round class), the second stream of overlapped segments
+//   high priority     side streams A, B, D (the 16-, 8- and 4-round classes: the long entities are the sweep's critical path anyway)
+//                     and the stream the view weights are drawn on beside the tree rebuild
 enum { PLAN_STREAM_MAIN = 0, PLAN_STREAM_A = 1, PLAN_STREAM_B = 2, PLAN_STREAM_C = 3, PLAN_STREAM_D = 4, PLAN_N_STREAMS = 5 };
 
 // Register counts of the compiled kernels (hipFuncGetAttributes at mvhdp_create; typical values in the CPU tests):
