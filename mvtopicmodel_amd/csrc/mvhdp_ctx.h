@@ -62,11 +62,8 @@ struct mvhdp_ctx {
     int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
     uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
     bool delta16_used = false;               // MvModel::delta16 holds deltas of the last sweep (until the apply pass)
-    bool p_beside = true;                    // the view weights drawn on `aux` beside the tree rebuild
     bool side_priority = true;               // side streams A and B at high priority (a hardware-queue pool of their own)
     hipStream_t side[PLAN_N_STREAMS]{};      // side streams of the wider kernel classes (created on first use; [0] unused: the handle's stream)
-    hipStream_t aux = nullptr;               // the view weights of a sweep, drawn beside its tree rebuild
-    hipEvent_t ev_aux[2]{};
     hipEvent_t ev_fork = nullptr, ev_join[PLAN_N_STREAMS]{};
     std::vector<hipEvent_t> ev_many;         // mvhdp_sweep_many: two events per sweep of the batch
     unsigned long long* d_stats_many = nullptr;   // mvhdp_sweep_many: [n][ST_COUNT]
