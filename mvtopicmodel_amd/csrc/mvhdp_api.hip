@@ -1059,172 +1059,6 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         }
     }
     h->last_need_full = p.need_full;
-    bool use_mirror = false;
-    for (int c = 0; c < MVHDP_N_CLASSES; c++) use_mirror = use_mirror || (p.cls[c].used && p.cls[c].narrow);
-    // the trees (and the mirror) of the sweep-start counts: what segments 0 and 1 sample from
-    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) {
-        step(mvhdp_launch_build_trees(mm, false, p.need_full, X[0]));
-        h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
-    } else if (p.need_full && !h->full_trees) {
-        step(mvhdp_launch_build_trees(mm, h->trees_inference, true, X[0]));
-        h->full_trees = true;
-    }
-    // the two copies of the model
-    MvModel B[2] = {mm, mm};
-    if (p.live) { B[1].dtab = ov.dtab2; B[1].root = ov.root2; if (ov.trees2) B[1].trees = ov.trees2; }
-    int32_t* D3[3] = {mm.delta, ov.delta2, ov.delta3};
-    if (p.seg_apply) {
-        B[1].counts = ov.counts2; B[1].counts16 = ov.counts16_2;
-        step(hipMemcpyAsync(ov.counts2, mm.counts, cbytes, hipMemcpyDeviceToDevice, X[0]));
-        step(hipMemcpyAsync(ov.counts16_2, mm.counts16, (size_t)nrows * mm.K * sizeof(uint16_t), hipMemcpyDeviceToDevice, X[0]));
-        if (!h->delta_clean) step(hipMemsetAsync(mm.delta, 0, cbytes, X[0]));
-        h->delta_clean = false;
-        if (ov.deltas_dirty) { step(hipMemsetAsync(ov.delta2, 0, cbytes, X[0])); step(hipMemsetAsync(ov.delta3, 0, cbytes, X[0])); }
-        ov.deltas_dirty = true;                                    // (cleared by mvhdp_sweep_finish / the batch's read-back when the sweep is seen to have finished)
-    } else if (flags & MVHDP_SWEEP_NO_APPLY) {                     // (live, document shards: the caller wants after - before)
-        step(mvhdp_launch_live_helper(mm, 0, d_stats, X[0])); h->delta_clean = false;
-    }
-    SegCtl ctl[2] = {{h->d_ovf_meta + META_CLASS_COUNTS, h->d_doc_counter, nullptr}, {(unsigned int*)(ov.ctl2 + 8), ov.ctl2, ov.lists2}};
-    step(mvhdp_launch_ctl_reset(d_stats, ST_COUNT, h->d_act_key, (unsigned long long*)h->d_ovf_meta, META_WORDS64, nullptr, nullptr, X[0]));
-    step(hipEventRecord(ev_k0, X[0]));
-    step(hipEventRecord(ov.ev_start, X[0]));
-    step(hipStreamWaitEvent(X[1], ov.ev_start, 0));
-    auto ev_done = [&](int s) { return ov.ev_seg[(size_t)3 * s]; };
-    auto ev_applied = [&](int s) { return ov.ev_seg[(size_t)3 * s + 1]; };
-    auto ev_reset = [&](int s) { return ov.ev_seg[(size_t)3 * s + 2]; };
-    auto share_of = [&](int seg, int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
-
-    for (int seg = 0; seg < nseg && e == hipSuccess && mm.D > 0; seg++) {
-        hipStream_t xs = X[seg & 1];
-        const SegCtl& cs = ctl[seg & 1];
-        MvModel mk;
-        if (p.seg_apply) {
-            // segment s reads the copy updated by A(s-2): copy 0 for segments 0 and 1, then (s-1) mod 2; its deltas go to buffer s mod 3
-            // (A(seg - 2) sits in front of this segment on the same stream)
-            mk = B[seg == 0 ? 0 : (seg - 1) & 1];
-            mk.delta = D3[seg % 3];
-        } else {
-            // live: the counts are one; the trees of segment s are rebuilt, from the live counts, when segment s-1 is nearly through
-            mk = mm;
-            mk.delta = mm.counts;
-            mk.dtab = B[seg & 1].dtab; mk.root = B[seg & 1].root; mk.trees = B[seg & 1].trees;
-            if (seg >= 1 && !(flags & MVHDP_SWEEP_REUSE_TREES)) {
-                step(hipStreamWaitEvent(xs, ev_reset(seg - 1), 0));          // (the head the gate watches has been reset for segment s-1)
-                const int64_t n_prev = share_of(seg - 1, mm.D), H_prev = p.route ? share_of(seg - 1, p.H) : 0;
-                // (three fifths through: the rebuild takes about a millisecond beside the samplers, and the next segment's first blocks
-                // should be waiting when the current segment's queue runs dry)
-                const unsigned long long thr = (unsigned long long)((n_prev - H_prev) * 3 / 5);
-                step(mvhdp_launch_gate(ctl[(seg - 1) & 1].qheads + p.pc, thr, xs));
-                MvModel tm = mm;
-                tm.dtab = mk.dtab; tm.root = mk.root; tm.trees = mk.trees;
-                if (p.live16) step(mvhdp_launch_build_trees_from_mirror(tm, p.need_full, xs));
-                else step(mvhdp_launch_build_trees(tm, false, p.need_full, xs));
-            } else if (seg >= 1) {
-                mk.dtab = mm.dtab; mk.root = mm.root; mk.trees = mm.trees;     // REUSE_TREES: the host's trees, for every segment
-            }
-        }
-        step(mvhdp_launch_ctl_reset(nullptr, 0, nullptr, nullptr, 0, cs.class_counts, cs.qheads, xs));
-        step(hipEventRecord(ev_reset(seg), xs));
-        step(launch_segment_kernels(h, p, mk, sl, seg, xs, cs, d_stats));
-        step(hipEventRecord(ev_done(seg), xs));
-        if (p.seg_apply) {
-            // A(seg), beside the kernels of segment seg + 1: the other copy += deltas of seg - 1 and seg; its trees.  On this segment's
-            // own stream, between K(seg) and K(seg + 2) -- which needs it anyway --, behind A(seg - 1) on the other stream.  (A stream
-            // of its own shared a hardware queue with the side stream of the wider class kernels: the runtime has four.)
-            if (seg >= 1) step(hipStreamWaitEvent(xs, ev_applied(seg - 1), 0));
-            const MvModel& dst = B[(seg + 1) & 1];
-            step(mvhdp_launch_apply2_counts(dst, D3[seg % 3], seg >= 1 ? D3[(seg - 1) % 3] : nullptr, use_mirror, d_stats + ST_NEGATIVE, xs));
-            step(hipEventRecord(ev_applied(seg), xs));
-        }
-    }
-    // everything back onto the handle's stream
-    if (mm.D > 0 && e == hipSuccess) {
-        if (p.seg_apply) {
-            step(hipStreamWaitEvent(X[0], ev_applied(nseg - 1), 0));
-            if (nseg >= 2) step(hipStreamWaitEvent(X[0], ev_done(nseg - 2), 0));
-            // the copy A(nseg-1) did not write lacks the last segment's deltas
-            const MvModel& last = B[(nseg + 1) & 1];
-            step(mvhdp_launch_apply_sparse(last, D3[(nseg - 1) % 3], use_mirror, X[0]));
-            h->have_trees = false;
-            // (both copies equal now; copy 0 = mm is the model, every delta buffer is zero again)
-        } else {
-            step(hipStreamWaitEvent(X[0], ev_done(nseg - 1), 0));
-            if (nseg >= 2) step(hipStreamWaitEvent(X[0], ev_done(nseg - 2), 0));
-        }
-    }
-    if (p.live) {
-        if (p.live16 && mm.D > 0) { step(mvhdp_launch_widen_mirror(mm, X[0])); h->have_trees = false; }
-        if (flags & MVHDP_SWEEP_NO_APPLY) {
-            step(mvhdp_launch_live_helper(mm, 1, d_stats, X[0]));
-            if (!(flags & MVHDP_SWEEP_REUSE_TREES)) h->have_trees = false;
-        } else step(mvhdp_launch_live_helper(mm, 2, d_stats, X[0]));
-        if (!(flags & MVHDP_SWEEP_REUSE_TREES)) h->have_trees = false;     // (the last segments' trees sit in either table set)
-    }
-    step(hipEventRecord(ev_k1, X[0]));
-    if (e != hipSuccess) HIPC(h, e);
-    return MVHDP_OK;
-}
-
-// Everything one sweep puts on the device, in stream order; returns without waiting (except at the segment borders of a live /
-// segmented sweep over a model with inactive topics, where the host performs the activation UPD:263-270).
-// d_stats: [ST_COUNT] counters of THIS sweep; ev_k0/ev_k1: recorded around the sweep kernels.
-static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, uint64_t seed, const double* p_override,
-                         const DebugBufs* db, unsigned long long* d_stats, hipEvent_t ev_k0, hipEvent_t ev_k1, SweepOutcome& oc)
-{
-    if (p.overlap && !db) return enqueue_overlapped(h, p, sweep_idx, seed, p_override, d_stats, ev_k0, ev_k1);
-    MvModel& mm = h->mm;
-    const int M = mm.M;
-    const uint32_t flags = p.flags;
-    const int nseg = p.nseg;
-    hipStream_t s = h->stream;
-    hipError_t e = hipSuccess;
-    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-
-    SweepLaunch sl{};
-    sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
-    sl.flags = flags & 0x7fffu; sl.S_cap = p.S_cap;
-    if (h->tu.single_wave && p.live) sl.flags |= MVHDP_SL_STRICT_LIVE;
-#ifdef MVHDP_PROBE
-    if (const char* f = getenv("MVHDP_ATOMIC_PROBE")) sl.flags |= ((unsigned)atoi(f) & 7u) << 16;     // measurement build only (mvhdp_sweep_fast.hip)
-#endif
-    sl.q_order_stride = 1;
-    sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
-    sl.live16 = p.live16 ? 1 : 0;
-    sl.delta16 = p.delta16 ? 1 : 0;
-    sl.stats = d_stats;
-    sl.act_key = h->d_act_key;
-    sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;
-    if (db) {
-        for (int m = 0; m < M; m++) sl.tok_dbg[m] = db->tok_dbg[m];
-        sl.n_trace = db->n_trace; sl.trace_doc = db->trace_doc; sl.trace_view = db->trace_view; sl.trace_pos = db->trace_pos; sl.trace_out = db->trace_out;
-    }
-    unsigned int* class_counts = h->d_ovf_meta + META_CLASS_COUNTS;
-
-    bool p_beside = false;                                       // the view weights are drawn beside the tree rebuild (neither reads what the other writes)
-    if (M > 1) {
-        if (!mm.p && mm.D > 0) step(hipMalloc(&mm.p, (size_t)mm.D * M * M * sizeof(double)));
-        if (e == hipSuccess) {
-            if (p_override) step(hipMemcpyAsync(mm.p, p_override, (size_t)mm.D * M * M * sizeof(double), hipMemcpyHostToDevice, s));
-            else if (h->p_beside && !(flags & MVHDP_SWEEP_REUSE_TREES) && !h->tu.single_stream && !h->tu.single_wave && !db) {
-                if (!h->aux) {
-                    int least = 0, greatest = 0;                 // (high priority: the queue pool of the wide classes' streams, mvhdp_plan.h)
-                    if (h->side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
-                        step(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, greatest));
-                    else step(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-                    step(hipEventCreateWithFlags(&h->ev_aux[0], hipEventDisableTiming));
-                    step(hipEventCreateWithFlags(&h->ev_aux[1], hipEventDisableTiming));
-                }
-                if (e == hipSuccess) {
-                    step(hipEventRecord(h->ev_aux[0], s));
-                    step(hipStreamWaitEvent(h->aux, h->ev_aux[0], 0));
-                    step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, h->aux));
-                    step(hipEventRecord(h->ev_aux[1], h->aux));
-                    p_beside = true;
-                }
-            } else step(mvhdp_launch_draw_p(mm, sweep_idx, sl.seed_lo, sl.seed_hi, s));
-        }
-    }
-    h->last_need_full = p.need_full;
     auto rebuild_trees = [&]() {
         step(mvhdp_launch_build_trees(mm, false, p.need_full, s));
         h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
