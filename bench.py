@@ -51,10 +51,14 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
     tok_s = tokens_per_launch / avg_kernel_s
     bpt = w["fabric_read_bytes_per_token"] + w["write_bytes_per_token"]
     gbs = tok_s * bpt / 1e9
-    ceil = prof.get("gather_ceiling_GBs") if prof.get("gather_ceiling_workload", workload) == workload else None   # (measured for C4's rows)
+    # the bare gather of THIS workload's rows (mirror row length, typical list size), where it was measured
+    ceil = (prof.get("gather_ceilings_GBs") or {}).get(workload)
+    ceil_src = (prof.get("gather_ceilings_source") or {}).get(workload)
+    if ceil is None and prof.get("gather_ceiling_workload", workload) == workload:
+        ceil, ceil_src = prof.get("gather_ceiling_GBs"), prof.get("gather_ceiling_source")
     physical = {"bytes_per_token": bpt, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                 "gather_ceiling": ceil, "frac_of_gather_ceiling": (gbs / ceil) if ceil else None,
-                "source": w.get("pmc_source"), "gather_ceiling_source": prof.get("gather_ceiling_source")}
+                "source": w.get("pmc_source"), "gather_ceiling_source": ceil_src}
     issue = None
     if "valu_busy_cycles_per_token" in w:
         cap = SIMDS * SIMD_CLOCK_GHZ * 1e9
@@ -426,6 +430,19 @@ def main():
             out["value_in_reference_sweeps"]["segmented"] = [v / eq["segmented"][1], v / eq["segmented"][0]]
         except Exception as e:
             out["segmented"] = {"error": repr(e)}
+        # ... and the deferred sweep once more, at the chain age the two modes above were timed at: `value` is taken over sweeps
+        # W .. W+K-1 from a random start (the driver's window: the slow first dozen sweeps are in it), the modes on an older chain --
+        # a like-for-like ratio needs this line
+        try:
+            dd = time_mode(0, base_idx + 2 * (sec_warm + args.live_steps))
+            v = total_tokens * args.live_steps / dd
+            out["deferred_same_age"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm, "ms_per_step": dd / args.live_steps * 1e3,
+                                        "note": "the deferred mode timed like `live` and `segmented`, after them: the denominator for comparing the modes"}
+            for k in ("live", "segmented"):
+                if "value" in out.get(k, {}):
+                    out[k]["vs_deferred_same_age"] = out[k]["value"] / v
+        except Exception as e:
+            out["deferred_same_age"] = {"error": repr(e)}
     if group is not None:
         group.close()
     if shard is not None:
