@@ -179,9 +179,6 @@ int mvhdp_sweep_kernel_regs(int cls, int flavour);
 int mvhdp_sweep_generic_regs(bool debug);
 
 #define MVHDP_DOC_BATCH 2
-#ifndef MVHDP_DOC_BATCH_BIG
-#define MVHDP_DOC_BATCH_BIG 2          /* entities per pull of the work queue while more than 16 per wave are left (experiment: 4, 8) */
-#endif
 #define MVHDP_HIST_BINS 17
 #define MVHDP_ENT_BINS 8
 #define MVHDP_NSLOTS_UNKNOWN 0xFFFFu

@@ -190,10 +190,9 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 #endif
     // (the last pulls of the queue take one entity at a time: the launch ends within one entity's time of its last pull)
     const long long q_single = q_total - 2LL * gridDim.x * (blockDim.x >> 6);
-    const long long q_big = q_total - 16LL * gridDim.x * (blockDim.x >> 6);       // (far from the end: MVHDP_DOC_BATCH_BIG entities per pull)
     long long q_seen = 0;
     for (;;) {
-      const long long batch = (q_seen >= q_single) ? 1 : (q_seen < q_big ? MVHDP_DOC_BATCH_BIG : MVHDP_DOC_BATCH);
+      const long long batch = (q_seen >= q_single) ? 1 : MVHDP_DOC_BATCH;    // (4 or 8 per pull far from the end: no gain, gpurun_out/r4v)
       long long q0 = 0;
       if (lane == 0) q0 = (long long)atomicAdd(sl.doc_counter, (unsigned long long)batch);
       q0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)q0);
