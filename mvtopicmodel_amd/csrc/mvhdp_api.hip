@@ -48,7 +48,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_FORCE_RMAX")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) h->tu.force_primary = v; }
     if (const char* f = getenv("MVHDP_NARROW")) h->tu.narrow = atoi(f) != 0 ? -1 : 0;
     if (const char* f = getenv("MVHDP_SINGLE_STREAM")) h->tu.single_stream = atoi(f) != 0;
-    if (const char* f = getenv("MVHDP_SIDE_PRIORITY")) h->side_priority = atoi(f);               // 0: none, 1: A, B, D, 2: A and B only      // 0: every side stream at normal priority (diagnostics)
+    if (const char* f = getenv("MVHDP_SIDE_PRIORITY")) h->side_priority = atoi(f);               // 0: none, 1: A, B and D, 2 (default): A and B      // 0: every side stream at normal priority (diagnostics)
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
@@ -775,7 +775,7 @@ static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const
             if (g.stream != PLAN_STREAM_MAIN && p.route && H_seg > 0) {
                 const int si = g.stream;
                 if (!h->side[si]) {
-                    // A, B and D (the classes of 4 and more rounds): high priority = a hardware-queue pool of their own (mvhdp_plan.h)
+                    // A and B (the classes of 8 and 16 rounds): high priority = a hardware-queue pool of their own (mvhdp_plan.h)
                     int least = 0, greatest = 0;
                     if (si != PLAN_STREAM_C && h->side_priority && !(h->side_priority == 2 && si == PLAN_STREAM_D) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
                         step(hipStreamCreateWithPriority(&h->side[si], hipStreamNonBlocking, greatest));

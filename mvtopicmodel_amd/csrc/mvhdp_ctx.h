@@ -62,7 +62,7 @@ struct mvhdp_ctx {
     int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
     uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
     bool delta16_used = false;               // MvModel::delta16 holds deltas of the last sweep (until the apply pass)
-    int side_priority = 1;                   // side streams A and B at high priority (a hardware-queue pool of their own)
+    int side_priority = 2;                   // side streams A and B at high priority (a hardware-queue pool of their own)
     hipStream_t side[PLAN_N_STREAMS]{};      // side streams of the wider kernel classes (created on first use; [0] unused: the handle's stream)
     hipEvent_t ev_fork = nullptr, ev_join[PLAN_N_STREAMS]{};
     std::vector<hipEvent_t> ev_many;         // mvhdp_sweep_many: two events per sweep of the batch

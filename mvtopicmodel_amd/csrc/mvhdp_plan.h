@@ -22,10 +22,13 @@
 // streams of one priority onto at most four hardware queues (GPU_MAX_HW_QUEUES), the null stream's included, and two streams that share
 // a hardware queue run one after the other: the C5 trace of round 4 (profiles/r04_timeline_c5_*.txt) showed the 8-, 4- and 2-round
 // kernels in ONE queue -- 5, 9 and 20 ms in series, the first two at two waves per SIMD with nothing beside them.  So the streams are
-// spread over the runtime's two queue pools, four each:
-//   normal priority   the null stream, the handle's stream, side stream C (the 2-round class), the second stream of overlapped segments
-//   high priority     side streams A, B, D (the 16-, 8- and 4-round classes: the long entities are the sweep's critical path anyway)
-// (measured, gpurun_out/r4t: C5 44.5 -> 42.6 ms over sweeps 5-24, C4 deferred / segmented / live unchanged)
+// spread over the runtime's two queue pools:
+//   normal priority   the null stream, the handle's stream, side streams C and D (the 2- and 4-round classes) -- four; a fifth, the second
+//                     stream of overlapped segments, shares a queue with one of them
+//   high priority     side streams A and B (the 16- and 8-round classes: the long entities are the sweep's critical path anyway)
+// Measured (gpurun_out/r4y, ms over sweeps 5-24): C5 deferred 44.0 -> 42.2, C5 in 8 segments 64.1 -> 58.1; C4 deferred / segmented / live
+// unchanged.  D in the high pool as well (so that no normal stream shares) costs the overlapped segments of C4 1.5 ms a sweep: a busy
+// high-priority queue delays the launches of the small kernels between the segments.
 enum { PLAN_STREAM_MAIN = 0, PLAN_STREAM_A = 1, PLAN_STREAM_B = 2, PLAN_STREAM_C = 3, PLAN_STREAM_D = 4, PLAN_N_STREAMS = 5 };
 
 // Register counts of the compiled kernels (hipFuncGetAttributes at mvhdp_create; typical values in the CPU tests):
