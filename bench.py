@@ -58,7 +58,9 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
         ceil, ceil_src = prof.get("gather_ceiling_GBs"), prof.get("gather_ceiling_source")
     physical = {"bytes_per_token": bpt, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                 "gather_ceiling": ceil, "frac_of_gather_ceiling": (gbs / ceil) if ceil else None,
-                "source": w.get("pmc_source"), "gather_ceiling_source": ceil_src}
+                "source": w.get("pmc_source"), "gather_ceiling_source": ceil_src,
+                # the cross-check: this run's kernel time (roofline.avg_kernel_ms, hipEvents) against the profiled runs' the counters are from
+                "profiled_kernel_ms_per_sweep": w.get("kernel_ms_per_sweep_profiled")}
     issue = None
     if "valu_busy_cycles_per_token" in w:
         cap = SIMDS * SIMD_CLOCK_GHZ * 1e9

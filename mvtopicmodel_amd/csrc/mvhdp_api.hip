@@ -392,9 +392,12 @@ extern "C" int mvhdp_build_counts(mvhdp_handle h)
         // a NO_APPLY sweep's deltas were never applied: z already holds its assignments, so the recount above includes
         // them -- drop the deltas instead of leaving them to be added on top
         HIPC(h, hipMemsetAsync(h->mm.delta, 0, (size_t)counts_len(h) * sizeof(int32_t), h->stream));
-        if (h->delta16_used) HIPC(h, hipMemsetD16Async(h->mm.delta16, (unsigned short)0x8000, (size_t)(h->mm.rowbase[h->mm.M] * h->mm.K), h->stream));
-        h->delta16_used = false;
         h->delta_pending = false; h->delta_clean = true;
+    }
+    if (h->delta16_used) {
+        // 16-bit delta cells of a sweep that never reached its apply pass (it failed: the recount is how a host recovers): back to the bias
+        HIPC(h, hipMemsetD16Async(h->mm.delta16, (unsigned short)0x8000, (size_t)(h->mm.rowbase[h->mm.M] * h->mm.K), h->stream));
+        h->delta16_used = false;
     }
     HIPC(h, hipStreamSynchronize(h->stream));
     h->have_counts = true; h->have_trees = false; h->counts_stale = false;

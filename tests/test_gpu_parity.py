@@ -316,6 +316,29 @@ def test_register_variants_overflow_chain_and_classified_side_streams(force, mod
     s.close()
 
 
+@pytest.mark.parametrize("prio", ["0", "1", "2"])
+def test_side_stream_priorities_never_change_a_result(prio, monkeypatch):
+    """Every kernel class runs on a stream of its own, the widest on high-priority streams (a hardware-queue pool of their own,
+    mvhdp_plan.h; MVHDP_SIDE_PRIORITY: 0 none, 1 the 4-round class too, 2 the default): where a kernel is queued is never what it computes."""
+    monkeypatch.setenv("MVHDP_SIDE_PRIORITY", prio)
+    K, V = 2048, [5000, 300]
+    rng = np.random.RandomState(22)
+    lens0 = np.array([60, 110, 150, 260, 300, 520, 700, 1100, 1500, 9, 0, 33, 64, 128, 256, 512, 1024] + [20] * 40, dtype=np.int64)
+    lens1 = rng.randint(0, 12, len(lens0)).astype(np.int64)
+    off0 = np.concatenate([[0], np.cumsum(lens0)]); off1 = np.concatenate([[0], np.cumsum(lens1)])
+    from mvtopicmodel_amd.synth import Corpus
+    c = Corpus(K, V, [off0, off1], [rng.randint(0, 5000, off0[-1]).astype(np.int32), rng.randint(0, 300, off1[-1]).astype(np.int32)])
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(2)])
+    for it in range(3):
+        ro = o.sweep(it, 32)
+        rs = s.sweep(it, 32)
+        assert rs.tokens == c.total_tokens and rs.changed == ro["stats"]["changed"]
+        assert_same_state(o, s, 2)
+    s.close()
+
+
 @pytest.mark.parametrize("mode", ["serial", "streams"])
 def test_views_longer_than_16_bit_counts_take_the_generic_kernel(mode, monkeypatch):
     """The 8- and 16-round variants count tokens per slot in 16 bits: an entity with a view of more than 65535 tokens
