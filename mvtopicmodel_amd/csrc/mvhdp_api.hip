@@ -1128,10 +1128,6 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         if (e != hipSuccess) break;
         step(launch_segment_kernels(h, p, mk, sl, seg, s, SegCtl{class_counts, h->d_doc_counter, nullptr}, d_stats));
     }
-    if (p.delta16 && (flags & MVHDP_SWEEP_NO_APPLY) && mm.D > 0) {       // the host (a group's exchange) reads ONE delta table
-        step(mvhdp_launch_fold_delta16(mm, s));
-        h->delta16_used = false;
-    }
     if (p.seg_apply && mm.D > 0) {                               // the last segment's deltas (the trees are rebuilt by whoever needs them next)
         step(mvhdp_launch_apply_delta(mm, d_stats, s, p.delta16));
         if (p.delta16) h->delta16_used = false;

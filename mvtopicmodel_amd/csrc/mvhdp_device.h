@@ -138,7 +138,6 @@ hipError_t mvhdp_launch_init_from_trees(const MvModel& mm, uint32_t seed_lo, uin
 hipError_t mvhdp_launch_draw_p(const MvModel& mm, uint32_t sweep_idx, uint32_t seed_lo, uint32_t seed_hi, hipStream_t s);
 hipError_t mvhdp_launch_sweep(const MvModel& mm, const SweepLaunch& sl, int grid_blocks, bool debug, hipStream_t s);
 hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s, bool with_delta16 = false);
-hipError_t mvhdp_launch_fold_delta16(const MvModel& mm, hipStream_t s);       // delta += delta16 - bias, delta16 = bias
 hipError_t mvhdp_launch_delay(int microseconds, hipStream_t s);
 // zeroes the given counter arrays (any may be null) and sets *act_key to "none", in one launch
 hipError_t mvhdp_launch_ctl_reset(unsigned long long* stats, int n_stats, long long* act_key, unsigned long long* meta, int n_meta,

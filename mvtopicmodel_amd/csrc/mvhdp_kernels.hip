@@ -1016,26 +1016,6 @@ hipError_t mvhdp_launch_delay(int microseconds, hipStream_t s)
     return hipGetLastError();
 }
 
-// A sweep that leaves its deltas to the host (MVHDP_SWEEP_NO_APPLY: document shards) hands over ONE table: the 16-bit cells are added to
-// the 32-bit deltas and set back to the bias, in stream order behind the sweep kernels.
-__global__ __launch_bounds__(256) void fold_delta16_kernel(int32_t* __restrict__ delta, uint16_t* __restrict__ delta16, int64_t n16)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        const int v = (int)delta16[i];
-        if (v != 0x8000) { delta[i] += v - 0x8000; delta16[i] = (uint16_t)0x8000; }
-    }
-}
-
-hipError_t mvhdp_launch_fold_delta16(const MvModel& mm, hipStream_t s)
-{
-    const int64_t n16 = mm.rowbase[mm.M] * mm.K;
-    if (n16 <= 0) return hipSuccess;
-    int grid = (int)std::min<int64_t>((n16 + 255) / 256, 8192);
-    hipLaunchKernelGGL(fold_delta16_kernel, dim3(grid), dim3(256), 0, s, mm.delta, mm.delta16, n16);
-    return hipGetLastError();
-}
-
 hipError_t mvhdp_launch_apply_delta(const MvModel& mm, unsigned long long* stats, hipStream_t s, bool with_delta16)
 {
     int64_t n = mm.rowbase[mm.M] * mm.K + (int64_t)mm.M * mm.K;

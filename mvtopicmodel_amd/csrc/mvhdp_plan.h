@@ -481,7 +481,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // NARROW flavour know the row's class; whatever else runs in the sweep writes the 32-bit table as ever, the apply pass adds both.
     // Not while a token may be unassigned: the row's class is taken from its counts, and first visits only add.
     p.delta16 = tu.delta16 != 0 && mirror_ok && !p.live && !p.frozen && !p.overlap && (nseg == 1 || p.seg_apply) && p.only_seg < 0 &&
-                !in.unassigned;        // (NO_APPLY -- document shards -- folds the cells into the 32-bit table behind the sweep kernels: one table for the all-reduce)
+                !(flags & MVHDP_SWEEP_NO_APPLY) && !in.unassigned;                 // (a group of document shards sweeps with NO_APPLY: 32-bit deltas for the all-reduce)
     if (want_live16) {
         bool all_fast = true;
         for (int c = 0; c < MVHDP_N_CLASSES; c++) if (p.cls[c].used && !p.cls[c].fast) all_fast = false;
