@@ -1115,7 +1115,7 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
                 // the updater catches up before the next segment (UPD:197-218) and the trees follow: tokensPerTopic first (every
                 // leaf needs all of it), then ONE pass per row: counts += delta, delta = 0, the row's tree and 16-bit mirror
                 step(mvhdp_launch_apply_nk(mm, d_stats + ST_NEGATIVE, s));
-                step(mvhdp_launch_build_trees_rows(mm, false, p.need_full, 0, mm.rowbase[M], true, d_stats + ST_NEGATIVE, s, p.delta16));
+                step(mvhdp_launch_build_trees_rows(mm, false, p.need_full, 0, mm.rowbase[M], true, d_stats + ST_NEGATIVE, s));
                 h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
             } else if (p.live && !(flags & MVHDP_SWEEP_REUSE_TREES)) {                   // from the live counts
                 if (p.live16) {                                                          // (the light rows' live counts are in the mirror)
@@ -1129,8 +1129,7 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         step(launch_segment_kernels(h, p, mk, sl, seg, s, SegCtl{class_counts, h->d_doc_counter, nullptr}, d_stats));
     }
     if (p.seg_apply && mm.D > 0) {                               // the last segment's deltas (the trees are rebuilt by whoever needs them next)
-        step(mvhdp_launch_apply_delta(mm, d_stats, s, p.delta16));
-        if (p.delta16) h->delta16_used = false;
+        step(mvhdp_launch_apply_delta(mm, d_stats, s));
         h->have_trees = false;
     }
     if (p.live) {

@@ -123,7 +123,7 @@ hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens_
 hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s);
 // the same for the rows [row_begin, row_end) only; apply_first: counts += delta, delta = 0 for those rows before the build
 hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
-                                         bool apply_first, unsigned long long* negatives, hipStream_t s, bool with_delta16 = false);
+                                         bool apply_first, unsigned long long* negatives, hipStream_t s);
 // a segment border of a live16 sweep: the light rows are read from the 16-bit mirror (and written through to the 32-bit table), the heavy ones from the table
 hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s);
 // end of a live16 sweep: counts <- mirror for the light rows

@@ -121,7 +121,7 @@ __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row,
 // from_mirror (a segment border of a live16 sweep, where the light rows' atomics went to the mirror): light rows are READ from the
 // mirror and written through to the 32-bit table; the flags and the mirror stay as they are.
 __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
-                                                         bool apply_first, unsigned long long* negatives, bool from_mirror, bool with_delta16)
+                                                         bool apply_first, unsigned long long* negatives, bool from_mirror)
 {
     extern __shared__ double t[];                  // 2K doubles
     const int K = mm.K, lane = threadIdx.x;
@@ -146,13 +146,8 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
             for (int k = lane; k < K; k += WAVE) {
                 int c = cnt[k];
                 if (apply_first) {
-                    int d = dl[k];
-                    if (d) dl[k] = 0;
-                    if (with_delta16) {                                    // (the segment's deltas of the small rows: 16-bit cells biased by 0x8000)
-                        const int v = (int)mm.delta16[row * K + k];
-                        if (v != 0x8000) { d += v - 0x8000; mm.delta16[row * K + k] = (uint16_t)0x8000; }
-                    }
-                    if (d) { c += d; cnt[k] = c; neg += c < 0; }           // UPD:202-215 logs a negative count; here it is reported
+                    const int d = dl[k];
+                    if (d) { c += d; cnt[k] = c; dl[k] = 0; neg += c < 0; }    // UPD:202-215 logs a negative count; here it is reported
                 }
                 sum += c < 0 ? 70000 : c;                                  // (a negative count is an error reported elsewhere: keep the row out of the mirror)
             }
@@ -195,13 +190,13 @@ hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bo
 }
 
 hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
-                                         bool apply_first, unsigned long long* negatives, hipStream_t s, bool with_delta16)
+                                         bool apply_first, unsigned long long* negatives, hipStream_t s)
 {
     int64_t nrows = row_end - row_begin;
     if (nrows <= 0) return hipSuccess;
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
-                       row_begin, row_end, apply_first, negatives, false, with_delta16 && apply_first);
+                       row_begin, row_end, apply_first, negatives, false);
     return hipGetLastError();
 }
 
@@ -211,7 +206,7 @@ hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_fu
     if (nrows <= 0) return hipSuccess;
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, write_full,
-                       (int64_t)0, nrows, false, (unsigned long long*)nullptr, true, false);
+                       (int64_t)0, nrows, false, (unsigned long long*)nullptr, true);
     return hipGetLastError();
 }
 

@@ -477,10 +477,10 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
         for (int c = 1; c < 5; c++) if (p.cls[c].used && p.cls[c].fast && p.cls[c].walk) p.cls[c].narrow = 1;
     // A live sweep updates n_wk while it samples: the mirror stays usable only if the sweep's own atomics keep it current, which takes
     // every kernel of the sweep in the NARROW (hence walk) flavour -- no generic kernel among them.
-    // The deltas of a deferred sweep that this call applies itself (in one piece, or segment by segment) in 16-bit cells where the row allows it: the kernels of the
+    // The deltas of a plain deferred sweep (one segment, applied by this call) in 16-bit cells where the row allows it: the kernels of the
     // NARROW flavour know the row's class; whatever else runs in the sweep writes the 32-bit table as ever, the apply pass adds both.
     // Not while a token may be unassigned: the row's class is taken from its counts, and first visits only add.
-    p.delta16 = tu.delta16 != 0 && mirror_ok && !p.live && !p.frozen && !p.overlap && (nseg == 1 || p.seg_apply) && p.only_seg < 0 &&
+    p.delta16 = tu.delta16 != 0 && mirror_ok && !p.live && !p.frozen && !p.seg_apply && nseg == 1 && p.only_seg < 0 &&
                 !(flags & MVHDP_SWEEP_NO_APPLY) && !in.unassigned;                 // (a group of document shards sweeps with NO_APPLY: 32-bit deltas for the all-reduce)
     if (want_live16) {
         bool all_fast = true;

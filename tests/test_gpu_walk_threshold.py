@@ -157,13 +157,6 @@ def test_16_bit_delta_cells_with_the_three_row_classes(monkeypatch, force, delta
     from mvtopicmodel_amd.native import SWEEP_NO_APPLY
     o.sweep(5, 33); s.sweep(5, 33, flags=SWEEP_NO_APPLY); s.apply_delta(-1, -1)
     assert_same_state(o, s, c.M)
-    # a segmented sweep folds them in between its segments (the updater's pass fused into the tree rebuild)
-    from mvtopicmodel_amd.native import SWEEP_LIVE_SEGMENTS, SWEEP_SEGMENT_APPLY
-    from tests.test_gpu_segmented import oracle_segmented_sweep
-    so, _ = oracle_segmented_sweep(o, c, 9, 33, 3)
-    st = s.sweep(9, 33, flags=SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(3))
-    assert st.changed == so["changed"]
-    assert_same_state(o, s, c.M)
     # ... and batches (mvhdp_sweep_many) fold the cells in after every sweep of the batch
     for it in (6, 7, 8):
         o.sweep(it, 33)

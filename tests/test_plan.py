@@ -166,14 +166,12 @@ def test_walk_threshold_search_finds_the_minimum_of_a_smooth_cost_curve():
 
 def test_sixteen_bit_delta_cells_are_for_plain_deferred_sweeps():
     """mvhdp_plan_output.delta16: the n_wk deltas of rows that cannot overflow 16 bits go to a table half the size -- when this call
-    applies them itself (in one piece or segment by segment); document shards (NO_APPLY), overlapped segments, live and frozen sweeps keep
-    the 32-bit table."""
+    applies them itself and in one piece; document shards (NO_APPLY), segments, live and frozen sweeps keep the 32-bit table."""
     kw = dict(tok=[80_000_000, 66_000_000, 1_000_000], ent=[550_000, 449_000, 1_000, 0, 0, 0, 0, 0])
     assert probe(**kw).delta16 == 1
     assert probe(flags=SWEEP_NO_APPLY, **kw).delta16 == 0
     assert probe(flags=SWEEP_LIVE, **kw).delta16 == 0
-    assert probe(flags=SWEEP_SEGMENT_APPLY | (8 << 16), **kw).delta16 == 1                # (the updater's pass between two segments folds them in)
-    assert probe(flags=SWEEP_SEGMENT_APPLY | 0x80 | (8 << 16), **kw).delta16 == 0         # overlapped segments: three 32-bit delta buffers in turn
+    assert probe(flags=SWEEP_SEGMENT_APPLY | (8 << 8), **kw).delta16 == 0
     assert probe(flags=SWEEP_FROZEN | SWEEP_REUSE_TREES, trees_current=1, **kw).delta16 == 0
     assert probe(debug=1, **kw).delta16 == 0                                             # the debug flavour does not read the mirror
     assert probe(tuning=dict(narrow=0), **kw).delta16 == 0                               # nor a sweep pinned to the 32-bit rows
