@@ -89,7 +89,11 @@ __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row,
     if (lane == 0) mm.root[row] = t[1];                    // tree[1] by itself: 8 bytes a type, L2-resident (WRK:519 without the walk)
     // the same numbers once more, grouped for the descent (see MvModel::dtab)
     double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
-    for (int x = lane; x < mm.dt_nblk; x += WAVE) {
+    // (written 16 bytes a lane, consecutive lanes consecutive addresses: unit u = pair j of block x -- whole 128-byte lines per store
+    // instead of a quarter of 64 different sectors; round 4: the rebuild is what every segment border of a segmented or live sweep pays)
+    double2* o = (double2*)dt;
+    for (int u = lane; u < mm.dt_nblk * 4; u += WAVE) {
+        const int x = u >> 2, j = u & 3;
         // block x of the row: block 0 is rooted at depth 0, then 2^dep blocks for dep = dt_f, dt_f+3, ... (arithmetic, not the
         // dt_base / dt_depth arrays: a lane-varying index into a kernel-argument array would go through scratch memory)
         int base = 0, dep = 0;
@@ -98,16 +102,15 @@ __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row,
             while (x >= base + (1 << dep)) { base += 1 << dep; dep += 3; }
         }
         const int b = (1 << dep) + (x - base);
-        double v[8];
+        // the block's eight doubles: L[b]; L[2b], L[2b+1]; L[4b .. 4b+3]; tree[1] (block 0 only) -- L[n] = tree[2n], the left-child sum
+        double v2[2];
 #pragma unroll
-        for (int q = 0; q < 7; q++) {
+        for (int h = 0; h < 2; h++) {
+            const int q = 2 * j + h;
             const int node = (q == 0) ? b : (q < 3) ? 2 * b + (q - 1) : 4 * b + (q - 3);
-            v[q] = (node < K) ? t[2 * node] : 0.0;
+            v2[h] = (q == 7) ? ((x == 0) ? t[1] : 0.0) : ((node < K) ? t[2 * node] : 0.0);
         }
-        v[7] = (x == 0) ? t[1] : 0.0;
-        double2* o = (double2*)(dt + (int64_t)x * 8);
-        o[0] = make_double2(v[0], v[1]); o[1] = make_double2(v[2], v[3]);
-        o[2] = make_double2(v[4], v[5]); o[3] = make_double2(v[6], v[7]);
+        o[u] = make_double2(v2[0], v2[1]);
     }
     __syncthreads();
 }
@@ -194,7 +197,7 @@ hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leave
 {
     int64_t nrows = row_end - row_begin;
     if (nrows <= 0) return hipSuccess;
-    int grid = (int)(nrows < 65536 ? nrows : 65536);
+    int grid = (int)(nrows < 65536 ? nrows : 65536);          // (a block per row: a tenth of that many blocks looping over rows is 6 % slower, gpurun_out/r5c)
     hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
                        row_begin, row_end, apply_first, negatives, false);
     return hipGetLastError();
