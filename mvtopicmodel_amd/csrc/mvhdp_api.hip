@@ -53,6 +53,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_FOUR_ROUND_ON_C")) h->tu.four_round_on_c = atoi(f);         // -1 by its token share (default), 0 / 1
     if (const char* f = getenv("MVHDP_DELTA16")) h->tu.delta16 = atoi(f) != 0;                   // 0: every n_wk delta in the 32-bit table (diagnostics)
     if (const char* f = getenv("MVHDP_FORK_DELAY_US")) h->tu.fork_delay_us = std::max(0, std::min(1000, atoi(f)));
     if (const char* f = getenv("MVHDP_FORCE_MODE")) { if (!strcmp(f, "serial")) h->tu.single_stream = 1; }   // "streams" (default): class kernels side by side

@@ -18,7 +18,8 @@
 #include "mvhdp_device.h"
 #include "../../include/mvhdp.h"
 
-// Streams of one sweep: the primary variant on the handle's stream, every wider class on a side stream of its own.  HIP maps the
+// Streams of one sweep: the primary variant on the handle's stream, every wider class that carries weight on a side stream of its own
+// (the 4-round class behind the 2-round one where it is a handful of entities: see stream_of in plan_sweep).  HIP maps the
 // streams of one priority onto at most four hardware queues (GPU_MAX_HW_QUEUES), the null stream's included, and two streams that share
 // a hardware queue run one after the other: the C5 trace of round 4 (profiles/r04_timeline_c5_*.txt) showed the 8-, 4- and 2-round
 // kernels in ONE queue -- 5, 9 and 20 ms in series, the first two at two waves per SIMD with nothing beside them.  So the streams are
@@ -129,6 +130,7 @@ struct PlanTuning {
     double walk_theta[MVHDP_MAXM] = {0};
     double primary_min_share = 0.10;            // the narrowest class holding at least this share of the tokens gets its own (primary) kernel
     int single_stream = 0;                      // 1: every class kernel on the handle's stream, one after another (diagnostics)
+    int four_round_on_c = -1;                   // the 4-round class behind the 2-round one on stream C: -1 where it holds under 3 % of the tokens, 0 never, 1 always
     int delta16 = 1;                            // 1: 16-bit delta cells for the rows that cannot overflow them (plain deferred sweeps); 0: never
     int narrow_wide = 1;                        // 1: deferred sweeps gather from the mirror in the wider variants too (0: the 1-round variant only)
     int fork_delay_us = 0;                      // microseconds the handle's stream is held between the fork event and the primary kernel (0: none)
@@ -425,7 +427,11 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     }
     p.fast = fast;
     p.pc = fast ? pc : 5;
-    const int stream_of[MVHDP_N_CLASSES] = {PLAN_STREAM_C, PLAN_STREAM_C, PLAN_STREAM_D, PLAN_STREAM_B, PLAN_STREAM_A, PLAN_STREAM_A};
+    // the 4-round class: a stream of its own where it carries weight (C5: a tenth of the tokens -- 42.5 against 43.4 ms a sweep, an 8-way
+    // shard 6.85 against 7.9), behind the 2-round class on stream C where it is a handful of entities (C4: 0.7 % of the tokens -- beside
+    // the others its few blocks only get in their way: an 8-way shard 3.66 against 3.85 ms); gpurun_out/r5e
+    const bool four_on_c = tu.four_round_on_c > 0 || (tu.four_round_on_c < 0 && !unknown && tok[2] < 0.03 * tot);
+    const int stream_of[MVHDP_N_CLASSES] = {PLAN_STREAM_C, PLAN_STREAM_C, four_on_c ? PLAN_STREAM_C : PLAN_STREAM_D, PLAN_STREAM_B, PLAN_STREAM_A, PLAN_STREAM_A};
     if (!fast) {
         p.cls[5] = gen; p.cls[5].used = true; p.cls[5].stream = PLAN_STREAM_MAIN;
         for (int c = 0; c < MVHDP_N_CLASSES; c++) p.class_map[c] = 5;
