@@ -840,7 +840,7 @@ static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const
 //     OTHER copy; segment s+2 waits for A(s).  At the end the copy that missed the last segment takes it, and both copies are the
 //     model again.  The F+trees are those of the sweep start for every segment, as the reference's are between two buildFTrees calls
 //     (PTM:1209; its updater refreshes the touched leaves only, UPD:242-260): rebuilding them per segment beside the samplers took a
-//     whole segment's time in the one block slot per CU the samplers leave (profiles/r04_overlap_timelines.md), which put the
+//     whole segment's time in the one block slot per CU the samplers leave (profiles/r04_timeline_c4_oseg8_trees_per_segment.txt), which put the
 //     rebuild back on the critical path.
 //         stream 0:  K(0) A(0) K(2) A(2) K(4) ...          A(s) behind K(s) on its stream and behind A(s-1) on the other one;
 //         stream 1:  K(1) A(1) K(3) A(3) ...               K(s+2) behind A(s): while A(s) runs, stream 1 - s mod 2 is sampling
