@@ -53,7 +53,6 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
-    if (const char* f = getenv("MVHDP_ROOMY_OVERLAP")) h->roomy_overlap = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_FOUR_ROUND_ON_C")) h->tu.four_round_on_c = atoi(f);         // -1 by its token share (default), 0 / 1
     if (const char* f = getenv("MVHDP_DELTA16")) h->tu.delta16 = atoi(f) != 0;                   // 0: every n_wk delta in the 32-bit table (diagnostics)
     if (const char* f = getenv("MVHDP_FORK_DELAY_US")) h->tu.fork_delay_us = std::max(0, std::min(1000, atoi(f)));
@@ -901,7 +900,6 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
     sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
     sl.live16 = p.live16 ? 1 : 0;
     sl.delta16 = p.delta16 ? 1 : 0;
-    sl.roomy = (p.overlap && h->roomy_overlap) ? 1 : 0;
     sl.stats = d_stats;
     sl.act_key = h->d_act_key;
     sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;
@@ -1046,7 +1044,6 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
     sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
     sl.live16 = p.live16 ? 1 : 0;
     sl.delta16 = p.delta16 ? 1 : 0;
-    sl.roomy = (p.overlap && h->roomy_overlap) ? 1 : 0;
     sl.stats = d_stats;
     sl.act_key = h->d_act_key;
     sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;

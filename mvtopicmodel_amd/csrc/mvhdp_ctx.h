@@ -61,7 +61,6 @@ struct mvhdp_ctx {
     unsigned int* d_ovf_meta = nullptr;      // META_*: the next sweep's histograms (tokens by list size, entities by kernel class), per-class list lengths, misroutes
     int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
     uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
-    bool roomy_overlap = true;               // overlapped segments run the 6-wave builds of the 1- and 2-round mirror flavours
     bool delta16_used = false;               // MvModel::delta16 holds deltas of the last sweep (until the apply pass)
     int side_priority = 2;                   // side streams A and B at high priority (a hardware-queue pool of their own)
     hipStream_t side[PLAN_N_STREAMS]{};      // side streams of the wider kernel classes (created on first use; [0] unused: the handle's stream)

@@ -93,7 +93,6 @@ struct SweepLaunch {
     int32_t walk;                      // 1: launch the kernel flavour that knows about thresholds (and counts the per-view statistics)
     int32_t narrow;                    // 1: the flavour that gathers n_wk from the 16-bit mirror
     int32_t delta16;                   // 1 (deferred sweep, narrow flavour): the n_wk deltas of rows without MVHDP_ROW_BIG go to MvModel::delta16
-    int32_t roomy;                     // 1: the 6-wave builds of the 1- and 2-round mirror flavours (two segments in flight: a block per CU is left free anyway)
     int32_t live16;                    // 1 (MVHDP_SWEEP_LIVE with narrow): the sweep's n_wk atomics of LIGHT rows go to the mirror itself, which is then the
                                        //   authoritative copy of those rows until the next tree build / widen pass; heavy rows: the 32-bit table as ever
     unsigned long long* slot_hist;     // [MVHDP_HIST_BINS] tokens of the entities whose NEW topic list has ceil(size/64) = 1..16, >16, then

@@ -52,9 +52,6 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #ifndef MVHDP_LB2_ROOMY
 #define MVHDP_LB2_ROOMY 6
 #endif
-#ifndef MVHDP_LB1_ROOMY
-#define MVHDP_LB1_ROOMY 6      // the 1-round mirror flavour for sweeps with two segments in flight: their grids leave a block per CU free anyway
-#endif
 #ifndef MVHDP_LB4
 #define MVHDP_LB4 4
 #endif
@@ -104,7 +101,7 @@ __device__ __forceinline__ int gather_cell(gptr_t p)
 // of the 72-register build): where a row of the mirror is 1 KiB or more (K >= 512; C5: K = 1000) the seventh wave hides less than the
 // spills cost -- C5's 2-round kernel 16.9 ms at 6 waves, 18.4 at 7; C4's (K = 400) gains 2 % at 7.
 template <int RMAX, bool DEBUG, bool WALK, bool NARROW, bool ROOMY = false>
-__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? (ROOMY ? MVHDP_LB2_ROOMY : MVHDP_LB2) : (RMAX == 1 ? (WALK ? (ROOMY ? MVHDP_LB1_ROOMY : MVHDP_LB1W) : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? (ROOMY ? MVHDP_LB2_ROOMY : MVHDP_LB2) : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef MVHDP_TIMING
@@ -657,7 +654,7 @@ static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow, int K = 0
 {
     if (narrow && walk && !debug) {
         if constexpr (RMAX == 2) { if (roomy_build(RMAX, K)) return (const void*)sweep_fast_kernel<2, false, true, true, true>; }
-        return (const void*)sweep_fast_kernel<RMAX, false, true, true>;      // (SweepLaunch::roomy picks the 6-wave build of the same kernel at launch)
+        return (const void*)sweep_fast_kernel<RMAX, false, true, true>;
     }
     return debug ? (const void*)sweep_fast_kernel<RMAX, true, true, false>
                  : walk ? (const void*)sweep_fast_kernel<RMAX, false, true, false> : (const void*)sweep_fast_kernel<RMAX, false, false, false>;
@@ -674,10 +671,9 @@ static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid
         if (e != hipSuccess) return e;
     }
     if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
-    else if (narrow && (roomy_build(RMAX, mm.K) || (sl.roomy && RMAX <= 2))) {
+    else if (narrow && roomy_build(RMAX, mm.K)) {
         // (the plan sized the grid for the 72-register build: the seventh block of a CU waits for a free slot and finds the queue empty)
         if constexpr (RMAX == 2) hipLaunchKernelGGL((sweep_fast_kernel<2, false, true, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
-        if constexpr (RMAX == 1) hipLaunchKernelGGL((sweep_fast_kernel<1, false, true, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
     }
     else if (narrow)  hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);
     else if (sl.walk) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
