@@ -53,6 +53,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_GATE_PCT")) { const int v = atoi(f); if (v >= 5 && v <= 95) h->gate_pct = v; }   // how far through a live segment the next one is prepared
     if (const char* f = getenv("MVHDP_FOUR_ROUND_ON_C")) h->tu.four_round_on_c = atoi(f);         // -1 by its token share (default), 0 / 1
     if (const char* f = getenv("MVHDP_DELTA16")) h->tu.delta16 = atoi(f) != 0;                   // 0: every n_wk delta in the 32-bit table (diagnostics)
     if (const char* f = getenv("MVHDP_FORK_DELAY_US")) h->tu.fork_delay_us = std::max(0, std::min(1000, atoi(f)));
@@ -966,7 +967,7 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
                 const int64_t n_prev = share_of(seg - 1, mm.D), H_prev = p.route ? share_of(seg - 1, p.H) : 0;
                 // (three fifths through: the rebuild takes about a millisecond beside the samplers, and the next segment's first blocks
                 // should be waiting when the current segment's queue runs dry)
-                const unsigned long long thr = (unsigned long long)((n_prev - H_prev) * 3 / 5);
+                const unsigned long long thr = (unsigned long long)((n_prev - H_prev) * h->gate_pct / 100);
                 step(mvhdp_launch_gate(ctl[(seg - 1) & 1].qheads + p.pc, thr, xs));
                 MvModel tm = mm;
                 tm.dtab = mk.dtab; tm.root = mk.root; tm.trees = mk.trees;

@@ -61,6 +61,7 @@ struct mvhdp_ctx {
     unsigned int* d_ovf_meta = nullptr;      // META_*: the next sweep's histograms (tokens by list size, entities by kernel class), per-class list lengths, misroutes
     int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
     uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
+    int gate_pct = 60;                       // overlapped live segments: the next segment's trees and kernels are enqueued when this share of the current one's queue is taken
     bool delta16_used = false;               // MvModel::delta16 holds deltas of the last sweep (until the apply pass)
     int side_priority = 2;                   // side streams A and B at high priority (a hardware-queue pool of their own)
     hipStream_t side[PLAN_N_STREAMS]{};      // side streams of the wider kernel classes (created on first use; [0] unused: the handle's stream)
