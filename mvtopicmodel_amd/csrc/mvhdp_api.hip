@@ -782,9 +782,12 @@ static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const
                 if (!h->side[si]) {
                     // A and B (the classes of 8 and 16 rounds): high priority = a hardware-queue pool of their own (mvhdp_plan.h)
                     int least = 0, greatest = 0;
-                    if (si != PLAN_STREAM_C && h->side_priority && !(h->side_priority == 2 && si == PLAN_STREAM_D) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
-                        step(hipStreamCreateWithPriority(&h->side[si], hipStreamNonBlocking, greatest));
-                    else step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
+                    bool made = false;
+                    if (si != PLAN_STREAM_C && h->side_priority && !(h->side_priority == 2 && si == PLAN_STREAM_D) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least) {
+                        made = hipStreamCreateWithPriority(&h->side[si], hipStreamNonBlocking, greatest) == hipSuccess;
+                        if (!made) { (void)hipGetLastError(); h->side[si] = nullptr; }      // (a runtime without stream priorities: an ordinary stream then)
+                    }
+                    if (!made) step(hipStreamCreateWithFlags(&h->side[si], hipStreamNonBlocking));
                 }
                 if (!h->ev_join[si]) step(hipEventCreateWithFlags(&h->ev_join[si], hipEventDisableTiming));
                 if (e != hipSuccess) return e;
