@@ -208,3 +208,44 @@ def test_random_shapes_segmented(seed, monkeypatch):
         if inactive is not None:
             assert np.array_equal(s.get_alpha()[0], o.get_alpha()) and np.array_equal(s.get_alpha()[1], o.get_inactive())
     s.close()
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("MVHDP_FUZZ_CASES", "40")) // 10)))
+def test_random_row_classes(seed, monkeypatch):
+    """Types with 15 k ... 100 k tokens in one corpus: the three row classes of build_trees_kernel (16-bit deltas and mirror counts,
+    32-bit deltas and mirror counts, 32-bit everything) in random proportions, under a random walk threshold (the narrow flavour),
+    a random primary variant and, for one sweep in three, as a batch or with the deltas left to the host."""
+    rng = np.random.RandomState(5000 + seed)
+    K = int(rng.choice([8, 24, 64, 130]))
+    V = [int(rng.randint(3, 40)), int(rng.randint(1, 9))]
+    total = int(rng.choice([50_000, 90_000, 130_000]))
+    D = int(rng.randint(40, 400))
+    lens0 = rng.multinomial(total, np.ones(D) / D).astype(np.int64)
+    lens1 = rng.randint(0, 6, D).astype(np.int64)
+    off = [np.concatenate([[0], np.cumsum(l)]) for l in (lens0, lens1)]
+    share = rng.dirichlet(np.full(V[0], float(rng.choice([0.05, 0.3, 1.0]))))          # a few dominant types
+    t0 = rng.choice(V[0], size=off[0][-1], p=share).astype(np.int32)
+    c = Corpus(K, V, off, [t0, rng.randint(0, V[1], off[1][-1]).astype(np.int32)])
+    hy = Hyper.defaults(K, V)
+    hy.gamma[:] = rng.uniform(0.3, 2.0, 2)
+    monkeypatch.setenv("MVHDP_WALK_THETA", "%.2f,%.2f" % tuple(rng.uniform(0.05, 0.9, 2)))
+    force = str(rng.choice(["", "", "1", "2", "4"]))
+    if force:
+        monkeypatch.setenv("MVHDP_FORCE_RMAX", force)
+    monkeypatch.setenv("MVHDP_DELTA16", str(rng.choice(["1", "1", "1", "0"])))
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    from mvtopicmodel_amd.native import SWEEP_NO_APPLY
+    it = 0
+    for step in range(3):
+        kind = int(rng.choice([0, 0, 1, 2]))
+        if kind == 1:                                                   # a batch of two sweeps
+            o.sweep(it, 91 + seed); o.sweep(it + 1, 91 + seed)
+            s.sweep_many(it, 2, 91 + seed); it += 2
+        elif kind == 2:                                                 # deltas left to the host, applied by it
+            o.sweep(it, 91 + seed); s.sweep(it, 91 + seed, flags=SWEEP_NO_APPLY); s.apply_delta(-1, -1); it += 1
+        else:
+            ro = o.sweep(it, 91 + seed); rs = s.sweep(it, 91 + seed); it += 1
+            assert rs.changed == ro["stats"]["changed"] and rs.tokens == c.total_tokens
+        assert_same_state(o, s, c.M)
+    s.close()
