@@ -974,8 +974,8 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
                 step(mvhdp_launch_gate(ctl[(seg - 1) & 1].qheads + p.pc, thr, xs));
                 MvModel tm = mm;
                 tm.dtab = mk.dtab; tm.root = mk.root; tm.trees = mk.trees;
-                if (p.live16) step(mvhdp_launch_build_trees_from_mirror(tm, p.need_full, xs));
-                else step(mvhdp_launch_build_trees(tm, false, p.need_full, xs));
+                if (p.live16) step(mvhdp_launch_build_trees_from_mirror(tm, p.need_full, xs, true));      // (the small-register flavour: beside the samplers)
+                else step(mvhdp_launch_build_trees(tm, false, p.need_full, xs, true));
             } else if (seg >= 1) {
                 mk.dtab = mm.dtab; mk.root = mm.root; mk.trees = mm.trees;     // REUSE_TREES: the host's trees, for every segment
             }

@@ -120,12 +120,12 @@ size_t mvhdp_sweep_wave_bytes(int M, int S_cap);
 
 hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens_per_view, hipStream_t s);
 // write_full = false: only the descent table (what the register-resident kernels read), not the FTree.tree arrays
-hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s);
+hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s, bool beside_samplers = false);
 // the same for the rows [row_begin, row_end) only; apply_first: counts += delta, delta = 0 for those rows before the build
 hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
                                          bool apply_first, unsigned long long* negatives, hipStream_t s);
 // a segment border of a live16 sweep: the light rows are read from the 16-bit mirror (and written through to the 32-bit table), the heavy ones from the table
-hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s);
+hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s, bool beside_samplers = false);
 // end of a live16 sweep: counts <- mirror for the light rows
 hipError_t mvhdp_launch_widen_mirror(const MvModel& mm, hipStream_t s);
 hipError_t mvhdp_launch_apply_nk(const MvModel& mm, unsigned long long* negatives, hipStream_t s);

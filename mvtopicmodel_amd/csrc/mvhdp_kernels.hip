@@ -123,6 +123,11 @@ __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row,
 // LIGHT and its mirror cells are its counts (none can ever reach 65535, however the tokens move between topics).
 // from_mirror (a segment border of a live16 sweep, where the light rows' atomics went to the mirror): light rows are READ from the
 // mirror and written through to the 32-bit table; the flags and the mirror stay as they are.
+// TB: cells a lane holds in flight in each pass (below).  For a rebuild that has the chip to itself 8 where a row is long (K > 512; C5,
+// K = 1000: 1.00 -> 0.73 ms) and 4 below (C4 0.196 -> 0.175 ms, C3 0.102 -> 0.097); 1 -- a quarter of the registers -- for a rebuild beside
+// a resident sweep kernel (overlapped live segments): what counts there is how many of its waves fit into the registers the samplers
+// leave, not how long one of them takes (TB = 8 there: C3 live 5.2 -> 5.8 ms).  gpurun_out/r5l, r5m.
+template <int TB>
 __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
                                                          bool apply_first, unsigned long long* negatives, bool from_mirror)
 {
@@ -143,16 +148,32 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
         uint16_t* c16 = mm.counts16 + row * K;
         const bool light_src = from_mirror && mm.heavy[row] != MVHDP_ROW_HEAVY;
         bool hv = false;
+        // Both passes over the row read in batches of TB cells a lane, every load of a batch issued before the first is used: one wave
+        // works on one row, so a loop that loads, divides and stores cell by cell pays a cache round trip per iteration -- 20 us a row
+        // at K = 400, which is what bounded this kernel (0.19 ms for 60 000 rows with 25 rows in flight per CU; round 4).
         // first pass over the row: the updater's catch-up (apply_first), the row's weight class, the mirror
         if (!from_mirror) {
             long long sum = 0;
-            for (int k = lane; k < K; k += WAVE) {
-                int c = cnt[k];
-                if (apply_first) {
-                    const int d = dl[k];
-                    if (d) { c += d; cnt[k] = c; dl[k] = 0; neg += c < 0; }    // UPD:202-215 logs a negative count; here it is reported
+            for (int k0 = 0; k0 < K; k0 += WAVE * TB) {
+                int cv[TB], dv[TB];
+#pragma unroll
+                for (int u = 0; u < TB; u++) {
+                    const int k = k0 + u * WAVE + lane;
+                    cv[u] = (k < K) ? cnt[k] : 0;
+                    dv[u] = (apply_first && k < K) ? dl[k] : 0;
                 }
-                sum += c < 0 ? 70000 : c;                                  // (a negative count is an error reported elsewhere: keep the row out of the mirror)
+#pragma unroll
+                for (int u = 0; u < TB; u++) {
+                    const int k = k0 + u * WAVE + lane;
+                    if (k < K) {
+                        int c = cv[u];
+                        if (apply_first) {
+                            const int d = dv[u];
+                            if (d) { c += d; cnt[k] = c; dl[k] = 0; neg += c < 0; }    // UPD:202-215 logs a negative count; here it is reported
+                        }
+                        sum += c < 0 ? 70000 : c;                          // (a negative count is an error reported elsewhere: keep the row out of the mirror)
+                    }
+                }
             }
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, WAVE);
@@ -160,23 +181,38 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
             // (between the two: a light row whose deltas of one sweep may pass +-32767 -- they stay in the 32-bit delta table, SweepLaunch::delta16)
             if (lane == 0) mm.heavy[row] = hv ? MVHDP_ROW_HEAVY : (sum > 32767 ? MVHDP_ROW_BIG : 0);
         }
-        for (int k = lane; k < K; k += WAVE) {
-            int c;
-            if (light_src) { c = (int)c16[k]; cnt[k] = c; }                // the mirror is the authority for this row: write it through
-            else {
-                c = cnt[k];
-                if (!from_mirror) c16[k] = hv ? (uint16_t)65535 : (uint16_t)c;
+        for (int k0 = 0; k0 < K; k0 += WAVE * TB) {
+            int cv[TB], nkv[TB];
+            double alv[TB];
+            bool inact[TB];
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int k = k0 + u * WAVE + lane;
+                const bool in = k < K;
+                cv[u] = in ? (light_src ? (int)c16[k] : cnt[k]) : 0;
+                nkv[u] = in ? nk[k] : 0;
+                alv[u] = (in && !inference_leaves) ? al[k] : 0.0;
+                inact[u] = in && !inference_leaves && mm.inactive[k];
             }
-            double leaf;
-            if (inference_leaves) {                                // INF:576: p_wt alone
-                leaf = ((double)c + beta) / ((double)nk[k] + beta_sum);
-            } else if (mm.inactive[k]) {                           // PTM:2670-2671
-                leaf = 0.0;
-            } else {
-                double p_wt = ((double)c + beta) / ((double)nk[k] + beta_sum);   // PTM:2676
-                leaf = gamma * al[k] * p_wt;                        // PTM:2678
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int k = k0 + u * WAVE + lane;
+                if (k < K) {
+                    const int c = cv[u];
+                    if (light_src) cnt[k] = c;                             // the mirror is the authority for this row: write it through
+                    else if (!from_mirror) c16[k] = hv ? (uint16_t)65535 : (uint16_t)c;
+                    double leaf;
+                    if (inference_leaves) {                                // INF:576: p_wt alone
+                        leaf = ((double)c + beta) / ((double)nkv[u] + beta_sum);
+                    } else if (inact[u]) {                                 // PTM:2670-2671
+                        leaf = 0.0;
+                    } else {
+                        double p_wt = ((double)c + beta) / ((double)nkv[u] + beta_sum);   // PTM:2676
+                        leaf = gamma * alv[u] * p_wt;                      // PTM:2678
+                    }
+                    t[K + k] = leaf;
+                }
             }
-            t[K + k] = leaf;
         }
         tree_from_leaves(mm, row, t, lane, write_full);
     }
@@ -187,9 +223,15 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
     }
 }
 
-hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s)
+hipError_t mvhdp_launch_build_trees(const MvModel& mm, bool inference_leaves, bool write_full, hipStream_t s, bool beside_samplers)
 {
-    return mvhdp_launch_build_trees_rows(mm, inference_leaves, write_full, 0, mm.rowbase[mm.M], false, nullptr, s);
+    if (!beside_samplers) return mvhdp_launch_build_trees_rows(mm, inference_leaves, write_full, 0, mm.rowbase[mm.M], false, nullptr, s);
+    const int64_t nrows = mm.rowbase[mm.M];
+    if (nrows <= 0) return hipSuccess;
+    int grid = (int)(nrows < 65536 ? nrows : 65536);
+    hipLaunchKernelGGL(build_trees_kernel<1>, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
+                       (int64_t)0, nrows, false, (unsigned long long*)nullptr, false);
+    return hipGetLastError();
 }
 
 hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
@@ -198,18 +240,29 @@ hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leave
     int64_t nrows = row_end - row_begin;
     if (nrows <= 0) return hipSuccess;
     int grid = (int)(nrows < 65536 ? nrows : 65536);          // (a block per row: a tenth of that many blocks looping over rows is 6 % slower, gpurun_out/r5c)
-    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
-                       row_begin, row_end, apply_first, negatives, false);
+    if (mm.K > 512)
+        hipLaunchKernelGGL(build_trees_kernel<8>, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
+                           row_begin, row_end, apply_first, negatives, false);
+    else
+        hipLaunchKernelGGL(build_trees_kernel<4>, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, inference_leaves, write_full,
+                           row_begin, row_end, apply_first, negatives, false);
     return hipGetLastError();
 }
 
-hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s)
+hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s, bool beside_samplers)
 {
     const int64_t nrows = mm.rowbase[mm.M];
     if (nrows <= 0) return hipSuccess;
     int grid = (int)(nrows < 65536 ? nrows : 65536);
-    hipLaunchKernelGGL(build_trees_kernel, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, write_full,
-                       (int64_t)0, nrows, false, (unsigned long long*)nullptr, true);
+    if (beside_samplers)
+        hipLaunchKernelGGL(build_trees_kernel<1>, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, write_full,
+                           (int64_t)0, nrows, false, (unsigned long long*)nullptr, true);
+    else if (mm.K > 512)
+        hipLaunchKernelGGL(build_trees_kernel<8>, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, write_full,
+                           (int64_t)0, nrows, false, (unsigned long long*)nullptr, true);
+    else
+        hipLaunchKernelGGL(build_trees_kernel<4>, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, write_full,
+                           (int64_t)0, nrows, false, (unsigned long long*)nullptr, true);
     return hipGetLastError();
 }
 
