@@ -574,7 +574,14 @@ static int async_buffers(mvhdp_group_ctx* g)
     for (int l : g->leaders) {
         hipStream_t st; hipEvent_t ev;
         GHIP(g, hipSetDevice(g->members[l]->device));
-        GHIP(g, hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); g->comm.push_back(st);
+        // the collective of the asynchronous exchange runs BESIDE the next sweep: a high-priority stream has a hardware queue outside the
+        // pool the sweep's streams share (mvhdp_plan.h) -- on a normal one it could land in the sweep kernels' queue and wait for them
+        int least = 0, greatest = 0;
+        st = nullptr;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+            hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+        if (!st) GHIP(g, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        g->comm.push_back(st);
         GHIP(g, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); g->ev_xfer.push_back(ev);
     }
     return MVHDP_OK;
