@@ -268,7 +268,7 @@ int mvhdp_get_view_weights(mvhdp_handle h, double* p /*[D][M][M]*/);
 /* ---- tuning: the sweep's own choices, pinned or carried over ----
  * None of these changes a result: they decide which kernel variant visits an entity and when a word tree is walked, never
  * what is sampled.  The library reads the environment ONCE, in mvhdp_create (MVHDP_FORCE_RMAX, MVHDP_NARROW, MVHDP_LIVE16,
- * MVHDP_WALK_THETA, MVHDP_SINGLE_STREAM, MVHDP_PRIMARY_MIN_SHARE, MVHDP_DEBUG: diagnostics); a host uses this block.
+ * MVHDP_WALK_THETA, MVHDP_SINGLE_STREAM, MVHDP_PRIMARY_MIN_SHARE, MVHDP_LIVE_ROWS, MVHDP_DEBUG: diagnostics); a host uses this block.
  * learnt_walk_step / tree_branch_share are what the walk-threshold search has found: read them from one handle
  * (mvhdp_get_tuning) and hand them to another -- a document shard, a resumed chain -- and it does not search again. */
 typedef struct {
@@ -289,7 +289,10 @@ typedef struct {
     int32_t live_overlap;                        /* MVHDP_SWEEP_LIVE with several segments: -1 (default) / 1: the next segment's trees are rebuilt (from the live counts)
                                                     and its kernels launched when the current segment is nearly through, so that no segment border idles the chip;
                                                     0: one segment after the other (the round-3 form) */
-    int32_t reserved2;
+    int32_t live_rows;                           /* MVHDP_SWEEP_LIVE: -1 (default) / 1: the tree branch of a token (WRK:533-535) samples from the word's LIVE count row and
+                                                    tree[1] follows every delta by an atomic -- what the reference's updater achieves by refreshing the two touched leaves
+                                                    per delta (UPD:242-260) -- wherever every kernel of the sweep is register-resident; no stored trees, two segments;
+                                                    0: stored trees rebuilt at every segment border, four segments (the round-4 form) */
 } mvhdp_tuning;
 int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t);
 int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t);

@@ -69,7 +69,7 @@ class TuningC(C.Structure):
                 ("live16", C.c_int32), ("single_wave", C.c_int32),
                 ("walk_theta", C.c_double * MAX_M), ("primary_min_share", C.c_double),
                 ("learnt_walk_step", C.c_int32 * 4), ("tree_branch_share", C.c_double * MAX_M),
-                ("live_overlap", C.c_int32), ("reserved2", C.c_int32)]
+                ("live_overlap", C.c_int32), ("live_rows", C.c_int32)]
 
 
 class GroupInfoC(C.Structure):

@@ -51,8 +51,12 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_SIDE_PRIORITY")) h->side_priority = atoi(f);               // 0: none, 1: A, B and D, 2 (default): A and B      // 0: every side stream at normal priority (diagnostics)
     if (const char* f = getenv("MVHDP_LIVE16")) h->tu.live16 = atoi(f);
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
+    if (const char* f = getenv("MVHDP_LIVE_ROWS")) h->tu.live_rows = atoi(f);                     // 0: stored trees rebuilt at every segment border (the round-4 form of a live sweep)
+    if (const char* f = getenv("MVHDP_LIVE_ROWS_THETA")) h->tu.live_rows_theta = atof(f);
+    if (const char* f = getenv("MVHDP_LIVE_ROWS_SEGMENTS")) h->tu.live_rows_segments = std::max(1, std::min(255, atoi(f)));
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
+    if (const char* f = getenv("MVHDP_LIVE_TREE_EVERY")) h->live_tree_every = std::max(1, atoi(f));   // (diagnostics: a live sweep rebuilds its trees at every n-th segment border only)
     if (const char* f = getenv("MVHDP_GATE_PCT")) { const int v = atoi(f); if (v >= 5 && v <= 95) h->gate_pct = v; }   // how far through a live segment the next one is prepared
     if (const char* f = getenv("MVHDP_FOUR_ROUND_ON_C")) h->tu.four_round_on_c = atoi(f);         // -1 by its token share (default), 0 / 1
     if (const char* f = getenv("MVHDP_DELTA16")) h->tu.delta16 = atoi(f) != 0;                   // 0: every n_wk delta in the 32-bit table (diagnostics)
@@ -125,7 +129,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMalloc(&mm.counts, cbytes));
     CREATE_HIP(hipMalloc(&mm.delta, cbytes));
     CREATE_HIP(hipMemset(mm.counts, 0, cbytes));
-    CREATE_HIP(hipMalloc(&mm.counts16, (size_t)nrows * K * sizeof(uint16_t)));
+    CREATE_HIP(hipMalloc(&mm.counts16, (size_t)nrows * K * sizeof(uint16_t) + 64));   // (+ 64: the 16-byte row loads of the live-rows form may end beyond the last row)
     CREATE_HIP(hipMemset(mm.counts16, 0, (size_t)nrows * K * sizeof(uint16_t)));
     CREATE_HIP(hipMalloc(&mm.delta16, (size_t)(nrows * K + 2) * sizeof(uint16_t)));
     CREATE_HIP(hipMemsetD16(mm.delta16, (unsigned short)0x8000, (size_t)(nrows * K + 2)));       // (the bias: see SweepLaunch::delta16)
@@ -134,6 +138,7 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMemset(mm.delta, 0, cbytes));
     CREATE_HIP(hipMalloc(&mm.trees, (size_t)nrows * 2 * K * sizeof(double)));
     CREATE_HIP(hipMalloc(&mm.root, (size_t)nrows * sizeof(double)));
+    CREATE_HIP(hipMalloc(&mm.coef, (size_t)M * (((K + 7) & ~7) + K + 8) * sizeof(float)));   // coef [M][Kp] (zero-padded rows), then the smoothing running sums [M][K]
     {
         // descent table layout (MvModel::dtab): internal levels nlev, first block dt_f levels, then blocks of three
         const int nlev = (K > 1) ? (32 - __builtin_clz((unsigned)(K - 1))) : 0;
@@ -178,11 +183,14 @@ static void release_device_resources(mvhdp_ctx* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
     for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); fr(h->d_present[m]); }
-    fr(h->mm.counts); fr(h->mm.delta16); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.dtab); fr(h->mm.p);
+    fr(h->mm.counts); fr(h->mm.delta16); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.coef); fr(h->mm.dtab); fr(h->mm.p);
     fr(h->d_alpha); fr(h->d_inactive); fr(h->d_ctl);
     if (h->h_ctl) { hipHostFree(h->h_ctl); h->h_ctl = nullptr; }
     h->d_stats = nullptr; h->d_act_key = nullptr; h->d_doc_counter = nullptr; h->d_ovf_meta = nullptr;
-    fr(h->d_doc_order); fr(h->d_lists); fr(h->d_nslots); fr(h->d_stats_many);
+    fr(h->d_doc_order); fr(h->d_lists); fr(h->d_nslots); fr(h->d_stats_many); fr(h->d_heavy_list); fr(h->d_heavy_ctl);
+    if (h->ev_rf_go) { hipEventDestroy(h->ev_rf_go); h->ev_rf_go = nullptr; }
+    if (h->ev_rf_done) { hipEventDestroy(h->ev_rf_done); h->ev_rf_done = nullptr; }
+    if (h->rf_stream) { hipStreamDestroy(h->rf_stream); h->rf_stream = nullptr; }
     fr(h->ov.counts2); fr(h->ov.counts16_2); fr(h->ov.dtab2); fr(h->ov.root2); fr(h->ov.trees2); fr(h->ov.delta2); fr(h->ov.delta3); fr(h->ov.ctl2); fr(h->ov.lists2);
     for (auto& e : h->ov.ev_seg) if (e) { hipEventDestroy(e); e = nullptr; }
     if (h->ov.ev_start) { hipEventDestroy(h->ov.ev_start); h->ov.ev_start = nullptr; }
@@ -487,9 +495,10 @@ extern "C" int mvhdp_get_tree(mvhdp_handle h, int32_t m, int32_t type, double* t
     CHECK_H(h);
     MvModel& mm = h->mm;
     if (m < 0 || m >= mm.M || type < 0 || type >= mm.V[m] || !tree) FAIL(h, MVHDP_ERR_INVALID_ARG, "get_tree: bad argument");
-    if (!h->have_trees) FAIL(h, MVHDP_ERR_STATE, "get_tree before build_trees");
+    const bool raw = getenv("MVHDP_REFRESH_FULL") != nullptr;        // (diagnostics: whatever FTree.tree holds, e.g. what heavy_refresh_kernel left there)
+    if (!h->have_trees && !raw) FAIL(h, MVHDP_ERR_STATE, "get_tree before build_trees");
     HIPC(h, hipSetDevice(h->device));
-    { int rc2 = ensure_full_trees(h); if (rc2) return rc2; }
+    if (!raw) { int rc2 = ensure_full_trees(h); if (rc2) return rc2; }
     HIPC(h, hipStreamSynchronize(h->stream));
     HIPC(h, hipMemcpy(tree, mm.trees + (mm.rowbase[m] + type) * 2 * mm.K, (size_t)2 * mm.K * sizeof(double), hipMemcpyDeviceToHost));
     return MVHDP_OK;
@@ -1041,12 +1050,15 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
     sl.sweep_idx = sweep_idx; sl.seed_lo = (uint32_t)seed; sl.seed_hi = (uint32_t)(seed >> 32);
     sl.flags = flags & 0x7fffu; sl.S_cap = p.S_cap;
     if (h->tu.single_wave && p.live) sl.flags |= MVHDP_SL_STRICT_LIVE;
+    if (p.live_rows && getenv("MVHDP_NO_ROW_SAMPLE")) sl.flags |= 0x2000u;                    // (measurement only: what the tree branch's row scan costs)
 #ifdef MVHDP_PROBE
     if (const char* f = getenv("MVHDP_ATOMIC_PROBE")) sl.flags |= ((unsigned)atoi(f) & 7u) << 16;     // measurement build only (mvhdp_sweep_fast.hip)
 #endif
     sl.q_order_stride = 1;
     sl.nk_global = p.nk_global; sl.block_shared_bytes = p.block_shared_bytes;
     sl.live16 = p.live16 ? 1 : 0;
+    sl.live_rows = p.live_rows ? 1 : 0;
+    sl.coef_lds = p.coef_lds ? 1 : 0;
     sl.delta16 = p.delta16 ? 1 : 0;
     sl.stats = d_stats;
     sl.act_key = h->d_act_key;
@@ -1067,11 +1079,43 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
         }
     }
     h->last_need_full = p.need_full;
+    // live-rows form on the mirror: the heavy words keep stored trees, and a small kernel beside the samplers keeps those current
+    // (heavy_refresh_kernel); not with one resident wave (mvhdp_tuning.single_wave: the sequential pin has no second kernel)
+    const bool dummy_poll = getenv("MVHDP_DUMMY_POLL") != nullptr;        // (diagnostics: the refresher's waves beside ANY sweep, with nothing to rebuild)
+    const bool refresher = ((p.live_rows && p.live16) || dummy_poll) && !h->tu.single_wave && !getenv("MVHDP_NO_HEAVY_REFRESH");
+    auto live_rows_prepare = [&](bool from_mirror) -> hipError_t {
+        if ((p.live16 || dummy_poll) && !h->d_heavy_list) {
+            hipError_t e1 = hipMalloc(&h->d_heavy_list, (size_t)MVHDP_HEAVY_CAP * sizeof(int32_t));
+            if (e1 == hipSuccess) e1 = hipMalloc(&h->d_heavy_ctl, 2 * sizeof(unsigned int));
+            if (e1 != hipSuccess) return e1;
+        }
+        if (refresher && !h->rf_stream) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest >= least ||
+                hipStreamCreateWithPriority(&h->rf_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+                (void)hipGetLastError(); h->rf_stream = nullptr;
+                hipError_t e1 = hipStreamCreateWithFlags(&h->rf_stream, hipStreamNonBlocking); if (e1 != hipSuccess) return e1;
+            }
+            hipError_t e1 = hipEventCreateWithFlags(&h->ev_rf_go, hipEventDisableTiming);
+            if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&h->ev_rf_done, hipEventDisableTiming);
+            if (e1 != hipSuccess) return e1;
+        }
+        return mvhdp_launch_live_rows_prepare(mm, from_mirror, p.live16, p.live16 ? h->d_heavy_list : nullptr, p.live16 ? h->d_heavy_ctl : nullptr, MVHDP_HEAVY_CAP, s);
+    };
     auto rebuild_trees = [&]() {
         step(mvhdp_launch_build_trees(mm, false, p.need_full, s));
         h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
     };
-    if (!(flags & MVHDP_SWEEP_REUSE_TREES)) rebuild_trees();
+    if (p.live_rows) {
+        // no stored trees: the weight classes and the mirror, the coefficients and tree[1] of every word from the sweep-start counts
+        step(live_rows_prepare(false));
+        h->have_trees = false; h->full_trees = false;
+    } else if (!(flags & MVHDP_SWEEP_REUSE_TREES)) rebuild_trees();
+    if (dummy_poll && !p.live_rows) {
+        if (!h->d_heavy_list) { step(hipMalloc(&h->d_heavy_list, (size_t)MVHDP_HEAVY_CAP * sizeof(int32_t))); step(hipMalloc(&h->d_heavy_ctl, 2 * sizeof(unsigned int))); }
+        if (!h->rf_stream) { step(hipStreamCreateWithFlags(&h->rf_stream, hipStreamNonBlocking)); step(hipEventCreateWithFlags(&h->ev_rf_go, hipEventDisableTiming)); step(hipEventCreateWithFlags(&h->ev_rf_done, hipEventDisableTiming)); }
+        step(hipMemsetAsync(h->d_heavy_ctl, 0, 2 * sizeof(unsigned int), s));
+    }
     else if (p.need_full && !h->full_trees) {
         step(mvhdp_launch_build_trees(mm, h->trees_inference, true, s));
         h->full_trees = true;
@@ -1122,7 +1166,9 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
                 step(mvhdp_launch_apply_nk(mm, d_stats + ST_NEGATIVE, s));
                 step(mvhdp_launch_build_trees_rows(mm, false, p.need_full, 0, mm.rowbase[M], true, d_stats + ST_NEGATIVE, s));
                 h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
-            } else if (p.live && !(flags & MVHDP_SWEEP_REUSE_TREES)) {                   // from the live counts
+            } else if (p.live_rows) {                                                    // tokensPerTopic has landed: new coefficients, exact roots
+                step(live_rows_prepare(p.live16));
+            } else if (p.live && !(flags & MVHDP_SWEEP_REUSE_TREES) && (h->live_tree_every <= 1 || seg % h->live_tree_every == 0)) {   // from the live counts
                 if (p.live16) {                                                          // (the light rows' live counts are in the mirror)
                     step(mvhdp_launch_build_trees_from_mirror(mm, p.need_full, s));
                     h->have_trees = true; h->full_trees = p.need_full; h->trees_inference = false;
@@ -1131,7 +1177,20 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
             step(mvhdp_launch_ctl_reset(nullptr, 0, nullptr, nullptr, 0, class_counts, h->d_doc_counter, s));
         }
         if (e != hipSuccess) break;
+        if (refresher) {
+            // the refresher starts behind the segment's prepare pass and runs beside the samplers; `stop` is set in stream order behind them
+            step(hipEventRecord(h->ev_rf_go, s));
+            step(hipStreamWaitEvent(h->rf_stream, h->ev_rf_go, 0));
+            if (!getenv("MVHDP_REFRESH_NO_KERNEL")) step(mvhdp_launch_heavy_refresh(mm, h->d_heavy_list, h->d_heavy_ctl, MVHDP_HEAVY_CAP, getenv("MVHDP_REFRESH_BLOCKS") ? atoi(getenv("MVHDP_REFRESH_BLOCKS")) : 16, h->rf_stream));
+            step(hipEventRecord(h->ev_rf_done, h->rf_stream));
+        }
         step(launch_segment_kernels(h, p, mk, sl, seg, s, SegCtl{class_counts, h->d_doc_counter, nullptr}, d_stats));
+        if (refresher) {
+            // (whatever failed above, the stop word is written and the refresher waited for: it also ends by itself after two seconds)
+            hipError_t e2 = mvhdp_launch_set_u32(h->d_heavy_ctl + 1, 1u, s);
+            if (e2 == hipSuccess) e2 = hipStreamWaitEvent(s, h->ev_rf_done, 0);
+            step(e2);
+        }
     }
     if (p.seg_apply && mm.D > 0) {                               // the last segment's deltas (the trees are rebuilt by whoever needs them next)
         step(mvhdp_launch_apply_delta(mm, d_stats, s));
@@ -1191,6 +1250,10 @@ static void learn_from_sweep(mvhdp_ctx* h, const SweepPlan& p, const unsigned lo
                     100.0 * hs[ST_T_QUEUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_PROLOGUE] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_VIEW] / hs[ST_T_TOTAL],
                     100.0 * hs[ST_T_CHUNK_HEAD] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_TOKENS] / hs[ST_T_TOTAL], 100.0 * hs[ST_T_CHUNK_END] / hs[ST_T_TOTAL],
                     (double)hs[ST_T_TOTAL] / std::max<double>(1.0, (double)hs[ST_TOKENS]));
+        if (hs[ST_T_ROWS])
+            fprintf(stderr, "[mvhdp] live rows: %.0f cycles per tree-branch token, %.0f of them until the row is there (%.1f%% of the waves' time; %llu such tokens)\n",
+                    (double)hs[ST_T_ROWS] / std::max<double>(1.0, (double)hs[ST_ONDEMAND]), (double)hs[ST_T_ROWS_WAIT] / std::max<double>(1.0, (double)hs[ST_ONDEMAND]),
+                    100.0 * hs[ST_T_ROWS] / hs[ST_T_TOTAL], hs[ST_ONDEMAND]);
         if (hs[ST_N_WAVES])
             fprintf(stderr, "[mvhdp] cycles per token in a wave's first / second / later entities: %.0f / %.0f / %.0f (tokens %llu / %llu / %llu); per wave: block init %.0f cycles, wait + flush at the end %.0f, whole wave %.0f\n",
                     (double)hs[ST_T_ENT0] / std::max<double>(1.0, (double)hs[ST_N_ENT0]), (double)hs[ST_T_ENT1] / std::max<double>(1.0, (double)hs[ST_N_ENT1]),
@@ -1438,7 +1501,7 @@ extern "C" int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t)
     memset(t, 0, sizeof *t);
     t->force_primary = h->tu.force_primary; t->narrow = h->tu.narrow; t->walk_fixed = h->tu.walk_fixed;
     t->single_stream = h->tu.single_stream; t->primary_min_share = h->tu.primary_min_share; t->live16 = h->tu.live16;
-    t->single_wave = h->tu.single_wave; t->live_overlap = h->tu.live_overlap;
+    t->single_wave = h->tu.single_wave; t->live_overlap = h->tu.live_overlap; t->live_rows = h->tu.live_rows;
     for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) { t->walk_theta[m] = h->tu.walk_theta[m]; t->tree_branch_share[m] = h->wt.walk_f[m]; }
     for (int g = 0; g < WALK_GROUPS; g++) t->learnt_walk_step[g] = g == h->wt.walk_cls ? h->wt.walk_i : h->wt.walk_i_by[g];
     t->learnt_walk_step[3] = -1;
@@ -1458,6 +1521,7 @@ extern "C" int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t)
     h->tu.live16 = t->live16 < 0 ? -1 : (t->live16 ? 1 : 0);
     h->tu.single_wave = t->single_wave ? 1 : 0;
     h->tu.live_overlap = t->live_overlap < 0 ? -1 : (t->live_overlap ? 1 : 0);
+    h->tu.live_rows = t->live_rows < 0 ? -1 : (t->live_rows ? 1 : 0);
     h->tu.primary_min_share = t->primary_min_share > 0.0 ? t->primary_min_share : 0.10;
     for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) h->tu.walk_theta[m] = t->walk_theta[m];
     if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) h->wt.restore(t->learnt_walk_step, t->tree_branch_share, h->mm.M);
@@ -1484,7 +1548,7 @@ extern "C" int mvhdp_plan_probe(const mvhdp_plan_input* pi, const mvhdp_tuning* 
     wt.init_defaults(in.K);
     if (t) {
         tu.force_primary = t->force_primary; tu.narrow = t->narrow; tu.walk_fixed = t->walk_fixed; tu.single_stream = t->single_stream;
-        tu.live16 = t->live16; tu.single_wave = t->single_wave ? 1 : 0; tu.live_overlap = t->live_overlap;
+        tu.live16 = t->live16; tu.single_wave = t->single_wave ? 1 : 0; tu.live_overlap = t->live_overlap; tu.live_rows = t->live_rows;
         if (t->primary_min_share > 0) tu.primary_min_share = t->primary_min_share;
         for (int m = 0; m < MVHDP_MAX_MODALITIES; m++) tu.walk_theta[m] = t->walk_theta[m];
         if (t->learnt_walk_step[0] >= 0 || t->learnt_walk_step[1] >= 0 || t->learnt_walk_step[2] >= 0) wt.restore(t->learnt_walk_step, t->tree_branch_share, in.M);

@@ -61,6 +61,11 @@ struct mvhdp_ctx {
     unsigned int* d_ovf_meta = nullptr;      // META_*: the next sweep's histograms (tokens by list size, entities by kernel class), per-class list lengths, misroutes
     int32_t* d_lists = nullptr;              // [MVHDP_N_CLASSES][D] entity lists written by route_kernel
     uint16_t* d_nslots = nullptr;            // [D] MvModel::nslots
+    // live-rows form of a live sweep on the mirror: the heavy rows (listed by the segment's prepare pass) and the kernel that keeps their
+    // stored trees current beside the samplers (mvhdp_kernels.hip heavy_refresh_kernel)
+    int32_t* d_heavy_list = nullptr; unsigned int* d_heavy_ctl = nullptr;     // [HEAVY_CAP] rows; [0] rows listed, [1] stop
+    hipStream_t rf_stream = nullptr; hipEvent_t ev_rf_go = nullptr, ev_rf_done = nullptr;
+    int live_tree_every = 1;                 // diagnostics (MVHDP_LIVE_TREE_EVERY): tree rebuilds of a live sweep at every n-th segment border only
     int gate_pct = 60;                       // overlapped live segments: the next segment's trees and kernels are enqueued when this share of the current one's queue is taken
     bool delta16_used = false;               // MvModel::delta16 holds deltas of the last sweep (until the apply pass)
     int side_priority = 2;                   // side streams A and B at high priority (a hardware-queue pool of their own)
@@ -108,6 +113,7 @@ bool mvhdp_is_live(mvhdp_ctx* h);
     (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MVHDP_ERR_HIP; } } while (0)
 #define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
 
+enum { MVHDP_HEAVY_CAP = 8192 };             // heavy rows a live sweep keeps trees for (each holds 65535 tokens or more: beyond any corpus that fits a GPU)
 enum { MVHDP_TAIL_WORDS = 4 };               // int32 words allocated behind counts_len() in the counts and delta buffers ([0]: a group's status word)
 static int64_t counts_len(const mvhdp_ctx* h) { return h->mm.rowbase[h->mm.M] * h->mm.K + (int64_t)h->mm.M * h->mm.K; }
 

@@ -41,6 +41,13 @@ struct MvModel {
     int32_t* delta;
     double* trees;                     // [sumV][2K]  FTree.tree (FT:21)
     double* root;                      // [sumV]      tree[1]
+    // MVHDP_SWEEP_LIVE in its "live rows" form (SweepLaunch::live_rows): the tree branch of a token (WRK:533-535) samples from the word's
+    // LIVE count row instead of a stored tree -- leaf_k = coef[m][k] * (n_wk + beta_m), coef[m][k] = (float)(gamma_m alpha_mk / (n_k + betaSum_m)),
+    // 0 for an inactive topic (PTM:2670-2678 with the segment-start tokensPerTopic) -- and `root` above holds sum_k leaf_k per type, built
+    // at the segment start and kept current by one fp64 atomic per FastQDelta (coef[new] - coef[old]): what UPD:242-260 does to the
+    // two touched leaves and the root path, without a tree.
+    float* coef;                       // [M][Kp] (Kp = K rounded up to a multiple of 8, the pad zero), then [M][K] the running sums over k of
+                                       //   coef[m][k] * beta_m (the smoothing part of every leaf of the view)
     // Descent table: what FTree.sample (FT:118-132) reads -- tree[1] and the left-child sums tree[2i] of the
     // internal nodes i -- regrouped so that three consecutive levels of one path share a 64-byte block
     // (8 doubles: L[b]; L[2b], L[2b+1]; L[4b..4b+3]; spare, = tree[1] in block 0; L[i] = tree[2i]).
@@ -95,6 +102,10 @@ struct SweepLaunch {
     int32_t delta16;                   // 1 (deferred sweep, narrow flavour): the n_wk deltas of rows without MVHDP_ROW_BIG go to MvModel::delta16
     int32_t live16;                    // 1 (MVHDP_SWEEP_LIVE with narrow): the sweep's n_wk atomics of LIGHT rows go to the mirror itself, which is then the
                                        //   authoritative copy of those rows until the next tree build / widen pass; heavy rows: the 32-bit table as ever
+    int32_t live_rows;                 // 1 (MVHDP_SWEEP_LIVE): the tree branch samples from the live n_wk row (MvModel::coef); tree[1] = MvModel::root of the
+                                       //   segment start; only heavy words (their rows are not in the mirror) walk a stored tree; walk_theta[m] is also
+                                       //   the u1 from which a token's row is loaded ahead of its turn
+    int32_t coef_lds;                  // 1: the block keeps MvModel::coef in LDS (block_shared_bytes holds room for it)
     unsigned long long* slot_hist;     // [MVHDP_HIST_BINS] tokens of the entities whose NEW topic list has ceil(size/64) = 1..16, >16, then
                                        // [MVHDP_ENT_BINS] entities per kernel class 0..5 of that new list ([6]: not known, [7]: spare) --
                                        // what the next sweep's plan is made from
@@ -112,7 +123,7 @@ enum {
     ST_VIEW_BASE, ST_VIEW_LAST = ST_VIEW_BASE + MVHDP_VIEW_STATS * MVHDP_MAXM - 1,
     // wave cycles by segment, summed over waves; filled only by a -DMVHDP_TIMING build (diagnostics)
     ST_T_QUEUE, ST_T_PROLOGUE, ST_T_VIEW, ST_T_CHUNK_HEAD, ST_T_TOKENS, ST_T_CHUNK_END, ST_T_TOTAL,
-    ST_T_ENT0, ST_T_ENT1, ST_T_ENT2, ST_N_ENT0, ST_N_ENT1, ST_N_ENT2, ST_T_INIT, ST_T_FLUSH, ST_N_WAVES,   // (timing build: a wave's first, second, later entities; block init and flush)
+    ST_T_ENT0, ST_T_ENT1, ST_T_ENT2, ST_N_ENT0, ST_N_ENT1, ST_N_ENT2, ST_T_INIT, ST_T_FLUSH, ST_N_WAVES, ST_T_ROWS, ST_T_ROWS_WAIT,   // (timing build: a wave's first, second, later entities; block init and flush)
     ST_COUNT
 };
 
@@ -128,6 +139,14 @@ hipError_t mvhdp_launch_build_trees_rows(const MvModel& mm, bool inference_leave
 hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_full, hipStream_t s, bool beside_samplers = false);
 // end of a live16 sweep: counts <- mirror for the light rows
 hipError_t mvhdp_launch_widen_mirror(const MvModel& mm, hipStream_t s);
+// a segment start of a live sweep in its live-rows form: MvModel::coef from the current tokensPerTopic, then per row the weight class and
+// 16-bit mirror (sweep start: from the 32-bit table; from_mirror: a later segment of a live16 sweep, light rows read from the mirror) and
+// MvModel::root = sum_k coef_k (n_wk + beta) -- no tree, no descent table: one pass over the counts; then the stored trees of the HEAVY
+// rows alone (with_heavy_trees: a sweep on the mirror, whose heavy words walk them)
+hipError_t mvhdp_launch_live_rows_prepare(const MvModel& mm, bool from_mirror, bool with_heavy_trees, int32_t* heavy_list, unsigned int* heavy_ctl, int heavy_cap, hipStream_t s);
+// the stored trees of the listed heavy rows rebuilt from the live counts again and again until ctl[1] (stop) is set or 2 s have passed
+hipError_t mvhdp_launch_heavy_refresh(const MvModel& mm, const int32_t* heavy_list, const unsigned int* ctl, int heavy_cap, int blocks, hipStream_t s);
+hipError_t mvhdp_launch_set_u32(unsigned int* p, unsigned int v, hipStream_t s);
 hipError_t mvhdp_launch_apply_nk(const MvModel& mm, unsigned long long* negatives, hipStream_t s);
 // overlapped segments: dst (counts / mirror / descent tables of the copy segment s + 2 reads) += dA (+ dB, zeroed), trees rebuilt; see the kernel
 hipError_t mvhdp_launch_apply2(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, bool write_full, unsigned long long* negatives, int max_blocks, hipStream_t s);

@@ -103,6 +103,8 @@ struct DeviceGuard {
 
 }  // namespace
 
+enum { XSCRATCH_BYTES = 1 << 20 };            // device scratch of the cross-rank statistics (one process per GPU)
+
 struct mvhdp_group_ctx {
     std::vector<mvhdp_ctx*> members;          // local members, in the caller's order
     std::vector<int> leader_of;               // per member: index of the first member on the same device (its delta buffer takes the device's sum)
@@ -126,6 +128,7 @@ struct mvhdp_group_ctx {
     bool async_pending = false;               // an exchange is in flight: the replicas lack each other's last sweep
     bool abort_raised = false;                // mvhdp_group_abort: the next sweep of this rank contributes nothing and fails on every rank
     std::vector<int> by_entity;               // member indices by ascending doc_id_base: the order of the "in entity order" statistics
+    void* d_scratch = nullptr;                // one process per GPU: device buffer of the cross-rank statistics (allocated with the group: no allocation stands between a rank and a collective)
     std::string err;
 };
 
@@ -228,6 +231,7 @@ static void group_release(mvhdp_group_ctx* g)
     for (hipStream_t st : g->comm) if (st) hipStreamDestroy(st);
     for (hipEvent_t ev : g->ev_xfer) if (ev) hipEventDestroy(ev);
     g->xbuf.clear(); g->sbuf.clear(); g->comm.clear(); g->ev_xfer.clear();
+    if (g->d_scratch) hipFree(g->d_scratch);
     if (g->ev_x0) hipEventDestroy(g->ev_x0);
     if (g->ev_x1) hipEventDestroy(g->ev_x1);
 }
@@ -294,6 +298,9 @@ extern "C" int mvhdp_group_create_rank(mvhdp_handle member, const uint8_t* id, i
     rc = group_common_init(g, 1, &member);
     if (rc) { g_group_create_error = g->err; group_release(g); delete g; return rc; }
     g->nranks = nranks; g->rank0 = rank; g->multi_process = true;
+    if (hipSetDevice(member->device) != hipSuccess || hipMalloc(&g->d_scratch, XSCRATCH_BYTES) != hipSuccess) {
+        g_group_create_error = "group_create_rank: the scratch buffer of the cross-rank statistics could not be allocated"; group_release(g); delete g; return MVHDP_ERR_HIP;
+    }
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     g->comms.assign(1, nullptr);
@@ -349,60 +356,74 @@ extern "C" int mvhdp_group_set_exchange_chunks(mvhdp_group g, int32_t chunks)
 // ---- the exchange: buffer `which` of every member becomes the sum over ALL members of all ranks ----
 // Stream order throughout, no host wait: co-located members are added into their device's leader, the leaders all-reduce the
 // element range [e0, e1) (RCCL, in place, on the leader's stream), and ev_reduced[l] marks the range complete on leader l.
+// None of the three returns before it has issued everything it was asked to issue: a local HIP failure is remembered (first error
+// wins, g->err says what) and the calls go on -- a rank that stops half way through an exchange leaves its peers inside a collective.
+struct XErr {
+    mvhdp_group_ctx* g;
+    int rc = MVHDP_OK;
+    void hip(hipError_t e, const char* what) { if (e != hipSuccess && rc == MVHDP_OK) { rc = MVHDP_ERR_HIP; g->err = std::string(what) + ": " + hipGetErrorString(e); } }
+    void nccl(ncclResult_t r, const char* what) { if (r != ncclSuccess && rc == MVHDP_OK) { rc = MVHDP_ERR_HIP; g->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"); } }
+};
+
 static int reduce_local(mvhdp_group_ctx* g, bool counts)
 {
     // members that share a device: delta_leader += delta_member, in stream order behind both sweeps
+    XErr x{g};
     const int n = (int)g->members.size();
     for (int i = 0; i < n; i++) {
         const int li = g->leader_of[i];
         if (li == i) continue;
         mvhdp_ctx *h = g->members[i], *L = g->members[li];
-        GHIP(g, hipSetDevice(L->device));
-        GHIP(g, hipStreamWaitEvent(L->stream, g->ev_swept[i], 0));
-        GHIP(g, launch_add_into(counts ? L->mm.counts : L->mm.delta, counts ? h->mm.counts : h->mm.delta, counts_len_of(L), L->stream));
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
+        x.hip(hipStreamWaitEvent(L->stream, g->ev_swept[i], 0), "hipStreamWaitEvent");
+        x.hip(launch_add_into(counts ? L->mm.counts : L->mm.delta, counts ? h->mm.counts : h->mm.delta, counts_len_of(L), L->stream), "add_into_kernel");
     }
-    return MVHDP_OK;
+    return x.rc;
 }
 
 static int allreduce_range(mvhdp_group_ctx* g, bool counts, int64_t e0, int64_t e1)
 {
     if (e1 <= e0 || g->comms.empty()) return MVHDP_OK;
     Rccl* r = &g_rccl;
-    if (g->comms.size() > 1) GNCCL(g, r->GroupStart());
+    XErr x{g};
+    if (g->comms.size() > 1) x.nccl(r->GroupStart(), "ncclGroupStart");
     for (size_t l = 0; l < g->leaders.size(); l++) {
         mvhdp_ctx* L = g->members[g->leaders[l]];
-        GHIP(g, hipSetDevice(L->device));
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
         int32_t* buf = (counts ? L->mm.counts : L->mm.delta) + e0;
-        GNCCL(g, r->AllReduce(buf, buf, (size_t)(e1 - e0), ncclInt32, ncclSum, g->comms[l], L->stream));
+        x.nccl(r->AllReduce(buf, buf, (size_t)(e1 - e0), ncclInt32, ncclSum, g->comms[l], L->stream), "ncclAllReduce");
     }
-    if (g->comms.size() > 1) GNCCL(g, r->GroupEnd());
-    return MVHDP_OK;
+    if (g->comms.size() > 1) x.nccl(r->GroupEnd(), "ncclGroupEnd");
+    return x.rc;
 }
 
 // the co-located members of a device take the reduced range from their leader
 static int fan_out_range(mvhdp_group_ctx* g, bool counts, int64_t e0, int64_t e1)
 {
     if (e1 <= e0 || g->members.size() == g->leaders.size()) return MVHDP_OK;
+    XErr x{g};
     for (size_t l = 0; l < g->leaders.size(); l++) {
         mvhdp_ctx* L = g->members[g->leaders[l]];
-        GHIP(g, hipSetDevice(L->device));
-        GHIP(g, hipEventRecord(g->ev_reduced[l], L->stream));
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
+        x.hip(hipEventRecord(g->ev_reduced[l], L->stream), "hipEventRecord");
         for (size_t i = 0; i < g->members.size(); i++) {
             if (g->leader_of[i] != g->leaders[l] || (int)i == g->leaders[l]) continue;
             mvhdp_ctx* h = g->members[i];
-            GHIP(g, hipStreamWaitEvent(h->stream, g->ev_reduced[l], 0));
+            x.hip(hipStreamWaitEvent(h->stream, g->ev_reduced[l], 0), "hipStreamWaitEvent");
             const int32_t* src = (counts ? L->mm.counts : L->mm.delta) + e0;
             int32_t* dst = (counts ? h->mm.counts : h->mm.delta) + e0;
-            GHIP(g, hipMemcpyAsync(dst, src, (size_t)(e1 - e0) * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+            x.hip(hipMemcpyAsync(dst, src, (size_t)(e1 - e0) * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream), "hipMemcpyAsync");
             // the leader's own update of this range zeroes its delta rows: not before this copy has read them
-            GHIP(g, hipEventRecord(g->ev_swept[i], h->stream));
-            GHIP(g, hipStreamWaitEvent(L->stream, g->ev_swept[i], 0));
+            x.hip(hipEventRecord(g->ev_swept[i], h->stream), "hipEventRecord");
+            x.hip(hipStreamWaitEvent(L->stream, g->ev_swept[i], 0), "hipStreamWaitEvent");
         }
     }
-    return MVHDP_OK;
+    return x.rc;
 }
 
 // buildInitialTypeTopicCounts PTM:600-652 over every shard: local counts, then the sum over all members of all ranks.
+// Collective; the failure protocol of group_step below: a rank whose recount failed contributes zeros and a 1 in the status word behind
+// the tokensPerTopic part, every rank enters the same all-reduce and all return an error from this call.
 extern "C" int mvhdp_group_build_counts(mvhdp_group g)
 {
     CHECK_G(g);
@@ -412,17 +433,45 @@ extern "C" int mvhdp_group_build_counts(mvhdp_group g)
         g->async_pending = false;
     }
     const int n = (int)g->members.size();
-    for (int i = 0; i < n; i++) GMEM(g, i, mvhdp_build_counts(g->members[i]));
-    for (int i = 0; i < n; i++) { GHIP(g, hipSetDevice(g->members[i]->device)); GHIP(g, hipEventRecord(g->ev_swept[i], g->members[i]->stream)); }
-    int rc = reduce_local(g, true); if (rc) return rc;
     const int64_t len = counts_len_of(g->members[0]);
-    rc = allreduce_range(g, true, 0, len); if (rc) return rc;
-    rc = fan_out_range(g, true, 0, len); if (rc) return rc;
+    int local_err = MVHDP_OK;
+    auto note = [&](int rc, const std::string& what) { if (rc != MVHDP_OK && local_err == MVHDP_OK) { local_err = rc; g->err = what; } };
+    XErr x{g};
     for (int i = 0; i < n; i++) {
-        GHIP(g, hipSetDevice(g->members[i]->device));
-        GHIP(g, hipStreamSynchronize(g->members[i]->stream));
-        GMEM(g, i, mvhdp_counts_written(g->members[i]));
+        mvhdp_ctx* h = g->members[i];
+        const int rc = mvhdp_build_counts(h);
+        if (rc != MVHDP_OK) note(rc, "member " + std::to_string(i) + ": " + h->err);
+        // a stale delta buffer (a failed exchange left the peers' sums in it) must not survive the recount
+        if (!h->delta_clean) { x.hip(hipSetDevice(h->device), "hipSetDevice"); x.hip(hipMemsetAsync(h->mm.delta, 0, (size_t)(len + MVHDP_TAIL_WORDS) * sizeof(int32_t), h->stream), "hipMemsetAsync"); h->delta_clean = true; h->delta_pending = false; }
     }
+    if (local_err != MVHDP_OK)
+        for (int i = 0; i < n; i++) { mvhdp_ctx* h = g->members[i]; x.hip(hipSetDevice(h->device), "hipSetDevice"); x.hip(hipMemsetAsync(h->mm.counts, 0, (size_t)len * sizeof(int32_t), h->stream), "hipMemsetAsync"); }
+    for (int i = 0; i < n; i++) { x.hip(hipSetDevice(g->members[i]->device), "hipSetDevice"); x.hip(hipEventRecord(g->ev_swept[i], g->members[i]->stream), "hipEventRecord"); }
+    note(reduce_local(g, true), g->err);
+    note(x.rc, g->err);
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        mvhdp_ctx* L = g->members[g->leaders[l]];
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, L->stream, L->mm.counts + len, local_err != MVHDP_OK ? 1 : 0);
+    }
+    note(allreduce_range(g, true, 0, len + 1), g->err);
+    note(fan_out_range(g, true, 0, len + 1), g->err);
+    int32_t failed_ranks = 0;
+    mvhdp_ctx* L0 = g->members[g->leaders[0]];
+    x.hip(hipSetDevice(L0->device), "hipSetDevice");
+    x.hip(hipMemcpyAsync(&failed_ranks, L0->mm.counts + len, sizeof failed_ranks, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
+    for (int i = 0; i < n; i++) {
+        x.hip(hipSetDevice(g->members[i]->device), "hipSetDevice");
+        x.hip(hipStreamSynchronize(g->members[i]->stream), "hipStreamSynchronize");
+    }
+    note(x.rc, g->err);
+    if (local_err == MVHDP_OK && failed_ranks == 0)
+        for (int i = 0; i < n; i++) { const int rc = mvhdp_counts_written(g->members[i]); if (rc != MVHDP_OK) note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err); }
+    else
+        for (int i = 0; i < n; i++) { g->members[i]->counts_stale = true; g->members[i]->have_trees = false; }
+    if (local_err != MVHDP_OK) return local_err;
+    if (failed_ranks != 0)
+        GFAIL(g, MVHDP_ERR_STATE, "the recount failed on " + std::to_string(failed_ranks) + " other rank(s) of the group (or the collective broke): the counts are not valid");
     return MVHDP_OK;
 }
 
@@ -431,10 +480,14 @@ extern "C" int mvhdp_group_build_counts(mvhdp_group g)
 //
 // Failure protocol (one process per GPU: a rank must never leave the others inside a collective).  Whatever happens locally, every
 // rank enters the SAME collectives -- their number depends only on replicated facts: the chunk count, the segment count taken from the
-// flags, whether the hyper-parameters hold inactive topics.  A rank whose sweep failed (or whose host called mvhdp_group_abort)
-// contributes zero deltas and a 1 in the status word behind the tokensPerTopic part, which is summed with that part: every rank reads
-// the sum at the end of the step and all return an error together.  After such an error the replicas agree with each other but not
-// with the failed rank's assignments: mvhdp_group_build_counts (a recount from z, collective) makes the model consistent again.
+// flags, whether the hyper-parameters hold inactive topics -- and none of the calls in between returns early (XErr).  A rank whose sweep
+// or local sum failed (or whose host called mvhdp_group_abort) contributes zero deltas and a 1 in the status word behind the
+// tokensPerTopic part, which is summed with that part: every rank reads the sum at the end of the step and all return an error together.
+// After such an error the replicas agree with each other but not with the failed rank's assignments: mvhdp_group_build_counts (a recount
+// from z, collective) makes the model consistent again.  A rank that fails LATER in the step (a HIP call of its own exchange) returns
+// its error alone, having entered every collective: its host raises mvhdp_group_abort and calls the next sweep, which then fails on
+// every rank together.  Whoever does not apply the sum leaves a delta buffer that is marked dirty: the next sweep (or the recount)
+// clears it before anything is added to it again.
 static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, std::vector<mvhdp_sweep_stats>& st)
 {
     const int n = (int)g->members.size();
@@ -456,42 +509,55 @@ static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uin
         const int rc = mvhdp_sweep_finish(g->members[i], ps[i], &st[i]);
         if (rc != MVHDP_OK) note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err);
     }
-    hipError_t he = hipSuccess;
-    auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && he == hipSuccess) { he = e; note(MVHDP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); } };
+    XErr x{g};
     const MvModel& mm = g->members[0]->mm;
     const int64_t rows = mm.rowbase[mm.M], K = mm.K, nk_off = rows * K, len = counts_len_of(g->members[0]);
-    if (local_err != MVHDP_OK) {
+    auto drop_local = [&]() {
         // nothing of this process enters the sum; its members' assignments may have moved without their counts: a recount is due
         for (int i = 0; i < n; i++) {
             mvhdp_ctx* h = g->members[i];
             hipSetDevice(h->device);
             hipMemsetAsync(h->mm.delta, 0, (size_t)len * sizeof(int32_t), h->stream);
-            h->delta_pending = false; h->delta_clean = true; h->counts_stale = true; h->have_trees = false; h->rows_applied = -1;
+            h->delta_pending = false; h->counts_stale = true; h->have_trees = false; h->rows_applied = -1;
         }
-    }
+    };
+    if (local_err != MVHDP_OK) drop_local();
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = g->members[i];
-        hip(hipSetDevice(h->device), "hipSetDevice");
-        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, h->stream, h->mm.delta + len, (g->leader_of[i] == i && local_err != MVHDP_OK) ? 1 : 0);
-        hip(hipEventRecord(g->ev_swept[i], h->stream), "hipEventRecord");
+        x.hip(hipSetDevice(h->device), "hipSetDevice");
+        x.hip(hipEventRecord(g->ev_swept[i], h->stream), "hipEventRecord");
     }
     // 2. the exchange, as a pipeline in stream order: the tokensPerTopic part (and the status word) first -- every tree needs all of
     //    it --, then the n_wk rows in `chunks` ranges: while range i+1 is on the wire, range i is applied and its F+trees rebuilt
     //    (mvhdp_apply_delta_rows).  The collectives are issued whatever the local status; what touches a member's model is not.
     mvhdp_ctx* L0 = g->members[g->leaders[0]];
-    hip(hipSetDevice(L0->device), "hipSetDevice");
-    hip(hipEventRecord(g->ev_x0, L0->stream), "hipEventRecord");
-    int xrc = reduce_local(g, false);
-    if (xrc == MVHDP_OK) xrc = allreduce_range(g, false, nk_off, len + 1);
-    if (xrc == MVHDP_OK) xrc = fan_out_range(g, false, nk_off, len + 1);
+    x.hip(hipSetDevice(L0->device), "hipSetDevice");
+    x.hip(hipEventRecord(g->ev_x0, L0->stream), "hipEventRecord");
+    {
+        const bool was_ok = local_err == MVHDP_OK;
+        note(reduce_local(g, false), g->err);
+        note(x.rc, g->err);
+        if (was_ok && local_err != MVHDP_OK) {
+            // the local sum itself failed: what the leaders hold is not this process's share -- zeros and a raised status word instead
+            for (int i = 0; i < n; i++) { hipSetDevice(g->members[i]->device); hipStreamSynchronize(g->members[i]->stream); }
+            drop_local();
+        }
+    }
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        mvhdp_ctx* L = g->members[g->leaders[l]];
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, L->stream, L->mm.delta + len, local_err != MVHDP_OK ? 1 : 0);
+    }
+    int xrc = allreduce_range(g, false, nk_off, len + 1);
+    { const int rc = fan_out_range(g, false, nk_off, len + 1); if (xrc == MVHDP_OK) xrc = rc; }
     bool applying = local_err == MVHDP_OK && xrc == MVHDP_OK;
     if (applying) for (int i = 0; i < n && applying; i++) { const int rc = mvhdp_apply_delta_begin(g->members[i]); if (rc) { note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err); applying = false; } }
     const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(g->chunks, rows));
     for (int c = 0; c < nch; c++) {
         const int64_t r0 = rows * c / nch, r1 = rows * (c + 1) / nch;
         if (r1 <= r0) continue;
-        if (xrc == MVHDP_OK) xrc = allreduce_range(g, false, r0 * K, r1 * K);
-        if (xrc == MVHDP_OK) xrc = fan_out_range(g, false, r0 * K, r1 * K);
+        { const int rc = allreduce_range(g, false, r0 * K, r1 * K); if (xrc == MVHDP_OK) xrc = rc; }     // (issued whatever happened before)
+        { const int rc = fan_out_range(g, false, r0 * K, r1 * K); if (xrc == MVHDP_OK) xrc = rc; }
         if (applying && xrc == MVHDP_OK)
             for (int i = 0; i < n && applying; i++) { const int rc = mvhdp_apply_delta_rows(g->members[i], r0, r1); if (rc) { note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err); applying = false; } }
     }
@@ -500,44 +566,46 @@ static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uin
     const bool has_inactive = g->members[0]->mm.first_inactive >= 0;       // the hyper-parameters are replicated: every rank answers alike
     if (has_inactive) {
         if (local_err == MVHDP_OK) for (int i = 0; i < n; i++) key = std::min<long long>(key, (long long)st[i].activation_key);
-        if (!g->comms.empty() && g->nranks > 1 && xrc == MVHDP_OK) {
+        if (!g->comms.empty() && g->nranks > 1) {
             Rccl* r = &g_rccl;
             for (size_t l = 0; l < g->leaders.size(); l++) {
                 mvhdp_ctx* L = g->members[g->leaders[l]];
-                hip(hipSetDevice(L->device), "hipSetDevice");
-                hip(hipMemcpyAsync(g->d_key[l], &key, sizeof key, hipMemcpyHostToDevice, L->stream), "hipMemcpyAsync");
+                x.hip(hipSetDevice(L->device), "hipSetDevice");
+                x.hip(hipMemcpyAsync(g->d_key[l], &key, sizeof key, hipMemcpyHostToDevice, L->stream), "hipMemcpyAsync");
             }
-            ncclResult_t nr = ncclSuccess;
-            if (g->comms.size() > 1) nr = r->GroupStart();
-            for (size_t l = 0; l < g->leaders.size() && nr == ncclSuccess; l++) {
+            if (g->comms.size() > 1) x.nccl(r->GroupStart(), "ncclGroupStart");
+            for (size_t l = 0; l < g->leaders.size(); l++) {
                 mvhdp_ctx* L = g->members[g->leaders[l]];
-                hip(hipSetDevice(L->device), "hipSetDevice");
-                nr = r->AllReduce(g->d_key[l], g->d_key[l], 1, ncclInt64, ncclMin, g->comms[l], L->stream);
+                x.hip(hipSetDevice(L->device), "hipSetDevice");
+                x.nccl(r->AllReduce(g->d_key[l], g->d_key[l], 1, ncclInt64, ncclMin, g->comms[l], L->stream), "activation key all-reduce");
             }
-            if (g->comms.size() > 1 && nr == ncclSuccess) nr = r->GroupEnd();
-            if (nr != ncclSuccess) note(MVHDP_ERR_HIP, std::string("activation key all-reduce: ") + r->GetErrorString(nr));
-            hip(hipSetDevice(L0->device), "hipSetDevice");
-            hip(hipMemcpyAsync(&key, g->d_key[0], sizeof key, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
-            hip(hipStreamSynchronize(L0->stream), "hipStreamSynchronize");
+            if (g->comms.size() > 1) x.nccl(r->GroupEnd(), "ncclGroupEnd");
+            x.hip(hipSetDevice(L0->device), "hipSetDevice");
+            x.hip(hipMemcpyAsync(&key, g->d_key[0], sizeof key, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
+            x.hip(hipStreamSynchronize(L0->stream), "hipStreamSynchronize");
         }
     }
     if (xrc != MVHDP_OK && local_err == MVHDP_OK) local_err = xrc;         // (g->err was set where the collective failed)
     // the status word of the whole group, read behind everything this step put on the first device's stream
     int32_t failed_ranks = 0;
-    hip(hipSetDevice(L0->device), "hipSetDevice");
-    hip(hipEventRecord(g->ev_x1, L0->stream), "hipEventRecord");
-    hip(hipMemcpyAsync(&failed_ranks, L0->mm.delta + len, sizeof failed_ranks, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
-    hip(hipStreamSynchronize(L0->stream), "hipStreamSynchronize");
+    x.hip(hipSetDevice(L0->device), "hipSetDevice");
+    x.hip(hipEventRecord(g->ev_x1, L0->stream), "hipEventRecord");
+    x.hip(hipMemcpyAsync(&failed_ranks, L0->mm.delta + len, sizeof failed_ranks, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
+    x.hip(hipStreamSynchronize(L0->stream), "hipStreamSynchronize");
+    note(x.rc, g->err);
     const int32_t topic = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_TOPIC(key), view = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_VIEW(key);
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = g->members[i];
         if (applying) {
             const int rc2 = mvhdp_apply_delta_end(h, topic, view);
             if (rc2 != MVHDP_OK) note(rc2, "member " + std::to_string(i) + ": " + h->err);
-        } else if (h->rows_applied >= 0) {                  // a bracket this step opened and could not close
+        } else {
             hipSetDevice(h->device); hipStreamSynchronize(h->stream);
-            h->rows_applied = -1; h->have_trees = false; h->counts_stale = true; h->delta_pending = false;
-        } else { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
+            if (h->rows_applied >= 0) { h->rows_applied = -1; h->have_trees = false; }     // a bracket this step opened and could not close
+            // The collectives ran in place on this member's delta buffer: it now holds the OTHER ranks' sums (or half an exchange), which
+            // nothing will apply.  Mark it dirty: the next sweep's enqueue and mvhdp_group_build_counts clear a dirty buffer first.
+            h->counts_stale = true; h->delta_pending = false; h->delta_clean = false;
+        }
         st[i].activation_key = key; st[i].activated_topic = topic; st[i].activated_modality = view;
         st[i].activations = topic >= 0 ? 1 : 0;
     }
@@ -545,10 +613,10 @@ static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uin
     hipSetDevice(L0->device);
     if (hipEventElapsedTime(&ms, g->ev_x0, g->ev_x1) == hipSuccess) g->last_exchange_ms += ms;
     if (local_err != MVHDP_OK) return local_err;
-    if (failed_ranks > 0) {
+    if (failed_ranks != 0) {
         // the other replicas applied the same (partial) sum and agree with each other; the model as a whole needs the recount
         for (int i = 0; i < n; i++) g->members[i]->counts_stale = true;
-        GFAIL(g, MVHDP_ERR_STATE, "the sweep failed on " + std::to_string(failed_ranks) + " other rank(s) of the group: call mvhdp_group_build_counts on every rank");
+        GFAIL(g, MVHDP_ERR_STATE, "the sweep failed on " + std::to_string(failed_ranks) + " other rank(s) of the group (or the collective broke): call mvhdp_group_build_counts on every rank");
     }
     return MVHDP_OK;
 }
@@ -587,28 +655,31 @@ static int async_buffers(mvhdp_group_ctx* g)
     return MVHDP_OK;
 }
 
-// what is in flight lands: every member adds the other shards' share of the exchanged deltas; *failed: ranks whose sweep had failed
+// what is in flight lands: every member adds the other shards' share of the exchanged deltas; *failed: ranks whose sweep had failed.
+// Issues everything it has to issue whatever fails on the way (a step of the asynchronous exchange calls it in front of its own
+// collective, which the peers are about to enter).
 static int async_land(mvhdp_group_ctx* g, int32_t* failed)
 {
     *failed = 0;
     if (!g->async_pending) return MVHDP_OK;
+    XErr x{g};
     const int64_t len = counts_len_of(g->members[0]);
     for (size_t i = 0; i < g->members.size(); i++) {
         mvhdp_ctx* h = g->members[i];
         size_t l = 0; while (g->leaders[l] != g->leader_of[i]) l++;
-        GHIP(g, hipSetDevice(h->device));
-        GHIP(g, hipStreamWaitEvent(h->stream, g->ev_xfer[l], 0));
+        x.hip(hipSetDevice(h->device), "hipSetDevice");
+        x.hip(hipStreamWaitEvent(h->stream, g->ev_xfer[l], 0), "hipStreamWaitEvent");
         const int grid = (int)std::min<int64_t>((len + 255) / 256, 8192);
         hipLaunchKernelGGL(add_remote_kernel, dim3(grid), dim3(256), 0, h->stream, h->mm.counts, g->xbuf[i], g->sbuf[i], len);
-        GHIP(g, hipGetLastError());
+        x.hip(hipGetLastError(), "add_remote_kernel");
         h->have_trees = false;
     }
     mvhdp_ctx* L0 = g->members[g->leaders[0]];
-    GHIP(g, hipSetDevice(L0->device));
-    GHIP(g, hipMemcpyAsync(failed, g->xbuf[g->leaders[0]] + len, sizeof(int32_t), hipMemcpyDeviceToHost, L0->stream));
-    for (mvhdp_ctx* h : g->members) { GHIP(g, hipSetDevice(h->device)); GHIP(g, hipStreamSynchronize(h->stream)); }
+    x.hip(hipSetDevice(L0->device), "hipSetDevice");
+    x.hip(hipMemcpyAsync(failed, g->xbuf[g->leaders[0]] + len, sizeof(int32_t), hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
+    for (mvhdp_ctx* h : g->members) { x.hip(hipSetDevice(h->device), "hipSetDevice"); x.hip(hipStreamSynchronize(h->stream), "hipStreamSynchronize"); }
     g->async_pending = false;
-    return MVHDP_OK;
+    return x.rc;
 }
 
 extern "C" int mvhdp_group_drain(mvhdp_group g)
@@ -616,8 +687,9 @@ extern "C" int mvhdp_group_drain(mvhdp_group g)
     CHECK_G(g);
     DeviceGuard dg;
     int32_t failed = 0;
-    int rc = async_land(g, &failed); if (rc) return rc;
-    if (failed > 0) {
+    int rc = async_land(g, &failed);
+    if (rc) { for (mvhdp_ctx* h : g->members) h->counts_stale = true; return rc; }
+    if (failed != 0) {
         for (mvhdp_ctx* h : g->members) h->counts_stale = true;
         GFAIL(g, MVHDP_ERR_STATE, "a sweep whose deltas were still on the wire had failed on " + std::to_string(failed) + " rank(s): call mvhdp_group_build_counts on every rank");
     }
@@ -627,7 +699,10 @@ extern "C" int mvhdp_group_drain(mvhdp_group g)
 static int group_step_async(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uint32_t flags, std::vector<mvhdp_sweep_stats>& st)
 {
     const int n = (int)g->members.size();
+    // (decided from replicated facts, before anything is on a device: every rank refuses alike)
     if (g->members[0]->mm.first_inactive >= 0) GFAIL(g, MVHDP_ERR_UNSUPPORTED, "group_sweep: ASYNC_EXCHANGE with inactive topics (their activation has to be agreed on before the next sweep)");
+    // the exchange buffers are allocated by the FIRST such sweep, before any peer can be inside this step's collective: a rank that
+    // cannot allocate fails here alone, and its host follows the protocol of a rank that cannot go on (mvhdp_group_abort)
     int rc = async_buffers(g); if (rc) return rc;
     const int64_t len = counts_len_of(g->members[0]);
     const size_t bytes = (size_t)len * sizeof(int32_t);
@@ -645,58 +720,65 @@ static int group_step_async(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t see
         const int r = mvhdp_sweep_finish(g->members[i], ps[i], &st[i]);
         if (r != MVHDP_OK) note(r, "member " + std::to_string(i) + ": " + g->members[i]->err);
     }
+    // From here to the all-reduce below nothing returns: the peers enter that collective whatever happens on this rank (XErr).
+    XErr x{g};
     // 2. the previous sweep's exchange has had this sweep's time: it lands now (counts were restored to the sweep-start snapshot by
     //    the NO_APPLY form: first this sweep's own deltas go back in, then the other shards' share of the previous one)
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = g->members[i];
-        if (local_err != MVHDP_OK) { hipSetDevice(h->device); hipMemsetAsync(h->mm.delta, 0, bytes, h->stream); h->counts_stale = true; }
-        else { hipSetDevice(h->device); launch_add_into(h->mm.counts, h->mm.delta, len, h->stream); }
+        x.hip(hipSetDevice(h->device), "hipSetDevice");
+        if (local_err != MVHDP_OK) { x.hip(hipMemsetAsync(h->mm.delta, 0, bytes, h->stream), "hipMemsetAsync"); h->counts_stale = true; }
+        else x.hip(launch_add_into(h->mm.counts, h->mm.delta, len, h->stream), "add_into_kernel");
     }
     int32_t failed = 0;
-    rc = async_land(g, &failed); if (rc) return rc;
+    note(async_land(g, &failed), g->err);
+    note(x.rc, g->err);
+    if (local_err != MVHDP_OK)                             // (a failure found after the deltas went back in: this rank still ships zeros and a raised word)
+        for (int i = 0; i < n; i++) { mvhdp_ctx* h = g->members[i]; hipSetDevice(h->device); hipMemsetAsync(h->mm.delta, 0, bytes, h->stream); h->counts_stale = true; }
     // 3. this sweep's deltas go on the wire (a copy: the delta buffer is the next sweep's), the collective on its own stream
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = g->members[i];
-        GHIP(g, hipSetDevice(h->device));
-        GHIP(g, hipMemcpyAsync(g->xbuf[i], h->mm.delta, bytes, hipMemcpyDeviceToDevice, h->stream));
-        GHIP(g, hipMemcpyAsync(g->sbuf[i], h->mm.delta, bytes, hipMemcpyDeviceToDevice, h->stream));
-        GHIP(g, hipMemsetAsync(h->mm.delta, 0, bytes, h->stream));
+        x.hip(hipSetDevice(h->device), "hipSetDevice");
+        x.hip(hipMemcpyAsync(g->xbuf[i], h->mm.delta, bytes, hipMemcpyDeviceToDevice, h->stream), "hipMemcpyAsync");
+        x.hip(hipMemcpyAsync(g->sbuf[i], h->mm.delta, bytes, hipMemcpyDeviceToDevice, h->stream), "hipMemcpyAsync");
+        x.hip(hipMemsetAsync(h->mm.delta, 0, bytes, h->stream), "hipMemsetAsync");
         hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, h->stream, g->xbuf[i] + len, (g->leader_of[i] == i && local_err != MVHDP_OK) ? 1 : 0);
-        GHIP(g, hipEventRecord(g->ev_swept[i], h->stream));
+        x.hip(hipEventRecord(g->ev_swept[i], h->stream), "hipEventRecord");
         h->delta_pending = false; h->delta_clean = true; h->have_trees = false;
     }
     for (size_t l = 0; l < g->leaders.size(); l++) {
         const int li = g->leaders[l];
         mvhdp_ctx* L = g->members[li];
-        GHIP(g, hipSetDevice(L->device));
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
         for (int i = 0; i < n; i++) {
             if (g->leader_of[i] != li) continue;
-            GHIP(g, hipStreamWaitEvent(g->comm[l], g->ev_swept[i], 0));
-            if (i != li) GHIP(g, launch_add_into(g->xbuf[li], g->xbuf[i], len, g->comm[l]));
+            x.hip(hipStreamWaitEvent(g->comm[l], g->ev_swept[i], 0), "hipStreamWaitEvent");
+            if (i != li) x.hip(launch_add_into(g->xbuf[li], g->xbuf[i], len, g->comm[l]), "add_into_kernel");
         }
     }
     if (!g->comms.empty()) {
         Rccl* r = &g_rccl;
-        if (g->comms.size() > 1) GNCCL(g, r->GroupStart());
+        if (g->comms.size() > 1) x.nccl(r->GroupStart(), "ncclGroupStart");
         for (size_t l = 0; l < g->leaders.size(); l++) {
             mvhdp_ctx* L = g->members[g->leaders[l]];
-            GHIP(g, hipSetDevice(L->device));
+            x.hip(hipSetDevice(L->device), "hipSetDevice");
             int32_t* buf = g->xbuf[g->leaders[l]];
-            GNCCL(g, r->AllReduce(buf, buf, (size_t)(len + 1), ncclInt32, ncclSum, g->comms[l], g->comm[l]));
+            x.nccl(r->AllReduce(buf, buf, (size_t)(len + 1), ncclInt32, ncclSum, g->comms[l], g->comm[l]), "ncclAllReduce");
         }
-        if (g->comms.size() > 1) GNCCL(g, r->GroupEnd());
+        if (g->comms.size() > 1) x.nccl(r->GroupEnd(), "ncclGroupEnd");
     }
     for (size_t l = 0; l < g->leaders.size(); l++) {
         const int li = g->leaders[l];
-        GHIP(g, hipSetDevice(g->members[li]->device));
+        x.hip(hipSetDevice(g->members[li]->device), "hipSetDevice");
         for (int i = 0; i < n; i++)
-            if (g->leader_of[i] == li && i != li) GHIP(g, hipMemcpyAsync(g->xbuf[i], g->xbuf[li], (size_t)(len + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, g->comm[l]));
-        GHIP(g, hipEventRecord(g->ev_xfer[l], g->comm[l]));
+            if (g->leader_of[i] == li && i != li) x.hip(hipMemcpyAsync(g->xbuf[i], g->xbuf[li], (size_t)(len + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, g->comm[l]), "hipMemcpyAsync");
+        x.hip(hipEventRecord(g->ev_xfer[l], g->comm[l]), "hipEventRecord");
     }
     g->async_pending = true;
+    note(x.rc, g->err);
     for (int i = 0; i < n; i++) { st[i].activation_key = LLONG_MAX; st[i].activated_topic = -1; st[i].activated_modality = -1; st[i].activations = 0; }
-    if (local_err != MVHDP_OK) return local_err;
-    if (failed > 0) {
+    if (local_err != MVHDP_OK) { for (mvhdp_ctx* h : g->members) h->counts_stale = true; return local_err; }
+    if (failed != 0) {
         for (mvhdp_ctx* h : g->members) h->counts_stale = true;
         GFAIL(g, MVHDP_ERR_STATE, "the previous sweep failed on " + std::to_string(failed) + " other rank(s) of the group: call mvhdp_group_build_counts on every rank");
     }
@@ -776,47 +858,83 @@ extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t see
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+// The cross-rank pieces of the statistics (one process per GPU).  Same rule as the sweep: a rank whose own part failed still enters
+// the collective -- with zeros and a raised status slot -- so that every rank learns of it from the result and all return an error from
+// the same call; nothing is allocated on the way (the scratch buffer exists since mvhdp_group_create_rank) and no HIP failure returns
+// before the all-reduce has been issued.  local_status: MVHDP_OK or this rank's error; *failed_ranks: ranks that raised their slot.
+
 // all[r*n + i] = rank r's vals[i]; single process: all = vals
-int xrank_gather_f64(mvhdp_group_ctx* g, const double* vals, int n, std::vector<double>& all)
+int xrank_gather_f64(mvhdp_group_ctx* g, const double* vals, int n, int local_status, std::vector<double>& all, int* failed_ranks)
 {
+    *failed_ranks = 0;
     if (!g->multi_process || g->nranks <= 1) { all.assign(vals, vals + n); return MVHDP_OK; }
     mvhdp_ctx* L = g->members[g->leaders[0]];
-    const size_t total = (size_t)g->nranks * n;
+    const size_t per = (size_t)n + 1, total = (size_t)g->nranks * per;
+    if (total * sizeof(double) > XSCRATCH_BYTES || !g->d_scratch) GFAIL(g, MVHDP_ERR_INVALID_ARG, "xrank_gather_f64: message larger than the scratch buffer");   // (replicated sizes: every rank refuses alike)
     std::vector<double> host(total, 0.0);
-    std::copy(vals, vals + n, host.begin() + (size_t)g->rank0 * n);
-    double* d = nullptr;
-    GHIP(g, hipSetDevice(L->device));
-    GHIP(g, hipMalloc(&d, total * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(d, host.data(), total * sizeof(double), hipMemcpyHostToDevice, L->stream);
-    ncclResult_t nr = ncclSuccess;
-    if (e == hipSuccess) nr = g_rccl.AllReduce(d, d, total, ncclDouble, ncclSum, g->comms[0], L->stream);
-    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(host.data(), d, total * sizeof(double), hipMemcpyDeviceToHost, L->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
-    hipFree(d);
-    GHIP(g, e);
-    if (nr != ncclSuccess) GFAIL(g, MVHDP_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
-    all.swap(host);
+    if (local_status == MVHDP_OK) std::copy(vals, vals + n, host.begin() + (size_t)g->rank0 * per);
+    host[(size_t)g->rank0 * per + n] = local_status == MVHDP_OK ? 0.0 : 1.0;
+    XErr x{g};
+    double* d = (double*)g->d_scratch;
+    x.hip(hipSetDevice(L->device), "hipSetDevice");
+    x.hip(hipMemcpyAsync(d, host.data(), total * sizeof(double), hipMemcpyHostToDevice, L->stream), "hipMemcpyAsync");
+    x.nccl(g_rccl.AllReduce(d, d, total, ncclDouble, ncclSum, g->comms[0], L->stream), "ncclAllReduce");
+    x.hip(hipMemcpyAsync(host.data(), d, total * sizeof(double), hipMemcpyDeviceToHost, L->stream), "hipMemcpyAsync");
+    x.hip(hipStreamSynchronize(L->stream), "hipStreamSynchronize");
+    if (x.rc != MVHDP_OK) return x.rc;
+    all.resize((size_t)g->nranks * n);
+    for (int r = 0; r < g->nranks; r++) {
+        std::copy(host.begin() + (size_t)r * per, host.begin() + (size_t)r * per + n, all.begin() + (size_t)r * n);
+        if (host[(size_t)r * per + n] != 0.0) (*failed_ranks)++;
+    }
     return MVHDP_OK;
 }
 
-// vals[i] <- sum over ranks (integers: any order)
-int xrank_sum_i32(mvhdp_group_ctx* g, int32_t* vals, size_t n)
+// vals[i] <- sum over ranks (integers: any order); in pieces of the scratch buffer, the status word behind the last one
+int xrank_sum_i32(mvhdp_group_ctx* g, int32_t* vals, size_t n, int local_status, int* failed_ranks)
 {
-    if (!g->multi_process || g->nranks <= 1 || n == 0) return MVHDP_OK;
+    *failed_ranks = 0;
+    if (!g->multi_process || g->nranks <= 1) return MVHDP_OK;
     mvhdp_ctx* L = g->members[g->leaders[0]];
-    int32_t* d = nullptr;
-    GHIP(g, hipSetDevice(L->device));
-    GHIP(g, hipMalloc(&d, n * sizeof(int32_t)));
-    hipError_t e = hipMemcpyAsync(d, vals, n * sizeof(int32_t), hipMemcpyHostToDevice, L->stream);
-    ncclResult_t nr = ncclSuccess;
-    if (e == hipSuccess) nr = g_rccl.AllReduce(d, d, n, ncclInt32, ncclSum, g->comms[0], L->stream);
-    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(vals, d, n * sizeof(int32_t), hipMemcpyDeviceToHost, L->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
-    hipFree(d);
-    GHIP(g, e);
-    if (nr != ncclSuccess) GFAIL(g, MVHDP_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
+    if (!g->d_scratch) GFAIL(g, MVHDP_ERR_STATE, "xrank_sum_i32: no scratch buffer");
+    const size_t cap = XSCRATCH_BYTES / sizeof(int32_t) - 1;
+    std::vector<int32_t> piece(cap + 1);
+    XErr x{g};
+    int32_t* d = (int32_t*)g->d_scratch;
+    x.hip(hipSetDevice(L->device), "hipSetDevice");
+    for (size_t off = 0; off < n || off == 0; off += cap) {
+        const size_t k = std::min(cap, n - off);
+        const bool last = off + k >= n;
+        if (local_status == MVHDP_OK) std::copy(vals + off, vals + off + k, piece.begin()); else std::fill(piece.begin(), piece.begin() + k, 0);
+        piece[k] = local_status == MVHDP_OK ? 0 : 1;
+        const size_t cnt = k + (last ? 1 : 0);
+        x.hip(hipMemcpyAsync(d, piece.data(), cnt * sizeof(int32_t), hipMemcpyHostToDevice, L->stream), "hipMemcpyAsync");
+        x.nccl(g_rccl.AllReduce(d, d, cnt, ncclInt32, ncclSum, g->comms[0], L->stream), "ncclAllReduce");
+        x.hip(hipMemcpyAsync(piece.data(), d, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, L->stream), "hipMemcpyAsync");
+        x.hip(hipStreamSynchronize(L->stream), "hipStreamSynchronize");
+        if (x.rc == MVHDP_OK) { std::copy(piece.begin(), piece.begin() + k, vals + off); if (last) *failed_ranks = piece[k]; }
+        if (last) break;
+    }
+    return x.rc;
+}
+
+// A statistic of a group whose asynchronous exchange is still in flight lands it first.  Returns non-zero only for what EVERY rank sees
+// alike (a peer's failed sweep, read from the exchanged status word); a failure of this rank alone goes to *local_status, and the
+// caller still enters its collectives.
+int land_before_statistics(mvhdp_group_ctx* g, int* local_status)
+{
+    if (!g->async_pending) return MVHDP_OK;
+    int32_t failed = 0;
+    const int rc = async_land(g, &failed);
+    if (rc != MVHDP_OK) { if (*local_status == MVHDP_OK) *local_status = rc; for (mvhdp_ctx* h : g->members) h->counts_stale = true; if (!g->multi_process) return rc; return MVHDP_OK; }
+    if (failed != 0) {
+        for (mvhdp_ctx* h : g->members) h->counts_stale = true;
+        GFAIL(g, MVHDP_ERR_STATE, "a sweep whose deltas were still on the wire had failed on " + std::to_string(failed) + " rank(s): call mvhdp_group_build_counts on every rank");
+    }
     return MVHDP_OK;
 }
+
+#define XFAILED(g, failed) GFAIL(g, MVHDP_ERR_STATE, "the statistic failed on " + std::to_string(failed) + " other rank(s) of the group")
 
 }  // namespace
 
@@ -836,16 +954,27 @@ extern "C" int mvhdp_group_log_likelihood(mvhdp_group g, double* out)
     CHECK_G(g);
     if (!out) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_log_likelihood: null");
     DeviceGuard dg;
-    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
+    int lst = MVHDP_OK;
+    { const int rcd = land_before_statistics(g, &lst); if (rcd) return rcd; }
+    const bool multi = g->multi_process && g->nranks > 1;
     const int M = g->members[0]->mm.M;
     for (int m = 0; m < M; m++) {
         double ll = 0;
         int64_t cnt = 0;
-        for (int i : g->by_entity) GMEM(g, i, mvhdp_ll_doc_accumulate(g->members[i], m, &ll, &cnt));
-        if (g->multi_process && g->nranks > 1) {
+        for (int i : g->by_entity) {
+            if (lst != MVHDP_OK) break;
+            const int rc = mvhdp_ll_doc_accumulate(g->members[i], m, &ll, &cnt);
+            if (rc != MVHDP_OK) { lst = rc; g->err = "member " + std::to_string(i) + ": " + g->members[i]->err; if (!multi) return rc; }
+        }
+        if (multi) {
             const double mine[2] = {ll, (double)cnt};
             std::vector<double> all;
-            int rc = xrank_gather_f64(g, mine, 2, all); if (rc) return rc;
+            int failed = 0;
+            const std::string keep = g->err;
+            const int rc = xrank_gather_f64(g, mine, 2, lst, all, &failed);
+            if (lst != MVHDP_OK) { g->err = keep; return lst; }
+            if (rc) return rc;
+            if (failed) XFAILED(g, failed);
             ll = 0; double c = 0;
             for (int r = 0; r < g->nranks; r++) { ll += all[(size_t)2 * r]; c += all[(size_t)2 * r + 1]; }
             cnt = (int64_t)c;
@@ -860,19 +989,30 @@ extern "C" int mvhdp_group_doc_topic_hist(mvhdp_group g, int32_t m, int32_t* his
 {
     CHECK_G(g);
     DeviceGuard dg;
-    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
+    int lst = MVHDP_OK;
+    { const int rcd = land_before_statistics(g, &lst); if (rcd) return rcd; }
+    const bool multi = g->multi_process && g->nranks > 1;
     const int K = g->members[0]->mm.K;
     const size_t nh = hist ? (size_t)K * (size_t)std::max(hist_len, 0) : 0, nl = doc_len_counts ? (size_t)std::max(len_len, 0) : 0;
     std::vector<int32_t> th(nh), tl(nl);
     if (hist) std::fill(hist, hist + nh, 0);
     if (doc_len_counts) std::fill(doc_len_counts, doc_len_counts + nl, 0);
-    for (size_t i = 0; i < g->members.size(); i++) {
-        GMEM(g, i, mvhdp_get_doc_topic_hist(g->members[i], m, hist ? th.data() : nullptr, hist_len, doc_len_counts ? tl.data() : nullptr, len_len));
+    std::string keep;
+    for (size_t i = 0; i < g->members.size() && lst == MVHDP_OK; i++) {
+        const int rc = mvhdp_get_doc_topic_hist(g->members[i], m, hist ? th.data() : nullptr, hist_len, doc_len_counts ? tl.data() : nullptr, len_len);
+        if (rc != MVHDP_OK) { lst = rc; g->err = keep = "member " + std::to_string(i) + ": " + g->members[i]->err; if (!multi) return rc; break; }
         for (size_t q = 0; q < nh; q++) hist[q] += th[q];
         for (size_t q = 0; q < nl; q++) doc_len_counts[q] += tl[q];
     }
-    int rc = xrank_sum_i32(g, hist, nh); if (rc) return rc;
-    return xrank_sum_i32(g, doc_len_counts, nl);
+    // (both collectives are entered whatever the first one said: their number depends on the arguments alone, which every rank passes alike)
+    int f1 = 0, f2 = 0;
+    const int rc1 = hist ? xrank_sum_i32(g, hist, nh, lst, &f1) : MVHDP_OK;
+    const int rc2 = doc_len_counts ? xrank_sum_i32(g, doc_len_counts, nl, lst, &f2) : MVHDP_OK;
+    if (lst != MVHDP_OK) { if (!keep.empty()) g->err = keep; return lst; }
+    if (rc1) return rc1;
+    if (rc2) return rc2;
+    if (f1 || f2) XFAILED(g, std::max(f1, f2));
+    return MVHDP_OK;
 }
 
 // countHistogram of optimizeBeta PTM:2295-2309: a statistic of the replicated n_wk -- any member's
@@ -880,7 +1020,10 @@ extern "C" int mvhdp_group_count_histogram(mvhdp_group g, int32_t m, int32_t* hi
 {
     CHECK_G(g);
     DeviceGuard dg;
-    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
+    // (no collective of its own; a drain is the landing of something every rank has already issued)
+    int lst = MVHDP_OK;
+    { const int rcd = land_before_statistics(g, &lst); if (rcd) return rcd; }
+    if (lst != MVHDP_OK) return lst;
     GMEM(g, 0, mvhdp_get_count_histogram(g->members[0], m, hist, len));
     return MVHDP_OK;
 }
@@ -891,13 +1034,24 @@ extern "C" int mvhdp_group_view_overlap_sums(mvhdp_group g, double* sums)
     CHECK_G(g);
     if (!sums) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_view_overlap_sums: null");
     DeviceGuard dg;
-    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
+    int lst = MVHDP_OK;
+    { const int rcd = land_before_statistics(g, &lst); if (rcd) return rcd; }
+    const bool multi = g->multi_process && g->nranks > 1;
     const int M = g->members[0]->mm.M;
     for (int i = 0; i < M * M; i++) sums[i] = 0.0;
-    for (int i : g->by_entity) GMEM(g, i, mvhdp_view_overlap_accumulate(g->members[i], sums));
-    if (g->multi_process && g->nranks > 1) {
+    std::string keep;
+    for (int i : g->by_entity) {
+        if (lst != MVHDP_OK) break;
+        const int rc = mvhdp_view_overlap_accumulate(g->members[i], sums);
+        if (rc != MVHDP_OK) { lst = rc; g->err = keep = "member " + std::to_string(i) + ": " + g->members[i]->err; if (!multi) return rc; }
+    }
+    if (multi) {
         std::vector<double> all;
-        int rc = xrank_gather_f64(g, sums, M * M, all); if (rc) return rc;
+        int failed = 0;
+        const int rc = xrank_gather_f64(g, sums, M * M, lst, all, &failed);
+        if (lst != MVHDP_OK) { if (!keep.empty()) g->err = keep; return lst; }
+        if (rc) return rc;
+        if (failed) XFAILED(g, failed);
         for (int i = 0; i < M * M; i++) { double a = 0; for (int r = 0; r < g->nranks; r++) a += all[(size_t)r * M * M + i]; sums[i] = a; }
     }
     return MVHDP_OK;
@@ -910,17 +1064,26 @@ extern "C" int mvhdp_group_gamma_doc_statistics(mvhdp_group g, int32_t m, double
     CHECK_G(g);
     if (!qs || !qw) GFAIL(g, MVHDP_ERR_INVALID_ARG, "group_gamma_doc_statistics: null");
     DeviceGuard dg;
-    if (g->async_pending) { const int rcd = mvhdp_group_drain(g); if (rcd) return rcd; }
+    int lst = MVHDP_OK;
+    { const int rcd = land_before_statistics(g, &lst); if (rcd) return rcd; }
+    const bool multi = g->multi_process && g->nranks > 1;
     double a = 0, b = 0;
+    std::string keep;
     for (int i : g->by_entity) {
+        if (lst != MVHDP_OK) break;
         double x = 0, y = 0;
-        GMEM(g, i, mvhdp_gamma_doc_statistics(g->members[i], m, gamma_m, seed, round, &x, &y));
+        const int rc = mvhdp_gamma_doc_statistics(g->members[i], m, gamma_m, seed, round, &x, &y);
+        if (rc != MVHDP_OK) { lst = rc; g->err = keep = "member " + std::to_string(i) + ": " + g->members[i]->err; if (!multi) return rc; break; }
         a += x; b += y;
     }
-    if (g->multi_process && g->nranks > 1) {
+    if (multi) {
         const double mine[2] = {a, b};
         std::vector<double> all;
-        int rc = xrank_gather_f64(g, mine, 2, all); if (rc) return rc;
+        int failed = 0;
+        const int rc = xrank_gather_f64(g, mine, 2, lst, all, &failed);
+        if (lst != MVHDP_OK) { if (!keep.empty()) g->err = keep; return lst; }
+        if (rc) return rc;
+        if (failed) XFAILED(g, failed);
         a = 0; b = 0;
         for (int r = 0; r < g->nranks; r++) { a += all[(size_t)2 * r]; b += all[(size_t)2 * r + 1]; }
     }

@@ -69,6 +69,7 @@ hipError_t mvhdp_launch_build_counts(const MvModel& mm, const int64_t* n_tokens,
 // ---------------------------------------------------------------------------
 // The tree of one (view, type) row from its K leaves in t[K .. 2K): FT:96-109 level by level (children before parents), then the
 // same numbers once more grouped for the descent (MvModel::dtab) and tree[1] by itself.  One wave (a block of 64 threads) per row.
+template <bool COHERENT = false>
 __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row, double* t, int lane, bool write_full)
 {
     const int K = mm.K;
@@ -86,7 +87,9 @@ __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row,
         double* out = mm.trees + row * 2 * K;
         for (int i = lane; i < 2 * K; i += WAVE) out[i] = t[i];
     }
-    if (lane == 0) mm.root[row] = t[1];                    // tree[1] by itself: 8 bytes a type, L2-resident (WRK:519 without the walk)
+    // COHERENT (heavy_refresh_kernel: the table is rewritten WHILE sweep kernels on the other XCDs read it): stores of agent scope -- written
+    // through this XCD's L2, which is not coherent with the others' for plain stores -- matched by agent-scope loads in the readers
+    if (lane == 0) { if (COHERENT) __hip_atomic_store(&mm.root[row], t[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else mm.root[row] = t[1]; }   // tree[1] by itself: 8 bytes a type, L2-resident (WRK:519 without the walk)
     // the same numbers once more, grouped for the descent (see MvModel::dtab)
     double* dt = mm.dtab + row * (int64_t)mm.dt_nblk * 8;
     // (written 16 bytes a lane, consecutive lanes consecutive addresses: unit u = pair j of block x -- whole 128-byte lines per store
@@ -110,7 +113,10 @@ __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row,
             const int node = (q == 0) ? b : (q < 3) ? 2 * b + (q - 1) : 4 * b + (q - 3);
             v2[h] = (q == 7) ? ((x == 0) ? t[1] : 0.0) : ((node < K) ? t[2 * node] : 0.0);
         }
-        o[u] = make_double2(v2[0], v2[1]);
+        if (COHERENT) {
+            __hip_atomic_store(&dt[2 * u], v2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&dt[2 * u + 1], v2[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else o[u] = make_double2(v2[0], v2[1]);
     }
     __syncthreads();
 }
@@ -129,7 +135,7 @@ __device__ __forceinline__ void tree_from_leaves(const MvModel& mm, int64_t row,
 // leave, not how long one of them takes (TB = 8 there: C3 live 5.2 -> 5.8 ms).  gpurun_out/r5l, r5m.
 template <int TB>
 __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool inference_leaves, bool write_full, int64_t row_begin, int64_t row_end,
-                                                         bool apply_first, unsigned long long* negatives, bool from_mirror)
+                                                         bool apply_first, unsigned long long* negatives, bool from_mirror, bool only_heavy = false)
 {
     extern __shared__ double t[];                  // 2K doubles
     const int K = mm.K, lane = threadIdx.x;
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(64) void build_trees_kernel(MvModel mm, bool infere
     int neg = 0;
     __builtin_amdgcn_s_setprio(3);                 // (a live sweep rebuilds the next segment's trees beside the current segment's samplers)
     for (int64_t row = row_begin + blockIdx.x; row < row_end; row += gridDim.x) {
+        if (only_heavy && mm.heavy[row] != MVHDP_ROW_HEAVY) continue;   // (live-rows form: every other word samples its tree branch from its live row)
         int m = 0;
         while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
         int32_t* cnt = mm.counts + row * K;
@@ -446,6 +453,173 @@ hipError_t mvhdp_launch_widen_mirror(const MvModel& mm, hipStream_t s)
     if (nrows <= 0) return hipSuccess;
     int64_t blocks = (nrows + 3) / 4;
     hipLaunchKernelGGL(widen_mirror_kernel, dim3((unsigned int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, mm);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MVHDP_SWEEP_LIVE, live-rows form (SweepLaunch::live_rows).  The reference's updater refreshes the two touched leaves of the word's
+// tree with every FastQDelta (UPD:242-260 -> FT:138-147), so a worker's tree branch (WRK:533-535) always samples from the word's
+// CURRENT counts; a stored tree that is rebuilt n times per sweep is up to 1/n sweep behind, and the LL curves price that (DESIGN.md
+// section 2: 4 rebuilds per sweep need 1.3-1.9 sweeps per reference sweep in the side views, 32 rebuilds match the reference).  Here the
+// tree branch reads the live row itself: leaf_k = coef[m][k] * (n_wk + beta_m) over all K topics by one wave-wide scan (row_sample_live in
+// mvhdp_sweep_fast.hip), and tree[1] -- which EVERY token's decision needs (WRK:519) -- is MvModel::root, exact at the segment start
+// (below) and moved by one fp64 atomic per changed token.  What a segment start costs is one pass over the counts: no tree, no descent
+// table (282 MB at C4) to write.
+//   coef[m][k] = (float)(gamma_m * alpha_mk / (n_k + betaSum_m)), 0 for an inactive topic      PTM:2670-2678
+//   smp[m][k]  = coef[m][0] * beta_m + ... + coef[m][k] * beta_m (fp32, in topic order): the smoothing part of every leaf of the view
+//   root[row]  = smp[m][K-1] + sum_k (double)coef[m][k] * n_wk: per lane over k = lane, lane + 64, ... ascending, then a butterfly
+//                over the lanes (the order the oracle restates for the sequential pin, tests/test_gpu_live.py)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void live_coef_kernel(MvModel mm)
+{
+    // one block per view: the coefficients (row padded to a multiple of 8 with zeros), then (one lane, in topic order) the running sums of
+    // the smoothing parts coef_k * beta
+    const int K = mm.K, Kp = (K + 7) & ~7, m = blockIdx.x;
+    const int32_t* nk = mm.counts + mm.rowbase[mm.M] * K + (int64_t)m * K;
+    float* cf = mm.coef + (int64_t)m * Kp;
+    float* smp = mm.coef + (int64_t)mm.M * Kp + (int64_t)m * K;
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x)
+        cf[k] = (k >= K || mm.inactive[k]) ? 0.0f : (float)(mm.gamma[m] * mm.alpha[(int64_t)m * (K + 1) + k] / ((double)nk[k] + mm.beta_sum[m]));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float beta32 = (float)mm.beta[m];
+        float run = 0.0f;
+        for (int k = 0; k < K; k++) { run += cf[k] * beta32; smp[k] = run; }
+    }
+}
+
+template <int TB>
+__global__ __launch_bounds__(64) void live_rows_prepare_kernel(MvModel mm, bool from_mirror, int32_t* heavy_list, unsigned int* heavy_n, int heavy_cap)
+{
+    const int K = mm.K, lane = threadIdx.x;
+    const int64_t nrows = mm.rowbase[mm.M];
+    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        int m = 0;
+        while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
+        const int32_t* cnt = mm.counts + row * K;
+        uint16_t* c16 = mm.counts16 + row * K;
+        const int Kp = (K + 7) & ~7;
+        const float* cf = mm.coef + (int64_t)m * Kp;
+        const float smp_total = mm.coef[(int64_t)mm.M * Kp + (int64_t)m * K + K - 1];   // S_m: the smoothing parts of the view's leaves, summed
+        const bool light_src = from_mirror && mm.heavy[row] != MVHDP_ROW_HEAVY;
+        bool hv = false;
+        if (!from_mirror) {                                          // the row's weight class, as build_trees_kernel decides it
+            long long sum = 0;
+            for (int k0 = 0; k0 < K; k0 += WAVE * TB) {
+                int cv[TB];
+#pragma unroll
+                for (int u = 0; u < TB; u++) { const int k = k0 + u * WAVE + lane; cv[u] = (k < K) ? cnt[k] : 0; }
+#pragma unroll
+                for (int u = 0; u < TB; u++) sum += cv[u] < 0 ? 70000 : cv[u];
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, WAVE);
+            hv = sum > 65534;
+            if (lane == 0) mm.heavy[row] = hv ? MVHDP_ROW_HEAVY : (sum > 32767 ? MVHDP_ROW_BIG : 0);
+        }
+        double acc = 0.0;
+        for (int k0 = 0; k0 < K; k0 += WAVE * TB) {
+            int cv[TB];
+            float fv[TB];
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int k = k0 + u * WAVE + lane;
+                const bool in = k < K;
+                cv[u] = in ? (light_src ? (int)c16[k] : cnt[k]) : 0;
+                fv[u] = in ? cf[k] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int k = k0 + u * WAVE + lane;
+                if (k < K) {
+                    if (!from_mirror) c16[k] = hv ? (uint16_t)65535 : (uint16_t)cv[u];
+                    acc += (double)fv[u] * (double)cv[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, WAVE);
+        if (lane == 0) mm.root[row] = (double)smp_total + acc;
+        // the HEAVY rows (a few hundred at most: each holds more than 65534 tokens), listed for the kernel that keeps their stored trees current
+        if (lane == 0 && heavy_list && mm.heavy[row] == MVHDP_ROW_HEAVY) {
+            const unsigned int i = atomicAdd(heavy_n, 1u);
+            if ((int)i < heavy_cap) heavy_list[i] = (int32_t)row;
+        }
+    }
+}
+
+// The stored trees of the HEAVY words of a live sweep in its live-rows form, kept current WHILE the samplers run: the reference's updater
+// refreshes the touched leaves of a word's tree with every delta (UPD:242-260); a heavy word's row is not in the mirror (its cells pass
+// 16 bits) and too long to sit in a lane's registers, so its tree branch walks a stored tree -- and half the tokens of a Zipf corpus
+// belong to heavy words, so a tree of the segment start would bring the staleness back that the live rows remove.
+// But the heavy words are FEW (170 of 60 000 at C4): a handful of waves rebuild all their trees from the live counts every few tens of
+// microseconds, beside the samplers, until the host's stream says the segment's samplers are done (`stop`, set in stream order behind
+// them) -- or two seconds have passed: the kernel always ends.  A sampler that reads a tree while it is being rewritten reads a mixture of
+// two nearly equal trees: every descent still ends at a topic (FT:122-132), like the reference's racy reads (PTM:84-87).
+__global__ __launch_bounds__(64) void heavy_refresh_kernel(MvModel mm, const int32_t* heavy_list, const unsigned int* ctl /* [0] rows listed, [1] stop */, int heavy_cap, bool write_full)
+{
+    extern __shared__ double t[];                  // 2K doubles
+    const int K = mm.K, lane = threadIdx.x;
+    const int64_t nrows = mm.rowbase[mm.M];
+    const int32_t* nk_all = mm.counts + nrows * K;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int n = min((int)__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), heavy_cap);
+#ifdef MVHDP_REFRESH_PRINT
+    if (blockIdx.x == 0 && lane == 0) printf("[refresher] %d heavy rows\n", n);
+#endif
+    for (int pass = 0; pass < 1000000; pass++) {
+        for (int i = blockIdx.x; i < n; i += gridDim.x) {
+            const int64_t row = heavy_list[i];
+            int m = 0;
+            while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
+            const int32_t* cnt = mm.counts + row * K;
+            const int32_t* nk = nk_all + (int64_t)m * K;
+            const double* al = mm.alpha + (int64_t)m * (K + 1);
+            const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
+            for (int k = lane; k < K; k += WAVE) {
+                const int c = __hip_atomic_load(&cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1: the samplers' atomics land at the memory side)
+                t[K + k] = mm.inactive[k] ? 0.0 : gamma * al[k] * (((double)c + beta) / ((double)nk[k] + beta_sum));   // PTM:2670-2678
+            }
+            tree_from_leaves<true>(mm, row, t, lane, write_full);
+        }
+#ifdef MVHDP_REFRESH_SLEEP_ONLY      /* experiment: idle waves that touch no memory, for 3 ms */
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000ull) break;
+        __builtin_amdgcn_s_sleep(127);
+        continue;
+#endif
+        if (n <= (int)blockIdx.x) break;                                      // (a block without a row of its own has nothing to do)
+        if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;     // 2 s of the 100 MHz counter
+    }
+}
+
+hipError_t mvhdp_launch_heavy_refresh(const MvModel& mm, const int32_t* heavy_list, const unsigned int* ctl, int heavy_cap, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(heavy_refresh_kernel, dim3(blocks), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, heavy_list, ctl, heavy_cap, getenv("MVHDP_REFRESH_FULL") != nullptr);
+    return hipGetLastError();
+}
+
+__global__ void set_u32_kernel(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+hipError_t mvhdp_launch_set_u32(unsigned int* p, unsigned int v, hipStream_t s)
+{
+    hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, s, p, v);
+    return hipGetLastError();
+}
+
+hipError_t mvhdp_launch_live_rows_prepare(const MvModel& mm, bool from_mirror, bool with_heavy_trees, int32_t* heavy_list, unsigned int* heavy_ctl, int heavy_cap, hipStream_t s)
+{
+    const int64_t nrows = mm.rowbase[mm.M];
+    hipLaunchKernelGGL(live_coef_kernel, dim3(mm.M), dim3(64), 0, s, mm);
+    if (nrows <= 0) return hipGetLastError();
+    const int grid = (int)(nrows < 65536 ? nrows : 65536);
+    if (heavy_ctl) { hipError_t e = hipMemsetAsync(heavy_ctl, 0, 2 * sizeof(unsigned int), s); if (e != hipSuccess) return e; }     // rows listed, stop
+    if (mm.K > 512) hipLaunchKernelGGL(live_rows_prepare_kernel<8>, dim3(grid), dim3(64), 0, s, mm, from_mirror, heavy_list, heavy_ctl, heavy_cap);
+    else hipLaunchKernelGGL(live_rows_prepare_kernel<4>, dim3(grid), dim3(64), 0, s, mm, from_mirror, heavy_list, heavy_ctl, heavy_cap);
+    // the HEAVY words (more than 65534 tokens: a few hundred rows at most) keep a stored tree, built from the 32-bit table where their
+    // counts live; the flags are those the pass above has just written (or kept)
+    if (with_heavy_trees)
+        hipLaunchKernelGGL(build_trees_kernel<4>, dim3(grid), dim3(64), (size_t)2 * mm.K * sizeof(double), s, mm, false, false, (int64_t)0, nrows, false,
+                           (unsigned long long*)nullptr, true, true);
     return hipGetLastError();
 }
 

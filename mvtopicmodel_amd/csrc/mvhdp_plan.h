@@ -89,6 +89,8 @@ struct SweepPlan {
     uint32_t block_shared_bytes = 0;
     bool delta16 = false;                       // a deferred sweep whose narrow kernels keep the deltas of the small rows in 16-bit cells (SweepLaunch::delta16)
     bool live16 = false;                        // a live sweep whose light rows are kept current in the 16-bit mirror (every kernel the NARROW flavour)
+    bool live_rows = false;                     // a live sweep whose tree branch samples from the live count rows (SweepLaunch::live_rows): no trees, no segment overlap
+    bool coef_lds = false;                      //   ... with the coefficient table of the segment in every block's LDS (block_shared_bytes holds room for it)
     int dominant = 0;                           // class holding most tokens (its group's walk threshold is the one being searched)
     int walk_cfg = 0;                           // key of the configuration the walk search compares sweeps within
 };
@@ -138,6 +140,11 @@ struct PlanTuning {
     int live_overlap = -1;                      // live sweeps: segments overlapped (two in flight); 0: one after the other
     int single_wave = 0;                        // diagnostics: every sweep kernel as one wavefront, class kernels one after another, live sweeps strictly ordered
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
+    int live_rows = -1;                         // live sweeps sample their tree branch from the live count rows (no stored trees): -1 / 1 wherever every kernel is
+                                                //   register-resident (default), 0: stored trees rebuilt at every segment border (the round-4 form)
+    int live_rows_segments = 1;                 // segments of such a sweep when the flags name none (a border refreshes tokensPerTopic and the roots: one pass over the counts)
+    double live_rows_theta = 0.3;               // steered views: a token's row is loaded ahead of its turn iff its u1 reaches this (a token below it that reaches the tree
+                                                //   branch after all loads it then)
 };
 
 // Walk-threshold search ("The thresholded walk").  The threshold changes WHEN a word tree is walked, never what
@@ -321,8 +328,12 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     if ((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) && in.debug) return fail(MVHDP_ERR_UNSUPPORTED, "sweep: SEGMENT_OVERLAP with debug outputs");
     // live / segmented sweeps: the entities are cut into nseg interleaved segments of the longest-first order
     // (a deferred sweep accepts a segment count too: same integers as one segment, the trees being those of the snapshot)
+    // (the live-rows form of a live sweep: decided here, before the segment count and the grids, from what cannot change below -- no
+    // entity can reach the generic LDS kernel, whose tree branch reads FTree.tree)
+    bool want_rows = p.live && !p.frozen && !in.debug && tu.live_rows != 0 && !(flags & (MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_GENERIC_KERNEL)) &&
+                     tu.force_primary != 32 && std::min<int64_t>(in.K, std::max<int64_t>(in.mdt, 1)) <= 1024 && in.mdt <= 65535;
     int nseg = (int)((flags >> 16) & 0xffu);
-    if (nseg == 0) nseg = (p.live || p.seg_apply) ? 4 : 1;
+    if (nseg == 0) nseg = want_rows ? std::max(1, tu.live_rows_segments) : (p.live || p.seg_apply) ? 4 : 1;
     p.only_seg = (int)(flags >> 24) - 1;                  // MVHDP_SWEEP_ONLY_SEGMENT(s): -1 = every segment
     // (more segments than entities: a whole sweep uses fewer; a single-segment call keeps the caller's count -- segments beyond the
     // last entity are empty -- so that document shards of different sizes walk through the same number of exchanges)
@@ -331,7 +342,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // two segments in flight (mvhdp_api.hip enqueue_overlapped): asked for (SEGMENT_OVERLAP), or a live sweep of several segments
     // whose borders need no host (no inactive topic waiting for its activation, no debug output)
     p.overlap = nseg > 1 && p.only_seg < 0 &&
-                ((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) || (p.live && !tu.single_wave && tu.live_overlap != 0 && in.first_inactive < 0 && !in.debug));
+                ((flags & MVHDP_SWEEP_SEGMENT_OVERLAP) || (p.live && !want_rows && !tu.single_wave && tu.live_overlap != 0 && in.first_inactive < 0 && !in.debug));
     if (p.only_seg >= 0) {
         if (p.live || p.seg_apply) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT excludes LIVE and SEGMENT_APPLY");
         if (p.only_seg >= nseg) return fail(MVHDP_ERR_INVALID_ARG, "sweep: ONLY_SEGMENT beyond the segment count");
@@ -346,6 +357,13 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // sweep instead of 5.7), so tokensPerTopic becomes current at each segment end -- together with the trees.
     p.nk_global = ((size_t)M * K * sizeof(int) > 24 * 1024) ? 1 : 0;
     p.block_shared_bytes = (uint32_t)((((size_t)(p.nk_global ? 0 : M * K) + MVHDP_HIST_BINS + MVHDP_ENT_BINS + MVHDP_MAXM * MVHDP_VIEW_STATS) * sizeof(int) + 15) & ~(size_t)15);
+    // live-rows form: the coefficient table [M][Kp] in LDS where it is small (C4: 4.8 KB; not C5's 20 KB, whose wide variants need their LDS for
+    // the slot state: those read it from global memory)
+    {
+        const size_t coef_bytes = (size_t)M * ((K + 7) & ~7) * sizeof(float);
+        p.coef_lds = want_rows && coef_bytes <= 12 * 1024;
+        if (p.coef_lds) p.block_shared_bytes += (uint32_t)((coef_bytes + 16 + 15) & ~(size_t)15);
+    }
 
     // ---- which classes hold entities (this sweep's topic lists), and the primary variant ----
     double tok[MVHDP_N_CLASSES], tot = 0;
@@ -496,5 +514,22 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
             for (int c = 0; c < MVHDP_N_CLASSES; c++) if (p.cls[c].used) { p.cls[c].walk = 1; p.cls[c].narrow = 1; }
         }
     }
-    p.walk_cfg = (p.fast ? (1 << p.dominant) : 32) * 2 + (p.route ? 1 : 0) + 64 * nseg + (p.live ? 1 << 16 : 0) + (p.seg_apply ? 1 << 17 : 0) + (p.live16 ? 1 << 18 : 0) + (p.overlap ? 1 << 19 : 0);
+    if (want_rows) {
+        bool all_fast = p.fast;
+        for (int c = 0; c < MVHDP_N_CLASSES; c++) if (p.cls[c].used && !p.cls[c].fast) all_fast = false;
+        if (all_fast) {
+            // every kernel the walk flavour (the tree branch lives in its walk-on-demand arm), nothing walked at the chunk head: u1 < 1 < theta
+            // every kernel the walk flavour (the tree branch lives beside its walk-on-demand arm).  The view's threshold: the u1 from which a
+            // token's row is loaded ahead of its turn (and a heavy word's stored tree walked at the chunk head) -- 0 where the tree branch
+            // takes a third of the view's tokens or more (the short side views), else tu.live_rows_theta
+            p.live_rows = true;
+            p.need_full = false;
+            for (int c = 0; c < MVHDP_N_CLASSES; c++)
+                if (p.cls[c].used) {
+                    p.cls[c].walk = 1;
+                    for (int m = 0; m < MVHDP_MAXM; m++) p.cls[c].theta[m] = (m < M && wt.controlled(m)) ? tu.live_rows_theta : 0.0;
+                }
+        } else p.coef_lds = false;
+    } else p.coef_lds = false;
+    p.walk_cfg = (p.live_rows ? 1 << 20 : 0) + (p.fast ? (1 << p.dominant) : 32) * 2 + (p.route ? 1 : 0) + 64 * nseg + (p.live ? 1 << 16 : 0) + (p.seg_apply ? 1 << 17 : 0) + (p.live16 ? 1 << 18 : 0) + (p.overlap ? 1 << 19 : 0);
 }

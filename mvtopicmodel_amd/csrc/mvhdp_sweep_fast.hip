@@ -61,6 +61,9 @@ size_t mvhdp_sweep_fast_wave_bytes(int M, int S_cap, int rmax)
 #ifndef MVHDP_LB16
 #define MVHDP_LB16 1
 #endif
+#ifndef MVHDP_LB_ROWS
+#define MVHDP_LB_ROWS 7      // the live-rows flavours of the 1- and 2-round variants (four more registers: the token's row)
+#endif
 #ifndef MVHDP_LB8
 #define MVHDP_LB8 1          // 3 waves/SIMD (168 VGPRs) spills 100 B/lane and is 13 % slower on C5 than 2 waves at 199
 #endif
@@ -97,11 +100,168 @@ __device__ __forceinline__ int gather_cell(gptr_t p)
 #define W_HEAVY 0x40000000                      // bit 30 of a lane's type id: the row is heavy (type ids stay below 2^29: mvhdp_create checks)
 #define W_BIG   0x20000000                      // bit 29: the row's deltas do not fit 16 bits for sure (MVHDP_ROW_BIG or heavy): they go to the 32-bit delta table
 #define W_ROW(w) ((w) & 0x1fffffff)
+// The tree branch of a live sweep in its live-rows form (SweepLaunch::live_rows; WRK:533-535 against what UPD:242-260 keeps current):
+// a topic with probability proportional to leaf_k = coef_k * (n_wk + beta) over ALL K topics, from the word's LIVE row.  The leaf splits
+// into a smoothing part coef_k * beta -- the same for every word of the view: its running sums smp[k] are a table of the segment -- and a
+// count part coef_k * n_wk, zero wherever the word has no token.  The target u2 * tree[1] falls into the smoothing part with probability
+// S / tree[1] -- small for any word with more than a handful of tokens -- and is searched in the table; otherwise in the row, which the
+// wave holds in registers: ONE 16-byte load per lane covers 512 cells of the 16-bit mirror (256 of the 32-bit table), lane l holding
+// the cells CPL*l .. CPL*l + CPL-1 in topic order; every lane sums its cells times their coefficients (from LDS), ONE DPP scan of the lane
+// sums finds the lane whose range holds the target, and that lane's running sums find the cell.
+// What a tree-branch token costs the wave is LATENCY (a wave samples its tokens one after the other), and a vector load issued once the
+// branch is known waits, in the in-order vmcnt counter, behind the next token's gather that is already in flight -- 3800 cycles per
+// tree-branch token, measured (-DMVHDP_TIMING), whatever the arithmetic behind it.  So the row is loaded at the TOP of the token's
+// body, before that gather is issued, for every token whose u1 reaches the view's threshold (only a large u1 can reach the tree branch:
+// the walk threshold of the other flavours, used the same way) -- the lines are in the L2 already, the token's own gather has just
+// brought them -- and the coefficients come from LDS (lgkmcnt): nothing on the tree branch's path waits for the memory system.
+// fp32 throughout: a live sweep is not reproducible run to run (the other waves' atomics land while it samples), so there is no fp64
+// sequence to certify against; with ONE resident wave the arithmetic below IS a definition, which the oracle restates operation for
+// operation (oracle/mvhdp_oracle.c, orc_row_sample_live).  A target beyond the row's mass (tree[1] is the segment start's; rounding)
+// takes the last topic that has mass.
+typedef unsigned int rowq_t __attribute__((ext_vector_type(4), aligned(4)));     // (a row of K cells need not start on a 16-byte boundary)
+typedef float coefq_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int smoothing_sample_live(const float* __restrict__ smp, int K, float t, int lane)
+{
+    for (int k0 = 0; k0 < K; k0 += WAVE) {
+        const int k = k0 + lane;
+        const float p = (k < K) ? smp[k] : 3.0e38f;
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(p > t && k < K);
+        if (hit) return k0 + (int)__builtin_ctzll(hit);
+    }
+    return K - 1;
+}
+
+// this lane's cells of batch b of a row (CELL16: eight 16-bit cells of the mirror, else four 32-bit cells), zero beyond the row's end
+template <bool CELL16>
+__device__ __forceinline__ rowq_t row_batch_load(gptr_t rowp, int K, int b, int lane)
+{
+    constexpr int CPL = CELL16 ? 8 : 4;
+    const int k = (b * WAVE + lane) * CPL;
+    rowq_t q = {0u, 0u, 0u, 0u};
+    if (k < K) q = *(const __attribute__((address_space(1))) rowq_t*)(rowp + (unsigned int)k * (CELL16 ? 2u : 4u));
+    return q;
+}
+
+// The batch in registers: the topic whose range holds `target` (>= 0), or -1 when the batch's mass ends below it; force: the last
+// cell with mass, whatever the target.  c0, c1: the coefficients of this lane's cells (zero beyond K, so that whatever the load brought
+// from beyond the row's end counts for nothing).  tot: the batch's mass; any: some cell of it has mass.
+// What this costs is instructions (seven waves share a SIMD: a wave gets an issue slot every twenty cycles or so), so the lane's cells
+// go two at a time: the products and their running sums are NS = CPL/2 packed fused multiply-adds (v_pk_fma_f32), the even cells in one
+// half, the odd cells in the other -- the lane's cells are therefore taken in the order even ones first (0, 2, 4, 6), then odd ones
+// (1, 3, 5, 7): any fixed order of the K leaves samples the same distribution --, and the cell inside the chosen lane is the NUMBER of
+// running sums that do not pass the target (they never decrease): a compare and an add-with-carry each, no select.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+template <bool CELL16>
+__device__ __forceinline__ int row_batch_pick(rowq_t q, coefq_t c0, coefq_t c1, int kb, float base, float target, bool force, float& tot, bool& any)
+{
+    constexpr int CPL = CELL16 ? 8 : 4, NS = CPL / 2;
+    f2_t n2[NS], k2[NS], A[NS];
+    if (CELL16) {
+        n2[0] = f2_t{(float)(q.x & 0xffffu), (float)(q.x >> 16)}; n2[1] = f2_t{(float)(q.y & 0xffffu), (float)(q.y >> 16)};
+        n2[NS - 2] = f2_t{(float)(q.z & 0xffffu), (float)(q.z >> 16)}; n2[NS - 1] = f2_t{(float)(q.w & 0xffffu), (float)(q.w >> 16)};
+        k2[0] = f2_t{c0.x, c0.y}; k2[1] = f2_t{c0.z, c0.w}; k2[NS - 2] = f2_t{c1.x, c1.y}; k2[NS - 1] = f2_t{c1.z, c1.w};
+    } else {
+        n2[0] = f2_t{(float)(int)q.x, (float)(int)q.y}; n2[NS - 1] = f2_t{(float)(int)q.z, (float)(int)q.w};
+        k2[0] = f2_t{c0.x, c0.y}; k2[NS - 1] = f2_t{c0.z, c0.w};
+    }
+    A[0] = n2[0] * k2[0];
+#pragma unroll
+    for (int s = 1; s < NS; s++) A[s] = __builtin_elementwise_fma(n2[s], k2[s], A[s - 1]);
+    const float ev = A[NS - 1].x;                                          // the even cells' sum; A[s].y: the running sums of the odd ones
+    const float acc = ev + A[NS - 1].y;
+    const float incl = wave_incl_scan_f_dpp(acc);
+    tot = bcast_f(incl, 63);
+    const unsigned long long pos = __builtin_amdgcn_ballot_w64(acc > 0.0f);
+    any = pos != 0;
+    if (!pos || !(force || base + tot > target)) return -1;
+    const unsigned long long hit = force ? 0ull : (__builtin_amdgcn_ballot_w64(base + incl > target) & pos);
+    const int hl = hit ? (int)__builtin_ctzll(hit) : 63 - (int)__builtin_clzll(pos);
+    const float thr = target - (base + (hl > 0 ? bcast_f(incl, hl - 1) : 0.0f));
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) cnt += (A[s].x <= thr) ? 1 : 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) cnt += (ev + A[s].y <= thr) ? 1 : 0;
+    int p = force ? CPL : bcast_i(cnt, hl);
+    if (p >= CPL) {
+        // every running sum of the lane stays at or below the target (rounding; or `force`): the last cell of the lane, in its order, that has mass
+        int lp = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) if (n2[s].x > 0.0f && k2[s].x > 0.0f) lp = s;
+#pragma unroll
+        for (int s = 0; s < NS; s++) if (n2[s].y > 0.0f && k2[s].y > 0.0f) lp = NS + s;
+        p = bcast_i(lp, hl);
+    }
+    return kb + hl * CPL + (p < NS ? 2 * p : 2 * (p - NS) + 1);
+}
+
+// in_lds: the view's coefficients (row padded to a multiple of 8 with zeros) come from LDS (cf_lds), else from global memory (cf_g)
+template <bool CELL16>
+__device__ __forceinline__ int row_sample_live(rowq_t q0, bool have_q0, bool in_lds, const __attribute__((address_space(3))) float* cf_lds, const float* __restrict__ cf_g, const float* __restrict__ smp, float S,
+                                                gptr_t rowp, int K, float u2f, float rootf, int lane, unsigned long long* t_after_wait)
+{
+    constexpr int CPL = CELL16 ? 8 : 4;
+    (void)t_after_wait;
+    float target = u2f * rootf;
+    if (target < S) return smoothing_sample_live(smp, K, target, lane);
+    target -= S;
+    float base = 0.0f;
+    int lastb = -1;
+    const int nb = (K + WAVE * CPL - 1) / (WAVE * CPL);
+    if (have_q0 && in_lds) {
+        // The common path, kept apart from the general loop below: row in registers since the top of the token's turn, coefficients from
+        // LDS -- no vector-memory operation is issued here, so the wait in front of the arithmetic is for the row alone (vmcnt counts in
+        // order: a load issued on ANY path through here would make the compiler wait for everything, the next token's gather included).
+        int kl = lane * CPL;
+        asm volatile("" : "+v"(kl));                                       // (formed here: hoisted out of the token loop it is spilled, and its reload is a vector-memory operation)
+        coefq_t c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (kl < K) {                                                      // (a lane beyond the row has no cells: the view's table ends at Kp, the last view's at the end of the block's)
+            c0 = *(const __attribute__((address_space(3))) coefq_t*)(cf_lds + kl);
+            if (CELL16) c1 = *(const __attribute__((address_space(3))) coefq_t*)(cf_lds + kl + 4);
+        }
+        float tot; bool any;
+#ifdef MVHDP_TIMING
+        { unsigned int probe = q0.x; asm volatile("v_mov_b32 %0, %0" : "+v"(probe)); *t_after_wait = __builtin_amdgcn_s_memtime(); }   // (the row has arrived)
+#endif
+        const int r = row_batch_pick<CELL16>(q0, c0, c1, 0, 0.0f, target, false, tot, any);
+        if (r >= 0) return r;
+        if (nb == 1) {
+            if (any) return row_batch_pick<CELL16>(q0, c0, c1, 0, 0.0f, 0.0f, true, tot, any);   // the target lies beyond the row's mass: the last cell that has any
+            return smoothing_sample_live(smp, K, u2f * S, lane);          // (a word without a counted token: a first visit of an unassigned one)
+        }
+    }
+    for (int pass = 0; pass < 2; pass++) {                                  // (pass 1: the target lies beyond the row's mass -- the last cell that has any)
+        for (int b = (pass ? lastb : 0); b < (pass ? lastb + 1 : nb); b++) {
+            const rowq_t q = (b == 0 && have_q0) ? q0 : row_batch_load<CELL16>(rowp, K, b, lane);
+            const int kl = (b * WAVE + lane) * CPL;                         // (the view's table is padded to Kp = K rounded up to 8: the lane that holds cell K-1 reads zeros behind it)
+            coefq_t c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (kl >= K) { }                                                // (a lane beyond the row has no cells)
+            else if (in_lds) {                                              // (ds_read_b128: counted by lgkmcnt, never behind a vector-memory operation)
+                c0 = *(const __attribute__((address_space(3))) coefq_t*)(cf_lds + kl);
+                if (CELL16) c1 = *(const __attribute__((address_space(3))) coefq_t*)(cf_lds + kl + 4);
+            } else {
+                c0 = *(const __attribute__((address_space(1))) coefq_t*)(cf_g + kl);
+                if (CELL16) c1 = *(const __attribute__((address_space(1))) coefq_t*)(cf_g + kl + 4);
+            }
+            float tot; bool any;
+            const int r = row_batch_pick<CELL16>(q, c0, c1, b * WAVE * CPL, base, target, pass != 0, tot, any);
+            if (r >= 0) return r;
+            if (any) lastb = b;
+            base += tot;
+        }
+        if (lastb < 0) break;
+    }
+    return smoothing_sample_live(smp, K, u2f * S, lane);                  // (a word without a counted token: a first visit of an unassigned one)
+}
+
 // ROOMY (the 2-round variant on the mirror only): the same kernel compiled for 6 waves per SIMD (80 registers, a third of the scratch
 // of the 72-register build): where a row of the mirror is 1 KiB or more (K >= 512; C5: K = 1000) the seventh wave hides less than the
 // spills cost -- C5's 2-round kernel 16.9 ms at 6 waves, 18.4 at 7; C4's (K = 400) gains 2 % at 7.
-template <int RMAX, bool DEBUG, bool WALK, bool NARROW, bool ROOMY = false>
-__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? (ROOMY ? MVHDP_LB2_ROOMY : MVHDP_LB2) : (RMAX == 1 ? (WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
+// LIVEROWS (walk flavour only): the live-rows form of a live sweep (SweepLaunch::live_rows) -- a flavour of its own so that the kernels of
+// every other mode stay what they were, register for register.
+template <int RMAX, bool DEBUG, bool WALK, bool NARROW, bool ROOMY = false, bool LIVEROWS = false>
+__global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? (ROOMY ? MVHDP_LB2_ROOMY : (LIVEROWS ? MVHDP_LB_ROWS : MVHDP_LB2)) : (RMAX == 1 ? (LIVEROWS ? MVHDP_LB_ROWS : WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef MVHDP_TIMING
@@ -124,6 +284,11 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     unsigned int* ent_s = hist_s + MVHDP_HIST_BINS;       // [MVHDP_ENT_BINS] entities by the kernel class of their NEW topic list
     unsigned int* vstat_s = ent_s + MVHDP_ENT_BINS;       // [MVHDP_MAXM][MVHDP_VIEW_STATS] per-view branch statistics of this block
     for (int i = threadIdx.x; i < nkd_len + MVHDP_HIST_BINS + MVHDP_ENT_BINS + (WALK ? MVHDP_MAXM * MVHDP_VIEW_STATS : 0); i += blockDim.x) nkd[i] = 0;
+    // live-rows form: the coefficient table of the segment (MvModel::coef, [M][Kp], Kp = K rounded up to 8, zero-padded) in LDS where the
+    // plan found room for it (SweepLaunch::coef_lds): the tree branch reads its coefficients without a vector-memory operation
+    const int Kp = (K + 7) & ~7;
+    float* const coef_s = (LIVEROWS && sl.coef_lds) ? (float*)(((uintptr_t)(vstat_s + MVHDP_MAXM * MVHDP_VIEW_STATS) + 15) & ~(uintptr_t)15) : nullptr;
+    if (LIVEROWS && coef_s) for (int i = threadIdx.x; i < M * Kp; i += blockDim.x) coef_s[i] = mm.coef[i];
     int32_t* const dnk_g = mm.delta + mm.rowbase[M] * K;    // n_k part of the delta buffer
     __syncthreads();
 #ifdef MVHDP_TIMING
@@ -164,7 +329,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
     unsigned int n_misclass = 0;
 #ifdef MVHDP_TIMING
     // diagnostics: where a wave's cycles go (s_memtime stamps at the segment borders; the stamps cost ~10 %)
-    unsigned long long tq = 0, tp = 0, tv = 0, th = 0, tt = 0, te = 0, t_ent[3] = {0, 0, 0}, n_ent[3] = {0, 0, 0};
+    unsigned long long tq = 0, tp = 0, tv = 0, th = 0, tt = 0, te = 0, t_ent[3] = {0, 0, 0}, n_ent[3] = {0, 0, 0}, t_rows = 0, t_rows_wait = 0;
     int e_ord = 0;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     unsigned long long t_last = t_begin;
@@ -327,6 +492,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
             };
             float rden32[RMAX], brden32[RMAX], oth32[RMAX];      // the fp32 forms the screening works with: 1/den, beta/den, oth
             const float beta32 = (float)beta_m, scale32 = (float)scale_m;
+            const float* const smp_m = mm.coef + (int64_t)M * Kp + (int64_t)m * K;                   // running sums of the smoothing parts coef_k * beta of the view's leaves
+            const float smS = LIVEROWS ? uniform_f(smp_m[K - 1]) : 0.0f;                             // S_m: their total
 #pragma unroll
             for (int r = 0; r < RMAX; r++) {
                 cn[r] = 0;
@@ -424,8 +591,14 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 // branch after all, walks on demand in the token loop (same table, same arithmetic, same topic).
                 double root_l = 0.0;
                 int zt_l = -1, st_l = -1;
-                const bool walk_l = tvalid && w_l >= 0 && (!WALK || u1_l >= walk_theta);
+                // live-rows form: only a HEAVY word's token walks a stored tree (heavy rows are not in the mirror, and a word of 65535 tokens and
+                // more moves its leaves by 1e-5 a token: its tree of the segment start is current enough); any other token that may reach
+                // the tree branch has its row loaded at the top of its turn (specm)
+                const bool heavy_l = NARROW && w_l >= 0 && (w_l & W_HEAVY);
+                const bool walk_l = tvalid && w_l >= 0 && (!WALK || u1_l >= walk_theta) && (!LIVEROWS || heavy_l);
                 const unsigned long long walked = WALK ? __ballot(walk_l) : ~0ull;
+                const unsigned long long specm = LIVEROWS ? __ballot(tvalid && w_l >= 0 && !heavy_l && u1_l >= walk_theta) : 0ull;
+                rowq_t rowq = {0u, 0u, 0u, 0u};
                 if (WALK && tvalid && w_l >= 0 && !walk_l) root_l = mm.root[row0 + W_ROW(w_l)];
                 {
                     const bool act = walk_l;
@@ -437,7 +610,16 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                     for (int bd = 0; bd < mm.dt_nbd; bd++) {
                         if (act && (bd == 0 || i < K)) {
                             const double2* __restrict__ blk = (const double2*)(dt + (int64_t)(mm.dt_base[bd] + (i - (1 << mm.dt_depth[bd]))) * 8);
-                            const double2 q0 = blk[0], q1 = blk[1], q2 = blk[2], q3 = blk[3];
+                            double2 q0, q1, q2, q3;
+                            if (LIVEROWS) {
+                                // (the heavy words' trees are being rewritten by heavy_refresh_kernel on another XCD while this kernel reads them:
+                                // loads of agent scope, past the L2 of this XCD, which plain stores of another one never reach)
+                                const double* bp = (const double*)blk;
+                                q0.x = __hip_atomic_load(bp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q0.y = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                q1.x = __hip_atomic_load(bp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q1.y = __hip_atomic_load(bp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                q2.x = __hip_atomic_load(bp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q2.y = __hip_atomic_load(bp + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                q3.x = __hip_atomic_load(bp + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q3.y = __hip_atomic_load(bp + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else { q0 = blk[0]; q1 = blk[1]; q2 = blk[2]; q3 = blk[3]; }
                             const int levels = (bd == 0) ? mm.dt_f : 3;
                             if (bd == 0) { root_l = q3.y; u = u2_l * root_l; }       // FT:120
                             int path = 0;
@@ -464,6 +646,8 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 
                 MVHDP_TSUB2(tv);                                             // (split 2: heavy flags, roots, the tree walk, the sampled topic's slot)
                 const float root32_l = (float)root_l;
+                // live-rows form: the tree branch's uniform is kept (the walk on demand of the other flavours draws it again: ten Philox rounds per tree-branch token)
+                const float u2f_l = LIVEROWS ? (float)u2_l : 0.0f;
                 MVHDP_TMAIN(th, te, tt);
                 // software pipeline: the n_wk values of the listed topics are gathered NB tokens ahead, into NB
                 // register buffers used in turn (the token loop is unrolled NB times so that no buffer is ever
@@ -639,6 +823,7 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
         for (int b = 0; b < 3; b++) { atomicAdd(&sl.stats[ST_T_ENT0 + b], t_ent[b]); atomicAdd(&sl.stats[ST_N_ENT0 + b], n_ent[b]); }
         atomicAdd(&sl.stats[ST_T_INIT], t_init_end - t_begin0); atomicAdd(&sl.stats[ST_T_FLUSH], (unsigned long long)__builtin_amdgcn_s_memtime() - t_loop_end);
         atomicAdd(&sl.stats[ST_N_WAVES], 1ull);
+        atomicAdd(&sl.stats[ST_T_ROWS], t_rows); atomicAdd(&sl.stats[ST_T_ROWS_WAIT], t_rows_wait);
 #endif
     }
 }
@@ -650,8 +835,12 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 static bool roomy_build(int rmax, int K) { return rmax == 2 && K >= 512; }
 
 template <int RMAX>
-static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow, int K = 0)
+static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow, int K = 0, bool live_rows = false)
 {
+    if (live_rows && !debug) {
+        if constexpr (RMAX == 2) { if (narrow && roomy_build(RMAX, K)) return (const void*)sweep_fast_kernel<2, false, true, true, true, true>; }
+        return narrow ? (const void*)sweep_fast_kernel<RMAX, false, true, true, false, true> : (const void*)sweep_fast_kernel<RMAX, false, true, false, false, true>;
+    }
     if (narrow && walk && !debug) {
         if constexpr (RMAX == 2) { if (roomy_build(RMAX, K)) return (const void*)sweep_fast_kernel<2, false, true, true, true>; }
         return (const void*)sweep_fast_kernel<RMAX, false, true, true>;
@@ -666,11 +855,17 @@ static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid
     size_t lds = sl.block_shared_bytes + (size_t)sl.waves_per_block * sl.wave_bytes;
     dim3 block(64 * sl.waves_per_block);
     const bool narrow = sl.narrow && sl.walk && !debug;
+    const bool rows = sl.live_rows && sl.walk && !debug;
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0, narrow, mm.K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fast_kernel_ptr<RMAX>(debug, sl.walk != 0, narrow, mm.K, rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
+    else if (rows) {
+        if (narrow && roomy_build(RMAX, mm.K)) { if constexpr (RMAX == 2) hipLaunchKernelGGL((sweep_fast_kernel<2, false, true, true, true, true>), dim3(grid_blocks), block, lds, s, mm, sl); }
+        else if (narrow) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, true, false, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+        else             hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, false, false, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+    }
     else if (narrow && roomy_build(RMAX, mm.K)) {
         // (the plan sized the grid for the 72-register build: the seventh block of a CU waits for a free slot and finds the queue empty)
         if constexpr (RMAX == 2) hipLaunchKernelGGL((sweep_fast_kernel<2, false, true, true, true>), dim3(grid_blocks), block, lds, s, mm, sl);

@@ -91,6 +91,8 @@ def lib():
     L.orc_sweep.restype = C.c_int
     L.orc_sweep_list.argtypes = [vp, u32, u64, i64, vp, u32, P(Stats), vp, vp, vp, i64]
     L.orc_sweep_list.restype = C.c_int
+    L.orc_sweep_live_seq.argtypes = [vp, u32, u64, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, P(Stats)]
+    L.orc_sweep_live_seq.restype = C.c_int
     L.orc_apply_delta.argtypes = [vp, vp, vp, i32, i32]
     L.orc_log_gamma_stirling.argtypes = [dbl]; L.orc_log_gamma_stirling.restype = dbl
     L.orc_mallet_digamma.argtypes = [dbl]; L.orc_mallet_digamma.restype = dbl
@@ -272,6 +274,18 @@ class Oracle:
         if rc:
             raise RuntimeError(f"orc_sweep_list rc={rc}")
         return dict(stats=st.as_dict(), delta_nwk=dn, delta_nk=dk)
+
+    def sweep_live_seq(self, sweep_idx, seed, order, nseg=1, rows=1, cell16=1, p=None, doc_id_base=0):
+        """MVHDP_SWEEP_LIVE as the sequential algorithm it is with one resident wavefront (mvhdp_tuning.single_wave): entities in
+        `order`, n_wk deltas landing at every 64-token chunk end, n_k / coefficients / roots of the segment start."""
+        st = Stats()
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        if p is not None:
+            p = np.ascontiguousarray(p, dtype=np.float64)
+        rc = self.L.orc_sweep_live_seq(self.h, int(sweep_idx), int(seed), int(doc_id_base), _ptr(p), _ptr(order), len(order), int(nseg), int(rows), int(cell16), C.byref(st))
+        if rc:
+            raise RuntimeError(f"orc_sweep_live_seq rc={rc}")
+        return dict(stats=st.as_dict())
 
     def apply_delta(self, dn, dk, act_topic=-1, act_modality=-1):
         dn = np.ascontiguousarray(dn, dtype=np.int32)

@@ -844,6 +844,309 @@ static int sweep_impl(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t d
     return 0;
 }
 
+/* ======================================================================== */
+/* The LIVE sweep as a sequential algorithm (MVHDP_SWEEP_LIVE with ONE resident  */
+/* wavefront: mvhdp_tuning.single_wave).  UPD:197-218 applied while WRK:425-590 */
+/* samples, with the visibility rule of the product's kernels:                  */
+/*   n_wk   a token sees the deltas of every earlier 64-token chunk (of any     */
+/*          entity) -- a chunk's FastQDelta records land together at its end    */
+/*   n_k    of the segment start (the block's private table lands at the        */
+/*          kernel's end); so are the coefficients and tree[1] of every word    */
+/*   tree branch (WRK:533-535)                                                  */
+/*     rows = 0   the stored trees of the segment start (FT:111-136)            */
+/*     rows = 1   the word's LIVE row: the arithmetic of row_sample_live        */
+/*                (mvhdp_sweep_fast.hip) restated operation for operation --    */
+/*                fp32, the DPP scan's order of additions, the packed fused     */
+/*                multiply-adds; cell16 = 1 (the 16-bit mirror: eight cells a   */
+/*                lane; a HEAVY word -- more than 65534 tokens at the sweep     */
+/*                start -- walks its stored tree) or 0 (32-bit rows: four)      */
+/* Entities are visited in `order` (the product's longest-first order), segment */
+/* s taking positions s, s + nseg, ...; a topic is activated (UPD:263-270) at   */
+/* the end of the segment whose delta reached it first.                         */
+/* ======================================================================== */
+
+/* wave_incl_scan_f_dpp (mvhdp_wave.h): row_shr 1, 2, 4, 8 inside rows of 16 lanes, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 */
+static void scan64_f32(float v[64])
+{
+    float t[64];
+    for (int sh = 1; sh <= 8; sh <<= 1) {
+        for (int i = 0; i < 64; i++) t[i] = ((i & 15) >= sh) ? v[i - sh] : 0.0f;
+        for (int i = 0; i < 64; i++) v[i] = v[i] + t[i];
+    }
+    for (int i = 0; i < 64; i++) t[i] = v[i];
+    for (int i = 16; i < 32; i++) v[i] = t[i] + t[15];
+    for (int i = 48; i < 64; i++) v[i] = t[i] + t[47];
+    for (int i = 0; i < 64; i++) t[i] = v[i];
+    for (int i = 32; i < 64; i++) v[i] = t[i] + t[31];
+}
+
+static int smoothing_sample_live(const float* smp, int K, float t)
+{
+    for (int k = 0; k < K; k++) if (smp[k] > t) return k;
+    return K - 1;
+}
+
+/* row_batch_pick: cells (b*64 + lane)*CPL + j of the row; coefficients zero from K on */
+static int row_batch_pick(const int32_t* row, const float* cf, int K, int cpl, int b, float base, float target, int force, float* tot, int* any)
+{
+    const int ns = cpl / 2;
+    float Ax[64][4], Ay[64][4], nx[64][4], ny[64][4], kx[64][4], ky[64][4], acc[64], incl[64];
+    for (int l = 0; l < 64; l++) {
+        const int kl = (b * 64 + l) * cpl;
+        for (int s2 = 0; s2 < ns; s2++) {
+            const int ke = kl + 2 * s2, ko = ke + 1;
+            nx[l][s2] = (kl < K && ke < K) ? (float)row[ke] : 0.0f; ny[l][s2] = (kl < K && ko < K) ? (float)row[ko] : 0.0f;
+            kx[l][s2] = (kl < K && ke < K) ? cf[ke] : 0.0f;         ky[l][s2] = (kl < K && ko < K) ? cf[ko] : 0.0f;
+        }
+        Ax[l][0] = nx[l][0] * kx[l][0]; Ay[l][0] = ny[l][0] * ky[l][0];
+        for (int s2 = 1; s2 < ns; s2++) { Ax[l][s2] = fmaf(nx[l][s2], kx[l][s2], Ax[l][s2 - 1]); Ay[l][s2] = fmaf(ny[l][s2], ky[l][s2], Ay[l][s2 - 1]); }
+        acc[l] = Ax[l][ns - 1] + Ay[l][ns - 1];
+        incl[l] = acc[l];
+    }
+    scan64_f32(incl);
+    *tot = incl[63];
+    int first_pos = -1, last_pos = -1;
+    for (int l = 0; l < 64; l++) if (acc[l] > 0.0f) { if (first_pos < 0) first_pos = l; last_pos = l; }
+    *any = last_pos >= 0;
+    if (last_pos < 0 || !(force || base + *tot > target)) return -1;
+    int hl = last_pos;
+    if (!force) for (int l = 0; l < 64; l++) if (acc[l] > 0.0f && base + incl[l] > target) { hl = l; break; }
+    const float thr = target - (base + (hl > 0 ? incl[hl - 1] : 0.0f));
+    const float ev = Ax[hl][ns - 1];
+    int cnt = 0;
+    for (int s2 = 0; s2 < ns; s2++) cnt += (Ax[hl][s2] <= thr) ? 1 : 0;
+    for (int s2 = 0; s2 < ns; s2++) cnt += (ev + Ay[hl][s2] <= thr) ? 1 : 0;
+    int pp = force ? cpl : cnt;
+    if (pp >= cpl) {
+        int lp = 0;
+        for (int s2 = 0; s2 < ns; s2++) if (nx[hl][s2] > 0.0f && kx[hl][s2] > 0.0f) lp = s2;
+        for (int s2 = 0; s2 < ns; s2++) if (ny[hl][s2] > 0.0f && ky[hl][s2] > 0.0f) lp = ns + s2;
+        pp = lp;
+    }
+    return b * 64 * cpl + hl * cpl + (pp < ns ? 2 * pp : 2 * (pp - ns) + 1);
+}
+
+int orc_row_sample_live(const int32_t* row, const float* cf, const float* smp, int K, int cell16, float u2f, float rootf)
+{
+    const int cpl = cell16 ? 8 : 4;
+    const float S = smp[K - 1];
+    float target = u2f * rootf;
+    if (target < S) return smoothing_sample_live(smp, K, target);
+    target -= S;
+    float base = 0.0f;
+    int lastb = -1;
+    const int nb = (K + 64 * cpl - 1) / (64 * cpl);
+    for (int b = 0; b < nb; b++) {
+        float tot; int any;
+        const int r = row_batch_pick(row, cf, K, cpl, b, base, target, 0, &tot, &any);
+        if (r >= 0) return r;
+        if (any) lastb = b;
+        base += tot;
+    }
+    if (lastb >= 0) { float tot; int any; return row_batch_pick(row, cf, K, cpl, lastb, 0.0f, 0.0f, 1, &tot, &any); }
+    return smoothing_sample_live(smp, K, u2f * S);
+}
+
+typedef struct {
+    float* coef;      /* [M][K] */
+    float* smp;       /* [M][K] */
+    double* root;     /* [sumV] */
+    uint8_t* heavy;   /* [sumV] more than 65534 tokens at the sweep start */
+    int32_t* nk_seg;  /* [M][K] tokensPerTopic of the segment start */
+    int32_t* nk_delta;
+} live_state;
+
+/* live_coef_kernel + live_rows_prepare_kernel (mvhdp_kernels.hip) */
+static void live_prepare(orc_model* o, live_state* ls, int rows, int cell16, int sweep_start)
+{
+    const int K = o->K, M = o->M;
+    const int64_t nrows = o->rowbase[M];
+    memcpy(ls->nk_seg, o->nk, (size_t)M * K * sizeof(int32_t));
+    memset(ls->nk_delta, 0, (size_t)M * K * sizeof(int32_t));
+    orc_build_trees(o);                                   /* the stored trees of the segment start (all of them: only some are read) */
+    if (sweep_start)
+        for (int64_t r = 0; r < nrows; r++) {
+            long long sum = 0;
+            for (int k = 0; k < K; k++) { const int c = o->nwk[(size_t)r * K + k]; sum += c < 0 ? 70000 : c; }
+            ls->heavy[r] = sum > 65534;
+        }
+    if (!rows) { for (int64_t r = 0; r < nrows; r++) ls->root[r] = o->trees[(size_t)r * 2 * K + 1]; return; }
+    for (int m = 0; m < M; m++) {
+        float* cf = ls->coef + (size_t)m * K; float* smp = ls->smp + (size_t)m * K;
+        for (int k = 0; k < K; k++)
+            cf[k] = o->inactive[k] ? 0.0f : (float)(o->gamma[m] * o->alpha[(size_t)m * (K + 1) + k] / ((double)o->nk[(size_t)m * K + k] + o->beta_sum[m]));
+        const float beta32 = (float)o->beta[m];
+        float run = 0.0f;
+        for (int k = 0; k < K; k++) { run += cf[k] * beta32; smp[k] = run; }
+        for (int64_t r = o->rowbase[m]; r < o->rowbase[m + 1]; r++) {
+            if (cell16 && ls->heavy[r]) { ls->root[r] = o->trees[(size_t)r * 2 * K + 1]; continue; }   /* build_trees_kernel(only_heavy) overwrites it */
+            double acc[64];
+            for (int l = 0; l < 64; l++) { acc[l] = 0.0; for (int k = l; k < K; k += 64) acc[l] += (double)cf[k] * (double)o->nwk[(size_t)r * K + k]; }
+            for (int sft = 32; sft >= 1; sft >>= 1) { double t[64]; for (int l = 0; l < 64; l++) t[l] = acc[l] + acc[l ^ sft]; memcpy(acc, t, sizeof t); }
+            ls->root[r] = (double)smp[K - 1] + acc[0];
+        }
+    }
+}
+
+/* WRK:301-601 for one entity of a live sweep (see the head of this section) */
+static int sample_one_doc_live(orc_model* o, live_state* ls, int rows, int cell16, int64_t d, int64_t doc_global, uint32_t sweep, uint64_t seed,
+                               const double* p, int first_inactive, orc_stats* st, int64_t* act_key,
+                               int32_t* localTopicCounts, int32_t* localTopicIndex, double* topicDocWordMasses, double* totalMassOtherModalities)
+{
+    const int K = o->K, M = o->M;
+    int docLength[ORC_MAX_M];
+    memset(localTopicCounts, 0, (size_t)M * K * sizeof(int32_t));
+    for (int m = 0; m < M; m++) {
+        docLength[m] = 0;
+        if (o->doc_off[m]) {
+            int64_t b = o->doc_off[m][d], e = o->doc_off[m][d + 1];
+            docLength[m] = (int)(e - b);
+            for (int64_t i = b; i < e; i++) if (o->z[m][i] != -1) localTopicCounts[(size_t)m * K + o->z[m][i]]++;
+        }
+    }
+    int denseIndex = 0;
+    for (int topic = 0; topic < K; topic++) {
+        int i = 0, found = 0;
+        while (i < M && !found) { if (localTopicCounts[(size_t)i * K + topic] != 0) { localTopicIndex[denseIndex++] = topic; found = 1; } i++; }
+    }
+    int nonZeroTopics = denseIndex;
+    for (int m = 0; m < M; m++) {
+        for (int k = 0; k < K; k++) totalMassOtherModalities[k] = 0;
+        for (denseIndex = 0; denseIndex < nonZeroTopics; denseIndex++) {
+            int topic = localTopicIndex[denseIndex];
+            for (int i = 0; i < M; i++)
+                if (i != m && docLength[i] != 0)
+                    totalMassOtherModalities[topic] += p[m * M + i]
+                        * (localTopicCounts[(size_t)i * K + topic] + o->gamma[i] * o->alpha[(size_t)i * (K + 1) + topic])
+                        / (docLength[i] + (double)o->gamma[i] * o->alpha_sum[i]);
+            totalMassOtherModalities[topic] = totalMassOtherModalities[topic] * (docLength[m] + (double)o->gamma[m] * o->alpha_sum[m]);
+        }
+        double newAll = 0;
+        for (int i = 0; i < M; i++) newAll += p[m * M + i] * (o->gamma[i] * o->alpha[(size_t)i * (K + 1) + K]) / (docLength[i] + (double)o->gamma[i] * o->alpha_sum[i]);
+        newAll = newAll * (docLength[m] + (double)o->gamma[m] * o->alpha_sum[m]);
+        if (docLength[m] == 0) continue;
+        const int64_t base = o->doc_off[m][d];
+        /* the FastQDelta records of the current 64-token chunk: (type, old, new), applied together at its end */
+        int32_t ch_type[64], ch_old[64], ch_new[64]; int64_t ch_key[64]; int n_ch = 0;
+        for (int position = 0; position < docLength[m]; position++) {
+            const int type = o->tokens[m][base + position];
+            if (type >= o->V[m]) { st->oov_skipped++; goto chunk_end; }
+            {
+                const int oldTopic = o->z[m][base + position];
+                const size_t r = (size_t)(o->rowbase[m] + type);
+                const int32_t* cnt = o->nwk + r * K;
+                if (oldTopic != -1) {
+                    localTopicCounts[(size_t)m * K + oldTopic]--;
+                    int del = localTopicCounts[(size_t)m * K + oldTopic] == 0;
+                    int jj = 0;
+                    while (del && jj < M) { del = localTopicCounts[(size_t)jj * K + oldTopic] == 0; jj++; }
+                    if (del) {
+                        denseIndex = 0;
+                        while (localTopicIndex[denseIndex] != oldTopic) { denseIndex++; if (denseIndex >= K) return 1; }
+                        while (denseIndex < nonZeroTopics) { if (denseIndex < K - 1) localTopicIndex[denseIndex] = localTopicIndex[denseIndex + 1]; denseIndex++; }
+                        nonZeroTopics--;
+                    }
+                }
+                double mass = 0.0;
+                for (denseIndex = 0; denseIndex < nonZeroTopics; denseIndex++) {
+                    int topic = localTopicIndex[denseIndex];
+                    int n = localTopicCounts[(size_t)m * K + topic];
+                    double p_wt = (cnt[topic] + o->beta[m]) / (ls->nk_seg[(size_t)m * K + topic] + o->beta_sum[m]);
+                    mass += (p[m * M + m] * n + totalMassOtherModalities[topic]) * p_wt;
+                    topicDocWordMasses[denseIndex] = mass;
+                }
+                const double newTopicMass = (first_inactive < 0) ? 0 : newAll / K;
+                double u1, u2;
+                orc_token_uniforms(seed, sweep, doc_global, m, (uint32_t)position, &u1, &u2);
+                const double root = ls->root[r];
+                double sample = u1 * (newTopicMass + mass + root);
+                int newTopic = -1;
+                if (sample < newTopicMass) { st->new_mass_cnt++; newTopic = first_inactive; }
+                else {
+                    sample -= newTopicMass;
+                    if (sample < mass) {
+                        st->topic_doc_mass_cnt++;
+                        int lb = orc_lower_bound(topicDocWordMasses, sample, nonZeroTopics);
+                        if (lb < 0) return 1;
+                        newTopic = localTopicIndex[lb];
+                    } else {
+                        st->word_ftree_mass_cnt++;
+                        if (!rows || (cell16 && ls->heavy[r])) newTopic = orc_ftree_sample(o->trees + r * 2 * K, K, u2);
+                        else newTopic = orc_row_sample_live(cnt, ls->coef + (size_t)m * K, ls->smp + (size_t)m * K, K, cell16, (float)u2, (float)root);
+                        if (newTopic == -2) return 1;
+                    }
+                }
+                if (newTopic == -1) newTopic = K - 1;
+                o->z[m][base + position] = newTopic;
+                localTopicCounts[(size_t)m * K + newTopic]++;
+                st->tokens++;
+                if (newTopic != oldTopic) {
+                    st->changed++;
+                    ch_type[n_ch] = type; ch_old[n_ch] = oldTopic; ch_new[n_ch] = newTopic;
+                    ch_key[n_ch] = (int64_t)(((uint64_t)doc_global << 34) | ((uint64_t)m << 31) | ((uint64_t)position << 11) | (uint64_t)newTopic);
+                    n_ch++;
+                }
+            }
+        chunk_end:
+            if ((position & 63) == 63 || position == docLength[m] - 1) {
+                for (int i = 0; i < n_ch; i++) {
+                    const size_t rr = (size_t)(o->rowbase[m] + ch_type[i]) * K;
+                    if (ch_old[i] != -1) { o->nwk[rr + ch_old[i]]--; ls->nk_delta[(size_t)m * K + ch_old[i]]--; }
+                    o->nwk[rr + ch_new[i]]++; ls->nk_delta[(size_t)m * K + ch_new[i]]++;
+                    if (o->inactive[ch_new[i]] && ch_key[i] < *act_key) *act_key = ch_key[i];
+                }
+                n_ch = 0;
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_sweep_live_seq(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base, const double* p_in,
+                       const int64_t* order, int64_t n_order, int nseg, int rows, int cell16, orc_stats* st)
+{
+    const int K = o->K, M = o->M;
+    const int64_t nrows = o->rowbase[M];
+    orc_stats local; memset(&local, 0, sizeof local);
+    local.activated_topic = -1; local.activated_modality = -1; local.activation_key = INT64_MAX;
+    double* p_own = NULL;
+    const double* p = p_in;
+    if (!p) { p_own = (double*)malloc((size_t)(o->D > 0 ? o->D : 1) * M * M * sizeof(double)); orc_draw_p_philox(o, seed, sweep_idx, doc_id_base, p_own); p = p_own; }
+    live_state ls;
+    ls.coef = (float*)calloc((size_t)M * K, sizeof(float)); ls.smp = (float*)calloc((size_t)M * K, sizeof(float));
+    ls.root = (double*)calloc((size_t)(nrows > 0 ? nrows : 1), sizeof(double)); ls.heavy = (uint8_t*)calloc((size_t)(nrows > 0 ? nrows : 1), 1);
+    ls.nk_seg = (int32_t*)calloc((size_t)M * K, sizeof(int32_t)); ls.nk_delta = (int32_t*)calloc((size_t)M * K, sizeof(int32_t));
+    int32_t* localTopicCounts = (int32_t*)malloc((size_t)M * K * sizeof(int32_t));
+    int32_t* localTopicIndex = (int32_t*)malloc((size_t)(K + 1) * sizeof(int32_t));
+    double* topicDocWordMasses = (double*)malloc((size_t)(K + 1) * sizeof(double));
+    double* totalMassOtherModalities = (double*)malloc((size_t)K * sizeof(double));
+    if (nseg < 1) nseg = 1;
+    for (int seg = 0; seg < nseg; seg++) {
+        int first_inactive = -1;
+        for (int k = 0; k < K; k++) if (o->inactive[k]) { first_inactive = k; break; }
+        live_prepare(o, &ls, rows, cell16, seg == 0);
+        int64_t act_key = INT64_MAX;
+        for (int64_t q = seg; q < n_order; q += nseg) {
+            const int64_t d = order[q];
+            if (d < 0 || d >= o->D) continue;
+            memset(localTopicIndex, 0, (size_t)(K + 1) * sizeof(int32_t));
+            topicDocWordMasses[0] = 0;
+            if (sample_one_doc_live(o, &ls, rows, cell16, d, doc_id_base + d, sweep_idx, seed, p + (size_t)d * M * M, first_inactive, &local, &act_key,
+                                    localTopicCounts, localTopicIndex, topicDocWordMasses, totalMassOtherModalities)) local.aborted_docs++;
+        }
+        for (size_t i = 0; i < (size_t)M * K; i++) o->nk[i] += ls.nk_delta[i];          /* the block's private tokensPerTopic table lands */
+        if (act_key != INT64_MAX) {                                                    /* UPD:263-270 at the segment's end */
+            const int t = (int)(act_key & 0x7ff), mv = (int)((act_key >> 31) & 7);
+            if (o->inactive[t]) { o->inactive[t] = 0; o->alpha[(size_t)mv * (K + 1) + t] = o->alpha[(size_t)mv * (K + 1) + K]; }
+            if (local.activated_topic < 0) { local.activated_topic = t; local.activated_modality = mv; local.activation_key = act_key; }
+        }
+    }
+    free(ls.coef); free(ls.smp); free(ls.root); free(ls.heavy); free(ls.nk_seg); free(ls.nk_delta);
+    free(localTopicCounts); free(localTopicIndex); free(topicDocWordMasses); free(totalMassOtherModalities); free(p_own);
+    if (st) *st = local;
+    return 0;
+}
+
 void orc_apply_delta(orc_model* o, const int32_t* delta_nwk, const int32_t* delta_nk,
                      int32_t act_topic, int32_t act_modality)
 {

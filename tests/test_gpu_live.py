@@ -244,39 +244,49 @@ def test_live_sweep_over_unassigned_tokens_stays_off_the_16_bit_mirror():
     s.close()
 
 
-@pytest.mark.parametrize("K,V,D,lam,cseed", [(40, [500, 60, 50], 150, [40, 5, 6], 41), (200, [3000, 300], 120, [160, 9], 42)])
-def test_one_wave_live_sweep_is_sequential_so_the_mirror_form_equals_the_32_bit_form(K, V, D, lam, cseed):
-    """The deterministic pin of the live sweep's two forms.  With ONE resident wavefront, ONE segment and every chunk's atomics waited
-    for (mvhdp_tuning.single_wave) a live sweep is the sequential algorithm: every token sees every earlier update.  The form that
-    keeps the light rows in the 16-bit mirror (packed +-1 / +-65536 atomics, 2-byte gathers, trees from the mirror, widen at the end)
-    and the form on the 32-bit table must then give the same assignments and the same counts, integer for integer."""
+def _longest_first(doc_off):
+    """the product's work-queue order: entities by decreasing token count over all views, ties in entity order (mvhdp_api.hip)"""
+    tot = sum(np.diff(np.asarray(o)) for o in doc_off)
+    return np.argsort(-tot, kind="stable").astype(np.int64)
+
+
+def _one_wave_against_the_oracle(o, s, order, M, sweeps, nseg, rows, live16, seed):
+    for it in range(sweeps):
+        ro = o.sweep_live_seq(it, seed, order, nseg=nseg, rows=rows, cell16=live16)["stats"]
+        st = s.sweep(it, seed, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(nseg))
+        assert (st.tokens, st.changed) == (ro["tokens"], ro["changed"]), f"sweep {it}: {st.changed} changed against the oracle's {ro['changed']}"
+        assert (st.new_mass_cnt, st.topic_doc_mass_cnt, st.word_ftree_mass_cnt) == (ro["new_mass_cnt"], ro["topic_doc_mass_cnt"], ro["word_ftree_mass_cnt"])
+        assert st.word_ftree_mass_cnt > 0
+        assert_same_state(o, s, M)
+
+
+@pytest.mark.parametrize("rows", [1, 0])
+@pytest.mark.parametrize("live16", [0, 1])
+@pytest.mark.parametrize("nseg", [1, 3])
+@pytest.mark.parametrize("K,V,D,lam,cseed,force", [(40, [500, 60, 50], 150, [40, 5, 6], 41, 1), (200, [3000, 300], 120, [160, 9], 42, 4), (600, [900, 90], 60, [200, 30], 43, 16)])
+def test_one_wave_live_sweep_equals_the_sequential_oracle(K, V, D, lam, cseed, force, nseg, live16, rows):
+    """The live sweep against the oracle (the live path was only ever compared with itself).  With ONE resident wavefront and
+    every chunk's atomics waited for (mvhdp_tuning.single_wave) a live sweep is a sequential algorithm with a defined visibility rule --
+    a token sees the n_wk deltas of every earlier 64-token chunk, tokensPerTopic / coefficients / roots of the segment start -- which
+    oracle/mvhdp_oracle.c::orc_sweep_live_seq restates (UPD:197-218 applied while WRK:425-590 samples).  Both forms of the tree branch:
+    rows = 1 the word's live count row (8 cells a lane on the 16-bit mirror, live16 = 1; 4 on the 32-bit table), rows = 0 stored trees of
+    the segment start; every integer must agree: assignments, n_wk, n_k, the branch counters.  K = 600: two batches of the mirror's row."""
     c = small_corpus(K, V, D, lam, cseed)
     hy = Hyper.defaults(K, V)
     o = make_oracle(c, hy)
-    z = [o.get_assignments(m) for m in range(c.M)]
-    a, b = make_native(c, hy, z), make_native(c, hy, z)
-    a.set_tuning(live16=0, single_wave=1)
-    b.set_tuning(live16=1, single_wave=1)
-    for it in range(4):
-        sa = a.sweep(it, 13, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1))
-        sb = b.sweep(it, 13, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1))
-        assert sa.tokens == sb.tokens == c.total_tokens and sa.changed == sb.changed
-        assert (sa.new_mass_cnt, sa.topic_doc_mass_cnt, sa.word_ftree_mass_cnt) == (sb.new_mass_cnt, sb.topic_doc_mass_cnt, sb.word_ftree_mass_cnt)
-        for m in range(c.M):
-            assert np.array_equal(a.get_assignments(m), b.get_assignments(m)), f"sweep {it}: assignments differ in view {m}"
-            (wa, ka), (wb, kb) = a.get_counts(m), b.get_counts(m)
-            assert np.array_equal(wa, wb) and np.array_equal(ka, kb)
-        _check_counts_are_counts_of_z(c, b, K)
-    # ... and it is not the deferred sweep (the updates ARE seen): a third handle, deferred, same stream, different assignments
-    d = make_native(c, hy, z)
-    d.sweep(0, 13)
-    assert any(not np.array_equal(d.get_assignments(m), z[m]) for m in range(c.M))
-    a.close(); b.close(); d.close()
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    # one kernel per segment (a class kernel's end is where its block's tokensPerTopic lands): the primary variant holds every list
+    s.set_tuning(live16=live16, single_wave=1, live_rows=rows, force_primary=force)
+    _one_wave_against_the_oracle(o, s, _longest_first(c.doc_off), c.M, 3, nseg, rows, live16, 13)
+    s.close()
 
 
-def test_one_wave_live_sweep_with_a_heavy_row():
-    """The same pin where one type holds more than 65534 tokens (a heavy row: its counts stay on the 32-bit table in both forms)."""
+@pytest.mark.parametrize("live16", [0, 1])
+def test_one_wave_live_sweep_with_a_heavy_row_equals_the_oracle(live16):
+    """... where one type holds more than 65534 tokens: on the mirror (live16 = 1) a heavy word's tree branch walks its stored tree of
+    the segment start (its cells pass 16 bits), on the 32-bit table it reads its live row like any other."""
     from mvtopicmodel_amd import NativeSampler
+    from oracle.binding import Oracle
     K, V = 8, [40]
     rng = np.random.default_rng(6)
     D, L = 700, 100
@@ -285,18 +295,45 @@ def test_one_wave_live_sweep_with_a_heavy_row():
     assert np.count_nonzero(tok == 0) > 65535
     off = (np.arange(D + 1) * L).astype(np.int64)
     z0 = rng.integers(0, K, size=D * L).astype(np.int32)
-    hs = []
-    for l16 in (0, 1):
-        s = NativeSampler(K, V, device=0)
-        s.set_corpus(0, off, tok); s.set_assignments(0, z0)
-        s.set_hyper(Hyper.defaults(K, V)); s.build_counts()
-        s.set_tuning(live16=l16, single_wave=1)
-        hs.append(s)
-    for it in range(2):
-        for s in hs:
-            s.sweep(it, 17, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1))
-        assert np.array_equal(hs[0].get_assignments(0), hs[1].get_assignments(0))
-        (wa, ka), (wb, kb) = hs[0].get_counts(0), hs[1].get_counts(0)
-        assert np.array_equal(wa, wb) and np.array_equal(ka, kb)
-    for s in hs:
-        s.close()
+    hy = Hyper.defaults(K, V)
+    o = Oracle(K, V)
+    o.set_corpus(0, off, tok); o.set_assignments(0, z0)
+    o.set_hyper(hy.alpha, hy.alpha_sum, hy.beta, hy.beta_sum, hy.gamma, hy.p_a, hy.p_b, hy.inactive)
+    o.build_counts()
+    s = NativeSampler(K, V, device=0)
+    s.set_corpus(0, off, tok); s.set_assignments(0, z0)
+    s.set_hyper(hy); s.build_counts()
+    s.set_tuning(live16=live16, single_wave=1, force_primary=1)
+    _one_wave_against_the_oracle(o, s, _longest_first([off]), 1, 2, 2, 1, live16, 17)
+    s.close()
+
+
+def test_one_wave_live_sweep_with_unassigned_tokens_and_an_inactive_topic_equals_the_oracle():
+    """... with tokens that have no topic yet (z = -1: a first visit only adds; such a sweep stays off the mirror) and a truncated HDP
+    (inActiveTopicIndex not empty: the new-topic branch WRK:522-526, a topic activated at the end of the segment whose delta reached it
+    first, UPD:263-270, its coefficient zero until then)."""
+    K, V = 50, [600, 70]
+    c = small_corpus(K, V, 140, [50, 7], 44)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[[41, 47]] = 1
+    hy = Hyper.defaults(K, V, inactive=inactive); hy.alpha[:, K] = 30.0
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(c.M)]
+    for m in range(c.M):
+        z[m][np.isin(z[m], [41, 47])] = 3
+        z[m][::11] = -1
+        o.set_assignments(m, z[m])
+    o.build_counts()
+    s = make_native(c, hy, z)
+    s.set_tuning(live16=1, single_wave=1, force_primary=1)               # (asked for, and refused by the plan while a token is unassigned)
+    order = _longest_first(c.doc_off)
+    acts = 0
+    for it in range(3):
+        ro = o.sweep_live_seq(it, 21, order, nseg=2, rows=1, cell16=0 if it == 0 else 1)["stats"]
+        st = s.sweep(it, 21, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(2))
+        assert st.changed == ro["changed"] and st.new_mass_cnt == ro["new_mass_cnt"]
+        acts += st.activations
+        assert_same_state(o, s, c.M)
+        a, ina = s.get_alpha()
+        assert np.array_equal(a, o.get_alpha()) and np.array_equal(ina, o.get_inactive())
+    assert acts >= 1
+    s.close()
