@@ -318,8 +318,9 @@ typedef struct {
     int32_t class_used[6], class_map[6], class_stream[6], class_grid[6], class_walk[6], class_narrow[6], class_register_resident[6];
     int64_t class_lds_bytes[6];
     double  class_theta0[6];                     /* walk threshold of view 0 for that class's kernel */
-    int32_t delta16, reserved;                   /* 1: the sweep keeps the n_wk deltas of rows with at most 32767 tokens in 16-bit cells (half the table the
-                                                    chunk-end atomics land in); plain deferred sweeps only */
+    int32_t delta16, live_rows;                  /* delta16 1: the sweep keeps the n_wk deltas of rows with at most 32767 tokens in 16-bit cells (half the table the
+                                                    chunk-end atomics land in), plain deferred sweeps only; live_rows 1: a live sweep in its live-rows form
+                                                    (mvhdp_tuning.live_rows) */
 } mvhdp_plan_output;
 int mvhdp_plan_probe(const mvhdp_plan_input* in, const mvhdp_tuning* tuning /* or NULL */, mvhdp_plan_output* out);
 /* The search alone: a kernel whose time per token at threshold step i is ns_by_step[i] (i = 0..20); steps_out[k] = the

@@ -92,7 +92,7 @@ class PlanOutputC(C.Structure):
                 ("class_used", C.c_int32 * 6), ("class_map", C.c_int32 * 6), ("class_stream", C.c_int32 * 6),
                 ("class_grid", C.c_int32 * 6), ("class_walk", C.c_int32 * 6), ("class_narrow", C.c_int32 * 6),
                 ("class_register_resident", C.c_int32 * 6), ("class_lds_bytes", C.c_int64 * 6), ("class_theta0", C.c_double * 6),
-                ("delta16", C.c_int32), ("reserved", C.c_int32)]
+                ("delta16", C.c_int32), ("live_rows", C.c_int32)]
 
 
 _lib = None

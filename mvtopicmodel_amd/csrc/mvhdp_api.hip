@@ -1567,6 +1567,7 @@ extern "C" int mvhdp_plan_probe(const mvhdp_plan_input* pi, const mvhdp_tuning* 
         po->class_theta0[c] = p.cls[c].theta[0];
     }
     po->delta16 = p.delta16 ? 1 : 0;
+    po->live_rows = p.live_rows ? 1 : 0;
     return MVHDP_OK;
 }
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ int gather_cell(gptr_t p)
 // brought them -- and the coefficients come from LDS (lgkmcnt): nothing on the tree branch's path waits for the memory system.
 // fp32 throughout: a live sweep is not reproducible run to run (the other waves' atomics land while it samples), so there is no fp64
 // sequence to certify against; with ONE resident wave the arithmetic below IS a definition, which the oracle restates operation for
-// operation (oracle/mvhdp_oracle.c, orc_row_sample_live).  A target beyond the row's mass (tree[1] is the segment start's; rounding)
+// operation (the sequential-live mode of the test oracle).  A target beyond the row's mass (tree[1] is the segment start's; rounding)
 // takes the last topic that has mass.
 typedef unsigned int rowq_t __attribute__((ext_vector_type(4), aligned(4)));     // (a row of K cells need not start on a 16-byte boundary)
 typedef float coefq_t __attribute__((ext_vector_type(4)));

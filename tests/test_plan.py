@@ -32,6 +32,8 @@ def probe(K=400, M=3, D=1_000_000, mdt=250, longer=(1_000_000, 900_000, 40, 0, 0
         t = _lib.TuningC()
         t.narrow = -1
         t.live16 = -1
+        t.live_rows = -1
+        t.live_overlap = -1
         for g in range(4):
             t.learnt_walk_step[g] = -1
         for k, v in tuning.items():
@@ -140,7 +142,16 @@ def test_forced_variants_flags_and_errors():
     po = probe(tok=[1, 100], ent=[1, 100], tuning=dict(force_primary=32))
     assert po.register_resident == 0 and list(po.class_used) == [0, 0, 0, 0, 0, 1] and po.need_full_trees == 1
     assert probe(tok=[1, 100], ent=[1, 100], flags=0x8).register_resident == 0                     # MVHDP_SWEEP_GENERIC_KERNEL
-    assert probe(flags=SWEEP_LIVE).segments == 4 and probe(flags=SWEEP_SEGMENT_APPLY | (8 << 16)).segments == 8 and probe().segments == 1
+    assert probe(flags=SWEEP_SEGMENT_APPLY | (8 << 16)).segments == 8 and probe().segments == 1
+    # a live sweep: its live-rows form (the tree branch reads the word's live count row: one segment is enough) wherever every kernel is
+    # register-resident; stored trees rebuilt at four segment borders otherwise
+    po = probe(flags=SWEEP_LIVE)
+    assert (po.segments, po.live_rows) == (1, 1) and all(po.class_walk[c] for c in range(6) if po.class_used[c])
+    po = probe(flags=SWEEP_LIVE, tuning=dict(live_rows=0))
+    assert (po.segments, po.live_rows) == (4, 0)
+    assert probe(flags=SWEEP_LIVE | (3 << 16)).segments == 3 and probe(flags=SWEEP_LIVE | (3 << 16)).live_rows == 1
+    assert probe(flags=SWEEP_LIVE, debug=1).live_rows == 0 and probe(flags=SWEEP_LIVE | SWEEP_REUSE_TREES, trees_current=1).live_rows == 0
+    assert probe(K=2048, M=2, D=1000, mdt=5000, longer=(1000, 900, 800, 500, 100), flags=SWEEP_LIVE).live_rows == 0      # (the generic kernel can be reached)
     assert probe(D=3, longer=(3, 3, 0, 0, 0), flags=SWEEP_LIVE | (200 << 16)).segments == 3        # never more segments than entities
     assert probe(flags=SWEEP_SEGMENT_APPLY | SWEEP_NO_APPLY).status == -1
     assert probe(flags=SWEEP_LIVE | SWEEP_FROZEN).status == -1
