@@ -349,8 +349,11 @@ typedef struct {
     int32_t rccl;                 /* 1: the collective is RCCL; 0: one device and no RCCL installed (device-side sum only) */
     int32_t rccl_version;
     int32_t exchange_chunks;      /* row ranges per exchange (default 4) */
-    int32_t reserved;
+    int32_t exchange_packed;      /* 1: the n_wk deltas of the rows whose type holds at most 32767 tokens travel two to a 32-bit word (a delta of one sweep,
+                                     summed over all ranks, cannot leave 16 bits there): agreed on by every rank behind the first completed sweep after a
+                                     (re)count, 0 until then */
     double  last_exchange_ms;     /* device time of the last sweep's exchange on this process's first device: collectives + updates + tree rebuilds */
+    int64_t last_exchange_bytes;  /* bytes this process handed to the collective in the last sweep, per device (96 MB at C4 at full width, 49 MB packed) */
 } mvhdp_group_info;
 /* one process drives n GPUs (the Java host of INTEGRATION.md): ncclCommInitAll over the members' devices */
 int mvhdp_group_create(int32_t n, const mvhdp_handle* members, mvhdp_group* out);

@@ -74,8 +74,8 @@ class TuningC(C.Structure):
 
 class GroupInfoC(C.Structure):
     _fields_ = [("local_members", C.c_int32), ("local_devices", C.c_int32), ("ranks", C.c_int32), ("first_rank", C.c_int32),
-                ("rccl", C.c_int32), ("rccl_version", C.c_int32), ("exchange_chunks", C.c_int32), ("reserved", C.c_int32),
-                ("last_exchange_ms", C.c_double)]
+                ("rccl", C.c_int32), ("rccl_version", C.c_int32), ("exchange_chunks", C.c_int32), ("exchange_packed", C.c_int32),
+                ("last_exchange_ms", C.c_double), ("last_exchange_bytes", C.c_int64)]
 
 
 class PlanInputC(C.Structure):

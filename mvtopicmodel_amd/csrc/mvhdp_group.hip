@@ -87,6 +87,48 @@ hipError_t launch_add_into(int32_t* dst, const int32_t* src, int64_t n, hipStrea
 
 __global__ void set_word_kernel(int32_t* p, int32_t v) { *p = v; }
 
+// ---- the exchange at half width ----
+// A row whose type holds at most 32767 tokens in the whole corpus (MvModel::heavy == 0: decided from the replicated counts whenever the
+// row's tree is built) cannot collect a delta beyond +-32767 in one sweep, summed over ALL ranks: a delta of a cell is bounded by the
+// tokens of the type that moved.  Two such deltas travel in one 32-bit word, a + 65536 b as a plain integer: the sum of the words over
+// the ranks is sum(a) + 65536 sum(b) (no wrap: both sums stay within 16 bits), from which sum(a) is the sign-extended low half and sum(b)
+// what is left.  The other rows (0.4 % of them at C4, half the tokens) travel as they are.  woff[r]: first word of row r in the packed
+// buffer (prefix over the rows of (K + 1) / 2 or K words), the same on every rank because the row classes are.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const int32_t* __restrict__ delta, const uint8_t* __restrict__ heavy, const int64_t* __restrict__ woff,
+                                                        int32_t* __restrict__ xp, int64_t r0, int64_t r1, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t row = r0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < r1; row += wstride) {
+        const int32_t* d = delta + row * K;
+        int32_t* o = xp + woff[row];
+        if (heavy[row] == 0) {
+            const int nw = (K + 1) >> 1;
+            for (int j = lane; j < nw; j += 64) { const int a = d[2 * j], b = (2 * j + 1 < K) ? d[2 * j + 1] : 0; o[j] = a + b * 65536; }
+        } else for (int k = lane; k < K; k += 64) o[k] = d[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_rows_kernel(int32_t* __restrict__ delta, const uint8_t* __restrict__ heavy, const int64_t* __restrict__ woff,
+                                                          const int32_t* __restrict__ xp, int64_t r0, int64_t r1, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t row = r0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < r1; row += wstride) {
+        int32_t* d = delta + row * K;
+        const int32_t* o = xp + woff[row];
+        if (heavy[row] == 0) {
+            const int nw = (K + 1) >> 1;
+            for (int j = lane; j < nw; j += 64) {
+                const int w = o[j];
+                const int a = (int)(short)(w & 0xffff);
+                d[2 * j] = a;
+                if (2 * j + 1 < K) d[2 * j + 1] = (w - a) >> 16;
+            }
+        } else for (int k = lane; k < K; k += 64) d[k] = o[k];
+    }
+}
+
 // counts += sum - own  (the other shards' share of an exchanged delta buffer)
 __global__ __launch_bounds__(256) void add_remote_kernel(int32_t* __restrict__ counts, const int32_t* __restrict__ sum, const int32_t* __restrict__ own, int64_t n)
 {
@@ -128,6 +170,18 @@ struct mvhdp_group_ctx {
     bool async_pending = false;               // an exchange is in flight: the replicas lack each other's last sweep
     bool abort_raised = false;                // mvhdp_group_abort: the next sweep of this rank contributes nothing and fails on every rank
     std::vector<int> by_entity;               // member indices by ascending doc_id_base: the order of the "in entity order" statistics
+    // the exchange at half width (pack_rows_kernel): the layout is fixed by the first completed sweep behind a (re)count -- from then on every
+    // token is assigned and a row's total, hence its class, cannot move -- and confirmed by all ranks in the sweep after it
+    bool pack_on = false;                      // the exchange travels packed (agreed on by every rank, see group_step)
+    bool pack_ready = false;                   // this process has computed the layout and proposes it
+    bool pack_allowed = true;                  // MVHDP_EXCHANGE16=0 switches it off (diagnostics)
+    int32_t pack_hash = 0;                     // 1 .. 4092: what this process proposes (the layout's word count, folded)
+    std::vector<int64_t> woff;                 // [rows + 1] first packed word of every row
+    std::vector<int64_t*> d_woff;              // per leader: the same on the device
+    std::vector<uint8_t*> d_cls;               // per leader: the row classes the layout was made from (MvModel::heavy of that moment)
+    std::vector<int32_t*> xpack;               // per leader: the packed buffer
+    long long sweeps_since_counts = 0;
+    long long last_exchange_bytes = 0;         // bytes this rank handed to the collective in the last sweep
     void* d_scratch = nullptr;                // one process per GPU: device buffer of the cross-rank statistics (allocated with the group: no allocation stands between a rank and a collective)
     std::string err;
 };
@@ -181,6 +235,7 @@ static int validate_members(int32_t n, const mvhdp_handle* members)
 
 static int group_common_init(mvhdp_group_ctx* g, int32_t n, const mvhdp_handle* members)
 {
+    if (const char* e = getenv("MVHDP_EXCHANGE16")) g->pack_allowed = atoi(e) != 0;      // (every rank of a group must say the same)
     std::map<int, int> first_on_device;
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = members[i];
@@ -232,6 +287,9 @@ static void group_release(mvhdp_group_ctx* g)
     for (hipEvent_t ev : g->ev_xfer) if (ev) hipEventDestroy(ev);
     g->xbuf.clear(); g->sbuf.clear(); g->comm.clear(); g->ev_xfer.clear();
     if (g->d_scratch) hipFree(g->d_scratch);
+    for (int64_t* q : g->d_woff) if (q) hipFree(q);
+    for (uint8_t* q : g->d_cls) if (q) hipFree(q);
+    for (int32_t* q : g->xpack) if (q) hipFree(q);
     if (g->ev_x0) hipEventDestroy(g->ev_x0);
     if (g->ev_x1) hipEventDestroy(g->ev_x1);
 }
@@ -342,6 +400,8 @@ extern "C" int mvhdp_group_get_info(mvhdp_group g, mvhdp_group_info* info)
     info->rccl = g->rccl_used ? 1 : 0; info->rccl_version = g->rccl_version;
     info->exchange_chunks = g->chunks;
     info->last_exchange_ms = g->last_exchange_ms;
+    info->last_exchange_bytes = g->last_exchange_bytes;
+    info->exchange_packed = g->pack_on ? 1 : 0;
     return MVHDP_OK;
 }
 
@@ -421,6 +481,71 @@ static int fan_out_range(mvhdp_group_ctx* g, bool counts, int64_t e0, int64_t e1
     return x.rc;
 }
 
+// The layout of the packed exchange, from the row classes as they stand (called behind a completed sweep of fully assigned tokens: a
+// row's total cannot move any more).  Local work only; what it yields is PROPOSED to the other ranks by the next sweep's status words.
+static int pack_prepare(mvhdp_group_ctx* g)
+{
+    if (g->pack_ready || !g->pack_allowed) return MVHDP_OK;
+    for (mvhdp_ctx* h : g->members) for (int m = 0; m < h->mm.M; m++) if (h->unassigned[m]) return MVHDP_OK;   // (a first visit only adds to its row: not yet)
+    mvhdp_ctx* L0 = g->members[g->leaders[0]];
+    const int64_t rows = L0->mm.rowbase[L0->mm.M];
+    const int K = L0->mm.K;
+    if (rows <= 0) return MVHDP_OK;
+    std::vector<uint8_t> cls((size_t)rows);
+    GHIP(g, hipSetDevice(L0->device));
+    GHIP(g, hipMemcpy(cls.data(), L0->mm.heavy, (size_t)rows, hipMemcpyDeviceToHost));
+    g->woff.assign((size_t)rows + 1, 0);
+    for (int64_t r = 0; r < rows; r++) g->woff[(size_t)r + 1] = g->woff[(size_t)r] + (cls[(size_t)r] == 0 ? (K + 1) / 2 : K);
+    if (g->d_woff.empty()) { g->d_woff.assign(g->leaders.size(), nullptr); g->d_cls.assign(g->leaders.size(), nullptr); g->xpack.assign(g->leaders.size(), nullptr); }
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        mvhdp_ctx* L = g->members[g->leaders[l]];
+        GHIP(g, hipSetDevice(L->device));
+        if (!g->d_woff[l]) GHIP(g, hipMalloc(&g->d_woff[l], (size_t)(rows + 1) * sizeof(int64_t)));
+        if (!g->d_cls[l]) GHIP(g, hipMalloc(&g->d_cls[l], (size_t)rows));
+        if (!g->xpack[l]) GHIP(g, hipMalloc(&g->xpack[l], (size_t)rows * K * sizeof(int32_t)));
+        GHIP(g, hipMemcpy(g->d_woff[l], g->woff.data(), (size_t)(rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        GHIP(g, hipMemcpy(g->d_cls[l], cls.data(), (size_t)rows, hipMemcpyHostToDevice));
+    }
+    g->pack_hash = (int32_t)(g->woff[(size_t)rows] % 4091) + 1;
+    g->pack_ready = true;
+    return MVHDP_OK;
+}
+
+static void pack_reset(mvhdp_group_ctx* g) { g->pack_on = false; g->pack_ready = false; g->pack_hash = 0; g->sweeps_since_counts = 0; }
+
+// rows [r0, r1) of every leader's delta buffer, packed, all-reduced and unpacked again: in stream order, nothing returns early
+static int allreduce_rows_packed(mvhdp_group_ctx* g, int64_t r0, int64_t r1)
+{
+    XErr x{g};
+    Rccl* r = &g_rccl;
+    const int64_t w0 = g->woff[(size_t)r0], w1 = g->woff[(size_t)r1];
+    const int K = g->members[0]->mm.K;
+    const int grid = (int)std::min<int64_t>((r1 - r0 + 3) / 4, 8192);
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        mvhdp_ctx* L = g->members[g->leaders[l]];
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(std::max(grid, 1)), dim3(256), 0, L->stream, L->mm.delta, g->d_cls[l], g->d_woff[l], g->xpack[l], r0, r1, K);
+        x.hip(hipGetLastError(), "pack_rows_kernel");
+    }
+    if (!g->comms.empty() && w1 > w0) {
+        if (g->comms.size() > 1) x.nccl(r->GroupStart(), "ncclGroupStart");
+        for (size_t l = 0; l < g->leaders.size(); l++) {
+            mvhdp_ctx* L = g->members[g->leaders[l]];
+            x.hip(hipSetDevice(L->device), "hipSetDevice");
+            x.nccl(r->AllReduce(g->xpack[l] + w0, g->xpack[l] + w0, (size_t)(w1 - w0), ncclInt32, ncclSum, g->comms[l], L->stream), "ncclAllReduce");
+        }
+        if (g->comms.size() > 1) x.nccl(r->GroupEnd(), "ncclGroupEnd");
+    }
+    for (size_t l = 0; l < g->leaders.size(); l++) {
+        mvhdp_ctx* L = g->members[g->leaders[l]];
+        x.hip(hipSetDevice(L->device), "hipSetDevice");
+        hipLaunchKernelGGL(unpack_rows_kernel, dim3(std::max(grid, 1)), dim3(256), 0, L->stream, L->mm.delta, g->d_cls[l], g->d_woff[l], g->xpack[l], r0, r1, K);
+        x.hip(hipGetLastError(), "unpack_rows_kernel");
+    }
+    g->last_exchange_bytes += (w1 - w0) * (long long)sizeof(int32_t);
+    return x.rc;
+}
+
 // buildInitialTypeTopicCounts PTM:600-652 over every shard: local counts, then the sum over all members of all ranks.
 // Collective; the failure protocol of group_step below: a rank whose recount failed contributes zeros and a 1 in the status word behind
 // the tokensPerTopic part, every rank enters the same all-reduce and all return an error from this call.
@@ -437,6 +562,7 @@ extern "C" int mvhdp_group_build_counts(mvhdp_group g)
     int local_err = MVHDP_OK;
     auto note = [&](int rc, const std::string& what) { if (rc != MVHDP_OK && local_err == MVHDP_OK) { local_err = rc; g->err = what; } };
     XErr x{g};
+    pack_reset(g);                                        // (new counts: the rows' classes are decided again)
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = g->members[i];
         const int rc = mvhdp_build_counts(h);
@@ -543,20 +669,28 @@ static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uin
             drop_local();
         }
     }
+    // the words behind the tokensPerTopic part, summed with it: [0] ranks whose sweep failed; [1], [2] this process's proposal for the
+    // packed exchange and its square (0: none yet) -- every rank proposes the same layout iff n * sum(h^2) == (sum h)^2 with sum h > 0,
+    // a test every rank makes on the same two sums, so all switch to the packed exchange behind the same sweep
+    const int32_t prop = (!g->pack_on && g->pack_ready && local_err == MVHDP_OK) ? g->pack_hash : 0;
     for (size_t l = 0; l < g->leaders.size(); l++) {
         mvhdp_ctx* L = g->members[g->leaders[l]];
         x.hip(hipSetDevice(L->device), "hipSetDevice");
         hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, L->stream, L->mm.delta + len, local_err != MVHDP_OK ? 1 : 0);
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, L->stream, L->mm.delta + len + 1, prop);
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, L->stream, L->mm.delta + len + 2, prop * prop);
     }
-    int xrc = allreduce_range(g, false, nk_off, len + 1);
-    { const int rc = fan_out_range(g, false, nk_off, len + 1); if (xrc == MVHDP_OK) xrc = rc; }
+    g->last_exchange_bytes += (len + 3 - nk_off) * (long long)sizeof(int32_t);
+    int xrc = allreduce_range(g, false, nk_off, len + 3);
+    { const int rc = fan_out_range(g, false, nk_off, len + 3); if (xrc == MVHDP_OK) xrc = rc; }
     bool applying = local_err == MVHDP_OK && xrc == MVHDP_OK;
     if (applying) for (int i = 0; i < n && applying; i++) { const int rc = mvhdp_apply_delta_begin(g->members[i]); if (rc) { note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err); applying = false; } }
     const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(g->chunks, rows));
     for (int c = 0; c < nch; c++) {
         const int64_t r0 = rows * c / nch, r1 = rows * (c + 1) / nch;
         if (r1 <= r0) continue;
-        { const int rc = allreduce_range(g, false, r0 * K, r1 * K); if (xrc == MVHDP_OK) xrc = rc; }     // (issued whatever happened before)
+        if (g->pack_on) { const int rc = allreduce_rows_packed(g, r0, r1); if (xrc == MVHDP_OK) xrc = rc; }
+        else { const int rc = allreduce_range(g, false, r0 * K, r1 * K); if (xrc == MVHDP_OK) xrc = rc; g->last_exchange_bytes += (r1 - r0) * K * (long long)sizeof(int32_t); }     // (issued whatever happened before)
         { const int rc = fan_out_range(g, false, r0 * K, r1 * K); if (xrc == MVHDP_OK) xrc = rc; }
         if (applying && xrc == MVHDP_OK)
             for (int i = 0; i < n && applying; i++) { const int rc = mvhdp_apply_delta_rows(g->members[i], r0, r1); if (rc) { note(rc, "member " + std::to_string(i) + ": " + g->members[i]->err); applying = false; } }
@@ -587,12 +721,15 @@ static int group_step(mvhdp_group_ctx* g, uint32_t sweep_idx, uint64_t seed, uin
     }
     if (xrc != MVHDP_OK && local_err == MVHDP_OK) local_err = xrc;         // (g->err was set where the collective failed)
     // the status word of the whole group, read behind everything this step put on the first device's stream
-    int32_t failed_ranks = 0;
+    int32_t tail[3] = {0, 0, 0};
     x.hip(hipSetDevice(L0->device), "hipSetDevice");
     x.hip(hipEventRecord(g->ev_x1, L0->stream), "hipEventRecord");
-    x.hip(hipMemcpyAsync(&failed_ranks, L0->mm.delta + len, sizeof failed_ranks, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
+    x.hip(hipMemcpyAsync(tail, L0->mm.delta + len, sizeof tail, hipMemcpyDeviceToHost, L0->stream), "hipMemcpyAsync");
     x.hip(hipStreamSynchronize(L0->stream), "hipStreamSynchronize");
     note(x.rc, g->err);
+    const int32_t failed_ranks = tail[0];
+    // (the test of the proposals: made from the reduced words alone, so every rank decides alike; a failed sweep decides nothing)
+    if (!g->pack_on && failed_ranks == 0 && tail[1] > 0 && (long long)g->nranks * tail[2] == (long long)tail[1] * tail[1]) g->pack_on = true;
     const int32_t topic = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_TOPIC(key), view = key == LLONG_MAX ? -1 : MVHDP_ACT_KEY_VIEW(key);
     for (int i = 0; i < n; i++) {
         mvhdp_ctx* h = g->members[i];
@@ -814,6 +951,7 @@ extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t see
     const int n = (int)g->members.size();
     std::vector<mvhdp_sweep_stats> total((size_t)n), st((size_t)n);
     g->last_exchange_ms = 0.0;
+    g->last_exchange_bytes = 0;
     int ret = MVHDP_OK;
     if (!(flags & MVHDP_SWEEP_ASYNC_EXCHANGE) && g->async_pending) { ret = mvhdp_group_drain(g); if (ret) return ret; }
     if (flags & MVHDP_SWEEP_ASYNC_EXCHANGE) {
@@ -842,6 +980,10 @@ extern "C" int mvhdp_group_sweep(mvhdp_group g, uint32_t sweep_idx, uint64_t see
         ret = group_step(g, sweep_idx, seed, flags, total);
     }
     g->sweeps++;
+    if (ret == MVHDP_OK && !(flags & MVHDP_SWEEP_ASYNC_EXCHANGE)) {
+        g->sweeps_since_counts++;
+        if (!g->pack_ready) (void)pack_prepare(g);           // (a failure here only means: no proposal from this rank, the exchange stays at full width)
+    }
     if (stats) for (int i = 0; i < n; i++) stats[i] = total[i];
     return ret;
 }

@@ -84,8 +84,10 @@ def main():
     def sweep(idx, flags=0):
         try:
             st = g.sweep(idx, SEED, flags)[0]
+            gi = g.info()
             log["events"].append({"sweep": idx, "ok": True, "tokens": int(st.tokens), "changed": int(st.changed),
-                                  "activated_topic": int(st.activated_topic), "activated_modality": int(st.activated_modality)})
+                                  "activated_topic": int(st.activated_topic), "activated_modality": int(st.activated_modality),
+                                  "packed": int(gi.exchange_packed), "bytes": int(gi.last_exchange_bytes)})
             return True
         except MvhdpError as e:
             log["events"].append({"sweep": idx, "ok": False, "code": e.code, "msg": str(e)})

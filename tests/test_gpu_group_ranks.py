@@ -33,9 +33,11 @@ def fake_rccl(tmp_path_factory):
     return out
 
 
-def run_ranks(tmp_path, fake, nranks, scenario, timeout=240, slot_bytes=None, collective_timeout_ms=20000):
+def run_ranks(tmp_path, fake, nranks, scenario, timeout=240, slot_bytes=None, collective_timeout_ms=20000, exchange16=None):
     env = dict(os.environ)
     env["MVHDP_RCCL_LIB"] = fake
+    if exchange16 is not None:
+        env["MVHDP_EXCHANGE16"] = str(exchange16)
     env["FAKE_RCCL_TIMEOUT_MS"] = str(collective_timeout_ms)
     if slot_bytes:
         env["FAKE_RCCL_SLOT_BYTES"] = str(slot_bytes)        # (smaller than a row range: the collective goes in pieces)
@@ -93,10 +95,18 @@ def assert_replicas_hold(arrs, tag, c, z=None):
             assert np.array_equal(a[f"{tag}_nk{m}"].astype(np.int64), want.sum(axis=0)), f"rank {r}: n_k of view {m} ({tag})"
 
 
-@pytest.mark.parametrize("nranks,scenario,slot", [(2, "deferred", None), (4, "deferred", 4096), (2, "inactive_deferred", None), (4, "inactive_deferred", None)])
-def test_deferred_sweeps_and_statistics_across_ranks_equal_the_single_handle(tmp_path, fake_rccl, nranks, scenario, slot):
-    procs, outs, logs, arrs = run_ranks(tmp_path, fake_rccl, nranks, scenario, slot_bytes=slot)
+@pytest.mark.parametrize("nranks,scenario,slot,x16", [(2, "deferred", None, None), (4, "deferred", 4096, None), (2, "deferred", None, 0),
+                                                      (2, "inactive_deferred", None, None), (4, "inactive_deferred", None, 0)])
+def test_deferred_sweeps_and_statistics_across_ranks_equal_the_single_handle(tmp_path, fake_rccl, nranks, scenario, slot, x16):
+    """Both widths of the exchange: the first sweep behind a count travels at full width, the second carries every rank's proposal of the
+    packed layout, from the third on the deltas of the small rows (at most 32767 tokens of their type) travel two to a word -- fewer
+    bytes, the same integers; MVHDP_EXCHANGE16=0 keeps the full width."""
+    procs, outs, logs, arrs = run_ranks(tmp_path, fake_rccl, nranks, scenario, slot_bytes=slot, exchange16=x16)
     assert_all_ok(procs, outs, logs)
+    for lg in logs:
+        assert [e["packed"] for e in lg["events"]] == ([0, 0, 0] if x16 == 0 else [0, 1, 1]), lg["events"]       # (agreed on at the end of the second sweep)
+        b = [e["bytes"] for e in lg["events"]]
+        assert b[0] == b[1] and (b[2] == b[0] if x16 == 0 else b[2] < 0.6 * b[0]), b
     c, z0 = W.corpus()
     hy = W.hyper(scenario)
     if scenario.startswith("inactive"):
