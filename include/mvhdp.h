@@ -151,8 +151,9 @@ typedef struct {
 /* With MVHDP_SWEEP_SEGMENT_APPLY: the updater runs BESIDE the samplers, as UPD:164-297 runs beside WRK:186-233 -- the deltas of
  * segment s are applied to the counts while segment s+1 is being sampled, so segment s+2 is the first to see them: every token of
  * segment s samples against the counts after segment s-2 (segments 0 and 1: the sweep-start counts).  The F+trees are built once, at
- * the start of the sweep, and serve every segment -- the reference rebuilds its trees only in buildFTrees (PTM:1209) and refreshes
- * touched leaves in between (UPD:242-260); plain SEGMENT_APPLY rebuilds them at every segment border.  Still a deterministic chain,
+ * the start of the sweep, and serve every segment: a DEVIATION from the reference, whose updater refreshes the two touched leaves with
+ * every delta (UPD:242-260) so that its trees follow the counts -- here a token's tree-branch mass and its count-based branch come from
+ * different model states (plain SEGMENT_APPLY rebuilds the trees at every segment border).  Still a deterministic chain,
  * followed by the oracle segment by segment (tests/test_gpu_segmented.py); and without the per-segment stall of plain SEGMENT_APPLY:
  * two segments are in flight, no kernel boundary idles the chip (the counts and their mirror are kept twice).  Not with inactive
  * topics (the activation of UPD:263-270 needs the host between segments): MVHDP_ERR_UNSUPPORTED. */

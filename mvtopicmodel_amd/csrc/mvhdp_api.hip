@@ -851,10 +851,12 @@ static hipError_t launch_segment_kernels(mvhdp_ctx* h, const SweepPlan& p, const
 //     against the copy that holds the deltas of every segment up to s-2 and writes its own deltas into buffer s mod 3; when its
 //     kernels are done the updater's kernel A(s) -- beside the kernels of segment s+1 -- adds the deltas of segments s-1 and s to the
 //     OTHER copy; segment s+2 waits for A(s).  At the end the copy that missed the last segment takes it, and both copies are the
-//     model again.  The F+trees are those of the sweep start for every segment, as the reference's are between two buildFTrees calls
-//     (PTM:1209; its updater refreshes the touched leaves only, UPD:242-260): rebuilding them per segment beside the samplers took a
-//     whole segment's time in the one block slot per CU the samplers leave (profiles/r04_timeline_c4_oseg8_trees_per_segment.txt), which put the
-//     rebuild back on the critical path.
+//     model again.  The F+trees are those of the sweep start for EVERY segment while n_wk and n_k advance: this DEVIATES from the reference,
+//     whose updater refreshes the two touched leaves with every delta (UPD:242-260 -> FT:138-147), so that its trees track the counts --
+//     here the tree-branch mass of a token and the count-based branch come from different model states, and the LL curves price that at
+//     about half a reference sweep per sweep.  Rebuilding the trees per segment beside the samplers took a whole
+//     segment's time in the one block slot per CU the samplers leave (profiles/r04_timeline_c4_oseg8_trees_per_segment.txt), which put
+//     the rebuild back on the critical path; the mode is opt-in for a host that knows its tree branch to be small.
 //         stream 0:  K(0) A(0) K(2) A(2) K(4) ...          A(s) behind K(s) on its stream and behind A(s-1) on the other one;
 //         stream 1:  K(1) A(1) K(3) A(3) ...               K(s+2) behind A(s): while A(s) runs, stream 1 - s mod 2 is sampling
 //   MVHDP_SWEEP_LIVE (racy by design, like the reference's updater)
@@ -1037,7 +1039,7 @@ static int enqueue_overlapped(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_i
 static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, uint64_t seed, const double* p_override,
                          const DebugBufs* db, unsigned long long* d_stats, hipEvent_t ev_k0, hipEvent_t ev_k1, SweepOutcome& oc)
 {
-    if (p.overlap && !db) return enqueue_overlapped(h, p, sweep_idx, seed, p_override, d_stats, ev_k0, ev_k1);
+    if (p.overlap) return enqueue_overlapped(h, p, sweep_idx, seed, p_override, d_stats, ev_k0, ev_k1);   // (the plan never overlaps segments of a sweep with debug outputs)
     MvModel& mm = h->mm;
     const int M = mm.M;
     const uint32_t flags = p.flags;

@@ -356,8 +356,8 @@ hipError_t mvhdp_launch_apply2(const MvModel& dst, const int32_t* dA, int32_t* d
     return hipGetLastError();
 }
 
-// The same update without the trees (MVHDP_SWEEP_SEGMENT_OVERLAP keeps the sweep-start trees for every segment, as the reference keeps
-// its trees between two buildFTrees calls, PTM:1209): dst += dA (+ dB), dB = 0, cell by cell, atomics where a delta is not zero.
+// The same update without the trees (MVHDP_SWEEP_SEGMENT_OVERLAP keeps the sweep-start trees for every segment -- a deviation from the
+// reference, whose updater refreshes the touched leaves per delta, UPD:242-260): dst += dA (+ dB), dB = 0, cell by cell, atomics where a delta is not zero.
 // Reads two delta buffers and touches what changed: a tenth of a millisecond of the whole chip at C4, a few tenths beside the samplers.
 __global__ __launch_bounds__(256) void apply2_counts_kernel(MvModel mm, const int32_t* __restrict__ dA, int32_t* __restrict__ dB, bool use_mirror,
                                                            int64_t n_cells, int64_t n_all, unsigned long long* negatives)

@@ -41,9 +41,12 @@ std::mutex g_reg_mutex;
 std::condition_variable g_reg_cv;
 std::set<void*> g_shards, g_groups;
 
-struct Group {                        // an mvhdp_group and how many members it has in this process
+struct Group {                        // an mvhdp_group, how many members it has in this process, and the model's shape for the checks
     mvhdp_group g = nullptr;
     int members = 0;
+    int K = 0, M = 0;                 // of the member Shards (validate_members: every member holds the same shape)
+    std::vector<Shard*> shards;       // the members, PINNED from nGroupCreate to nGroupDestroy: nDestroy of a member (a finalizer, another thread)
+                                      // waits for its pins, so a member cannot be destroyed under a group that still names it
     int pins = 0;
 };
 
@@ -423,15 +426,18 @@ JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupCreate(
     std::vector<jlong> hp(static_cast<size_t>(n));
     env->GetLongArrayRegion(handles, 0, n, hp.data());
     std::vector<mvhdp_handle> hs;
+    Group* gr = new Group();
+    auto unpin_all = [&]() { std::lock_guard<std::mutex> lk(g_reg_mutex); for (Shard* s : gr->shards) if (--s->pins == 0) g_reg_cv.notify_all(); gr->shards.clear(); };
     for (jsize i = 0; i < n; i++) {
-        ShardPin pin_(hp[i]); Shard* s = pin_.s;
-        if (!s) { throw_msg(env, "java/lang/IllegalStateException", "groupCreate: a member is closed"); return 0; }
+        Shard* s = nullptr;
+        { std::lock_guard<std::mutex> lk(g_reg_mutex); if (g_shards.count(reinterpret_cast<void*>(hp[i]))) { s = reinterpret_cast<Shard*>(hp[i]); s->pins++; } }
+        if (!s) { unpin_all(); delete gr; throw_msg(env, "java/lang/IllegalStateException", "groupCreate: a member is closed"); return 0; }
+        gr->shards.push_back(s);
         hs.push_back(s->h);
     }
-    Group* gr = new Group();
     int rc = mvhdp_group_create(n, hs.data(), &gr->g);
-    if (rc != MVHDP_OK) { delete gr; throw_group(env, nullptr, rc, "mvhdp_group_create"); return 0; }
-    gr->members = n;
+    if (rc != MVHDP_OK) { unpin_all(); delete gr; throw_group(env, nullptr, rc, "mvhdp_group_create"); return 0; }
+    gr->members = n; gr->K = gr->shards[0]->K; gr->M = gr->shards[0]->M;
     { std::lock_guard<std::mutex> lk(g_reg_mutex); g_groups.insert(gr); }
     return reinterpret_cast<jlong>(gr);
 }
@@ -448,15 +454,17 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupUniqueId
 
 JNIEXPORT jlong JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupCreateRank(JNIEnv* env, jclass, jlong p, jbyteArray id, jint rank, jint nranks)
 {
-    ShardPin pin_(p); Shard* s = pin_.s;
+    Shard* s = nullptr;
+    { std::lock_guard<std::mutex> lk(g_reg_mutex); if (g_shards.count(reinterpret_cast<void*>(p))) { s = reinterpret_cast<Shard*>(p); s->pins++; } }   // (kept until nGroupDestroy)
     if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return 0; }
-    if (bad_len(env, id, MVHDP_UNIQUE_ID_BYTES, "groupCreateRank id")) return 0;
+    auto unpin = [&]() { std::lock_guard<std::mutex> lk(g_reg_mutex); if (--s->pins == 0) g_reg_cv.notify_all(); };
+    if (bad_len(env, id, MVHDP_UNIQUE_ID_BYTES, "groupCreateRank id")) { unpin(); return 0; }
     uint8_t buf[MVHDP_UNIQUE_ID_BYTES];
     env->GetByteArrayRegion(id, 0, MVHDP_UNIQUE_ID_BYTES, reinterpret_cast<jbyte*>(buf));
     Group* gr = new Group();
     int rc = mvhdp_group_create_rank(s->h, buf, rank, nranks, &gr->g);
-    if (rc != MVHDP_OK) { delete gr; throw_group(env, nullptr, rc, "mvhdp_group_create_rank"); return 0; }
-    gr->members = 1;
+    if (rc != MVHDP_OK) { unpin(); delete gr; throw_group(env, nullptr, rc, "mvhdp_group_create_rank"); return 0; }
+    gr->members = 1; gr->K = s->K; gr->M = s->M; gr->shards.push_back(s);
     { std::lock_guard<std::mutex> lk(g_reg_mutex); g_groups.insert(gr); }
     return reinterpret_cast<jlong>(gr);
 }
@@ -466,6 +474,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupDestroy(
     Group* gr = unregister_and_drain<Group>(g_groups, p);
     if (!gr) return;
     mvhdp_group_destroy(gr->g);
+    { std::lock_guard<std::mutex> lk(g_reg_mutex); for (Shard* s : gr->shards) if (--s->pins == 0) g_reg_cv.notify_all(); }   // the members may be closed now
     delete gr;
 }
 
@@ -549,24 +558,26 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupAbort(JN
     if (rc) throw_group(env, gr->g, rc, "mvhdp_group_abort");
 }
 
-// modelLogLikelihood PTM:3322-3452 of the sharded model: out [M] (M = out.length, checked by the library's own loop bound)
+// modelLogLikelihood PTM:3322-3452 of the sharded model: out [M]
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupModelLogLikelihood(JNIEnv* env, jclass, jlong p, jdoubleArray out)
 {
     GroupPin gpin_(p); Group* gr = gpin_.s;
     if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
-    if (!out || env->GetArrayLength(out) < 1 || env->GetArrayLength(out) > MVHDP_MAX_MODALITIES) { throw_msg(env, "java/lang/IllegalArgumentException", "groupModelLogLikelihood: one entry per view"); return; }
+    if (bad_len(env, out, gr->M, "groupModelLogLikelihood: one entry per view")) return;
     double ll[MVHDP_MAX_MODALITIES] = {};
     int rc = mvhdp_group_log_likelihood(gr->g, ll);
     if (rc) { throw_group(env, gr->g, rc, "mvhdp_group_log_likelihood"); return; }
     env->SetDoubleArrayRegion(out, 0, env->GetArrayLength(out), ll);
 }
 
-// topicDocCounts / docLengthCounts over every entity of every member: hist [K*histLen] (K = hist.length / histLen)
+// topicDocCounts / docLengthCounts over every entity of every member: hist [K*histLen]
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupGetDocTopicHist(JNIEnv* env, jclass, jlong p, jint m, jintArray hist, jint histLen, jintArray lens)
 {
     GroupPin gpin_(p); Group* gr = gpin_.s;
     if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
-    if (histLen < 1 || (hist && env->GetArrayLength(hist) % histLen != 0)) { throw_msg(env, "java/lang/IllegalArgumentException", "groupGetDocTopicHist: hist must hold K rows of histLen"); return; }
+    // (the library zero-fills and sums K * histLen entries whatever it is handed: the shape is checked HERE, against the members' K and M)
+    if (m < 0 || m >= gr->M || histLen < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "groupGetDocTopicHist: bad view or histLen"); return; }
+    if (hist && bad_len(env, hist, (jlong)gr->K * histLen, "groupGetDocTopicHist hist [K][histLen]")) return;
     int rc;
     { Ints a(env, hist, 0), b(env, lens, 0); if (a.failed() || b.failed()) return;
       rc = mvhdp_group_doc_topic_hist(gr->g, m, reinterpret_cast<int32_t*>(a.p), histLen, reinterpret_cast<int32_t*>(b.p), lens ? env->GetArrayLength(lens) : 0); }
@@ -577,7 +588,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupGetCount
 {
     GroupPin gpin_(p); Group* gr = gpin_.s;
     if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
-    if (!hist || env->GetArrayLength(hist) < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "groupGetCountHistogram: empty array"); return; }
+    if (m < 0 || m >= gr->M || !hist || env->GetArrayLength(hist) < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "groupGetCountHistogram: bad view or empty array"); return; }
     int rc;
     { Ints a(env, hist, 0); if (a.failed()) return; rc = mvhdp_group_count_histogram(gr->g, m, reinterpret_cast<int32_t*>(a.p), env->GetArrayLength(hist)); }
     if (rc) throw_group(env, gr->g, rc, "mvhdp_group_count_histogram");
@@ -587,8 +598,8 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupViewOver
 {
     GroupPin gpin_(p); Group* gr = gpin_.s;
     if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
-    const jsize n = sums ? env->GetArrayLength(sums) : 0;
-    if (n < 1 || n > MVHDP_MAX_MODALITIES * MVHDP_MAX_MODALITIES) { throw_msg(env, "java/lang/IllegalArgumentException", "groupViewOverlapSums: M*M entries"); return; }
+    const jsize n = gr->M * gr->M;
+    if (bad_len(env, sums, n, "groupViewOverlapSums [M][M]")) return;
     double v[MVHDP_MAX_MODALITIES * MVHDP_MAX_MODALITIES] = {};
     int rc = mvhdp_group_view_overlap_sums(gr->g, v);
     if (rc) { throw_group(env, gr->g, rc, "mvhdp_group_view_overlap_sums"); return; }
@@ -599,6 +610,7 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupGammaDoc
 {
     GroupPin gpin_(p); Group* gr = gpin_.s;
     if (!gr) { throw_msg(env, "java/lang/IllegalStateException", "group is closed"); return; }
+    if (m < 0 || m >= gr->M) { throw_msg(env, "java/lang/IllegalArgumentException", "groupGammaDocStatistics: bad view"); return; }
     if (bad_len(env, out, 2, "groupGammaDocStatistics")) return;
     double v[2];
     int rc = mvhdp_group_gamma_doc_statistics(gr->g, m, gammaM, static_cast<uint64_t>(seed), static_cast<uint32_t>(round), &v[0], &v[1]);

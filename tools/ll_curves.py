@@ -4,7 +4,8 @@
   cpu       the reference's update discipline restated on the CPU (oracle/ref_threaded.c: sampler threads read the
             counts and trees while updater threads apply the deltas, PTM:1036-1101, UPD:164-297)
   deferred  the GPU sweep under the parity contract (every token sampled against the sweep-start counts)
-  live      the GPU sweep with MVHDP_SWEEP_LIVE (atomics on the shared counts, trees rebuilt n times per sweep)
+  live      the GPU sweep with MVHDP_SWEEP_LIVE (atomics on the shared counts; the tree branch from the live count rows, or -- live_rows 0 --
+            from stored trees rebuilt n times per sweep)
 
 all from the same corpus, the same initial assignments (PTM:465-515 with java.util.Random(1)) and the same fixed
 hyper-parameters (alpha 0.1, beta 0.01, gamma 1, p_a 0.31 = iteration 1 of the burn-in schedule, PTM:1168).  The
@@ -64,7 +65,7 @@ def run_cpu(args):
             curve.append({"sweep": it, "ll_per_token": (o.model_log_likelihood() / ntok).tolist(),
                           "changed_frac": st["changed"] / max(1, st["tokens"])})
             print(f"cpu sweep {it}: LL/token {curve[-1]['ll_per_token']}  ({secs:.0f} s)", flush=True)
-    out = {"runs": {f"cpu reference topology ({3 * T // 4} samplers + {T // 4} updaters)": curve},
+    out = {"runs": {f"cpu reference topology ({3 * T // 4} samplers + {T // 4} updaters)" + (f" seed {args.seed}" if args.seed != 20260101 else ""): curve},
            "workload": args.workload, "docs": c.D, "tokens": c.total_tokens, "cpu_seconds": secs}
     json.dump(out, open(args.out, "w"), indent=1)
 
@@ -79,7 +80,9 @@ def run_gpu(args):
     runs = {}
     modes = [("gpu deferred (snapshot sweep)", 0)]
     for n in args.live_segments:
-        modes.append((f"gpu live, {n} tree rebuild(s) per sweep", SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(n)))
+        # (n = 0: the library's default -- one segment in the live-rows form, four with stored trees)
+        form = {None: "", 1: " (tree branch from the live rows)", 0: " (stored trees rebuilt per segment)"}[args.live_rows]
+        modes.append((f"gpu live, {n if n else 'default'} segment(s) per sweep{form}", SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(n)))
     for n in args.segmented:
         modes.append((f"gpu deferred in {n} segments, applied in between", SWEEP_SEGMENT_APPLY | SWEEP_LIVE_SEGMENTS(n)))
     for n in args.overlapped:
@@ -106,6 +109,8 @@ def run_gpu(args):
             if l16 is not None and (flags & SWEEP_LIVE):
                 s.set_tuning(live16=l16)
                 name += " (live16=%d)" % l16
+            if args.live_rows is not None and (flags & SWEEP_LIVE):
+                s.set_tuning(live_rows=args.live_rows)
             if len(seeds) > 1:
                 name += " seed %d" % seed
             if args.tag:
@@ -213,6 +218,93 @@ def table(args):
             print(f"| {p['sweep']} | {target:.4f} | " + " | ".join(row) + " |")
 
 
+def _sweeps_needed(curve, m, target):
+    """GPU sweeps at which view m of `curve` first reaches `target` (linear interpolation between samples); None: not within the run"""
+    xs = [q["sweep"] for q in curve]
+    ys = [q["ll_per_token"][m] for q in curve]
+    if ys[0] >= target:
+        return 0.0
+    for i in range(1, len(xs)):
+        if ys[i] >= target > ys[i - 1]:
+            return xs[i - 1] + (target - ys[i - 1]) / (ys[i] - ys[i - 1]) * (xs[i] - xs[i - 1])
+    return None
+
+
+def _mode_of(name):
+    """run name without its seed / tag: the update mode"""
+    import re
+    return re.sub(r"\s*(seed \d+|\[[^\]]*\])", "", name).strip()
+
+
+def equivalents(args):
+    """What a sweep of each GPU update mode is worth IN EVERY VIEW: GPU sweeps needed to reach the LL/token the CPU restatement of the
+    reference reaches after n sweeps, n = 10, 20, ..., against every CPU chain given (two chains = the band of a nondeterministic
+    reference) and every seed of the mode; per view the range over all of them, and the worst view."""
+    runs, meta = {}, None
+    for f in args.files:
+        j = json.load(open(f))
+        runs.update(j["runs"]); meta = meta or j
+    cpus = {n: r for n, r in runs.items() if n.startswith("cpu")}
+    M = len(next(iter(runs.values()))[0]["ll_per_token"])
+    out = {"workload": meta["workload"], "docs": meta["docs"], "cpu_chains": sorted(cpus), "cpu_sweeps": [], "modes": {}, "sources": [os.path.basename(f) for f in args.files]}
+    targets = sorted({p["sweep"] for r in cpus.values() for p in r if p["sweep"] >= args.first and p["sweep"] % args.step == 0 and p["sweep"] <= args.last})
+    out["cpu_sweeps"] = targets
+    # the band of the reference itself: CPU chain A's sweeps needed to reach chain B's LL
+    band = {}
+    names = sorted(cpus)
+    for m in range(M):
+        rs = []
+        for a in names:
+            for b in names:
+                if a == b:
+                    continue
+                for t in targets:
+                    tv = [p["ll_per_token"][m] for p in cpus[b] if p["sweep"] == t]
+                    if tv:
+                        n = _sweeps_needed(cpus[a], m, tv[0])
+                        if n is not None:
+                            rs.append(n / t)
+        band[f"view{m}"] = [min(rs), max(rs)] if rs else None
+    out["cpu_band"] = band
+    modes = {}
+    for n, r in runs.items():
+        if not n.startswith("cpu"):
+            modes.setdefault(_mode_of(n), []).append(r)
+    for mode, rr in modes.items():
+        per_view, worst = {}, None
+        for m in range(M):
+            ratios, missed = [], 0
+            for r in rr:
+                for cn in names:
+                    for t in targets:
+                        tv = [p["ll_per_token"][m] for p in cpus[cn] if p["sweep"] == t]
+                        if not tv:
+                            continue
+                        n = _sweeps_needed(r, m, tv[0])
+                        if n is None:
+                            missed += 1
+                        else:
+                            ratios.append(n / t)
+            per_view[f"view{m}"] = {"min": min(ratios) if ratios else None, "max": max(ratios) if ratios else None, "not_reached": missed,
+                                    "n": len(ratios) + missed}
+            if ratios and (worst is None or max(ratios) > worst[1] or missed):
+                worst = (m, max(ratios), missed)
+        modes[mode] = {"runs": len(rr), "per_view": per_view,
+                       "worst_view": None if worst is None else {"view": worst[0], "max": worst[1], "not_reached": worst[2]}}
+    out["modes"] = modes
+    json.dump(out, open(args.out, "w"), indent=1)
+    print(f"# GPU sweeps per sweep of the CPU restatement of the reference, per view: {out['workload']}, {out['docs']} entities; CPU sweeps {targets[0]}..{targets[-1]}\n")
+    print("the reference's own band (one CPU chain against the other): " + ", ".join(f"view {m}: {band[f'view{m}'][0]:.2f}-{band[f'view{m}'][1]:.2f}" for m in range(M) if band[f"view{m}"]) + "\n")
+    print("| mode | runs | " + " | ".join(f"view {m}" for m in range(M)) + " |")
+    print("|---|---|" + "---|" * M)
+    for mode, d in modes.items():
+        cells = []
+        for m in range(M):
+            v = d["per_view"][f"view{m}"]
+            cells.append("not reached" if v["min"] is None else f"{v['min']:.2f}-{v['max']:.2f}" + (f" ({v['not_reached']}/{v['n']} not reached)" if v["not_reached"] else ""))
+        print(f"| {mode} | {d['runs']} | " + " | ".join(cells) + " |")
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -235,6 +327,7 @@ def main():
             p.add_argument("--live16", type=int, nargs="*", default=[], help="pin mvhdp_tuning.live16 (1: live sweeps keep the light n_wk rows in the 16-bit mirror); several values = one run each")
             p.add_argument("--seeds", type=int, nargs="*", default=[], help="one run per seed of every mode (the noise band of a chain)")
             p.add_argument("--tag", default="", help="appended to the run names (which library build this was)")
+            p.add_argument("--live-rows", type=int, default=None, help="pin mvhdp_tuning.live_rows: 1 the tree branch of a live sweep samples from the live count rows, 0 stored trees rebuilt at every segment border")
     p = sub.add_parser("group")
     p.add_argument("--workload", default="C3"); p.add_argument("--docs", type=int, default=200000)
     p.add_argument("--sweeps", type=int, default=100); p.add_argument("--every", type=int, default=5)
@@ -242,8 +335,12 @@ def main():
     p.add_argument("--shards", type=int, default=8); p.add_argument("--segments", type=int, default=4)
     p = sub.add_parser("table")
     p.add_argument("files", nargs="+")
+    p = sub.add_parser("equivalents")
+    p.add_argument("files", nargs="+")
+    p.add_argument("--out", required=True)
+    p.add_argument("--first", type=int, default=10); p.add_argument("--last", type=int, default=100); p.add_argument("--step", type=int, default=10)
     args = ap.parse_args()
-    {"cpu": run_cpu, "gpu": run_gpu, "group": run_group, "table": table}[args.cmd](args)
+    {"cpu": run_cpu, "gpu": run_gpu, "group": run_group, "table": table, "equivalents": equivalents}[args.cmd](args)
 
 
 if __name__ == "__main__":
