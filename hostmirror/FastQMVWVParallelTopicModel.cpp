@@ -382,6 +382,13 @@ void FastQMVWVParallelTopicModel::optimizeDP()
         const int len = histogramSize[m] + 1;
         topicDocCounts[m].assign((size_t)K * len, 0);
         check(dev_.docTopicHist(m, topicDocCounts[m].data(), len, docLengthCounts[m].data(), len), "mvhdp_get_doc_topic_hist");
+        if (deviceTableStatistics_) {                                                    // (opt-in: the same statistic from the library, see include/mvhdp.h)
+            std::vector<double> conc((size_t)K); std::vector<uint8_t> act((size_t)K);
+            for (int t = 0; t < K; t++) conc[t] = gamma[m] * alpha[m][t];
+            check(dev_.dpTableStatistics(m, topicDocCounts[m].data(), len, conc.data(), (randomSeed == -1) ? 0x9E3779B97F4A7C15ull : (uint64_t)(int64_t)randomSeed, (uint32_t)(gammaCalls_ * 16 + m), mk[m].data(), act.data()), "mvhdp_dp_table_statistics");
+            for (int t = 0; t < K; t++) if (act[t]) inActiveTopicIndex.erase(t);
+            continue;
+        }
         for (int t = 0; t < K; t++) {
             const int32_t* tdc = topicDocCounts[m].data() + (size_t)t * len;
             for (int i = 0; i < len; i++) {
@@ -399,6 +406,17 @@ void FastQMVWVParallelTopicModel::optimizeDP()
         }
     }
     // root tables simulation PTM:2491-2517
+    if (deviceTableStatistics_) {                                                        // (opt-in: the K * M draws from the library)
+        std::vector<int32_t> items((size_t)K * M), tabs((size_t)K * M);
+        std::vector<double> conc((size_t)K * M, gammaRoot);
+        for (int t = 0; t < K; t++)
+            for (int m = 0; m < M; m++) {
+                const double c = std::ceil(mk[m][t]);
+                items[(size_t)t * M + m] = mk[m][t] > 1 ? (c >= 2147483647.0 ? 2147483647 : (int)c) : (mk[m][t] == 1 ? 1 : 0);
+            }
+        check(dev_.antoniakDraws(K * M, items.data(), conc.data(), (randomSeed == -1) ? 0x9E3779B97F4A7C15ull : (uint64_t)(int64_t)randomSeed, (uint32_t)(gammaCalls_ * 16 + 15), tabs.data()), "mvhdp_antoniak_draws");
+        for (int t = 0; t < K; t++) for (int m = 0; m < M; m++) mk_root[t] += tabs[(size_t)t * M + m];
+    } else
     for (int t = 0; t < K; t++)
         for (int m = 0; m < M; m++) {
             if (mk[m][t] > 1) {
@@ -746,7 +764,8 @@ void mvtm_set_last_error(const char* msg) { g_host_err = msg ? msg : ""; }
 
 int mvtm_model_set_device_gamma_statistics(void* p, int on)
 {
-    ((FastQMVWVParallelTopicModel*)p)->setDeviceGammaStatistics(on != 0);
+    ((FastQMVWVParallelTopicModel*)p)->setDeviceGammaStatistics((on & 1) != 0);
+    ((FastQMVWVParallelTopicModel*)p)->setDeviceTableStatistics((on & 2) != 0);          // (bit 1: optimizeDP's table simulation on the device)
     return 0;
 }
 

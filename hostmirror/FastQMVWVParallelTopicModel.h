@@ -93,6 +93,8 @@ public:
     // ten rounds per view (reproducible against the Python oracle under an injected stream; 1.9 s per call at C4),
     // true = mvhdp_gamma_doc_statistics on the device (the same random variables in distribution; milliseconds)
     void setDeviceGammaStatistics(bool on) { deviceGammaStatistics_ = on; }
+    // true = optimizeDP's view-table simulation through mvhdp_dp_table_statistics (the Antoniak draws on the device; the default is the reference's loop)
+    void setDeviceTableStatistics(bool on) { deviceTableStatistics_ = on; }
 
     // PTM:396.  batchId / vectorSize / previousModel are outside the hot path (previousModel must be null).
     void addInstances(const std::vector<InstanceList>& training, const std::string& batchId = "", int vectorSize = 0);
@@ -204,7 +206,7 @@ private:
     int64_t docIdBase_ = 0;
     bool liveUpdates_ = false, segmentedUpdates_ = false;
     int liveSegments_ = 0;
-    bool deviceGammaStatistics_ = false;
+    bool deviceGammaStatistics_ = false, deviceTableStatistics_ = false;
     uint32_t gammaCalls_ = 0;
 };
 

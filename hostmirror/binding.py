@@ -207,7 +207,13 @@ class FastQMVWVParallelTopicModel:
 
     def setDeviceGammaStatistics(self, on):
         """optimizeGamma's per-entity sums on the device instead of the reference's sequential host loop."""
-        self.L.mvtm_model_set_device_gamma_statistics(self.p, int(bool(on)))
+        self._dev_stats = (getattr(self, "_dev_stats", 0) & ~1) | int(bool(on))
+        self.L.mvtm_model_set_device_gamma_statistics(self.p, self._dev_stats)
+
+    def setDeviceTableStatistics(self, on):
+        """optimizeDP's view-table simulation (the Antoniak draws, PTM:2454-2488) on the device instead of the reference's host loop."""
+        self._dev_stats = (getattr(self, "_dev_stats", 0) & ~2) | (2 if on else 0)
+        self.L.mvtm_model_set_device_gamma_statistics(self.p, self._dev_stats)
 
     def getInferencer(self, discr_weight=None, p_mean=None):
         """PTM:3457-3463."""

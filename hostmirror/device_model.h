@@ -124,6 +124,14 @@ public:
     {
         return g_ ? grp(mvhdp_group_gamma_doc_statistics(g_, m, gamma_m, seed, round, qs, qw)) : one(mvhdp_gamma_doc_statistics(shards_[0], m, gamma_m, seed, round, qs, qw), shards_[0]);
     }
+    int dpTableStatistics(int m, const int32_t* hist, int32_t len, const double* conc, uint64_t seed, uint32_t round, double* mk, uint8_t* active)
+    {
+        return one(mvhdp_dp_table_statistics(shards_[0], m, hist, len, conc, seed, round, mk, active), shards_[0]);   // (the histogram is the whole model's already)
+    }
+    int antoniakDraws(int n, const int32_t* items, const double* conc, uint64_t seed, uint32_t round, int32_t* tables)
+    {
+        return one(mvhdp_antoniak_draws(shards_[0], n, items, conc, seed, round, tables), shards_[0]);
+    }
     int logLikelihood(double* ll) { return g_ ? grp(mvhdp_group_log_likelihood(g_, ll)) : one(mvhdp_model_log_likelihood(shards_[0], ll), shards_[0]); }
 
     // one Gibbs sweep of the whole model; st: the counters summed over the shards, times the slowest shard's

@@ -223,6 +223,21 @@ int mvhdp_model_log_likelihood(mvhdp_handle h, double* log_likelihood /*[M]*/);
  * draws from its own counter-based stream (seed, global entity id, view, round): the same random variables in distribution,
  * reproducible, shard-independent.  A host keeps its closed-form updates and calls this for the two sums. */
 int mvhdp_gamma_doc_statistics(mvhdp_handle h, int32_t m, double gamma_m, uint64_t seed, uint32_t round, double* qs, double* qw);
+/* optimizeDP PTM:2454-2488, the view-table simulation over topicDocCounts[m] (hist [K][hist_len] as mvhdp_get_doc_topic_hist or
+ * mvhdp_group_doc_topic_hist returns it: host memory).  For every cell (topic t, count i) that holds entities: i == 1 adds them; i > 1
+ * adds them times ONE draw of the number of tables a CRP(conc[t]) makes of i items (conc[t] = gamma[m] * alpha[m][t], PTM:2471) -- the
+ * Antoniak distribution, drawn as the sum of the i - 1 Bernoulli(conc / (conc + l)) table openings from a counter-based stream
+ * (seed, round, view, topic, count).  The reference draws it through a table of Stirling numbers from a stream that cannot be seeded
+ * and scales the CACHED table row in place on every call (Samplers.java:1086-1110); a host that wants that sequence keeps its own loop
+ * (the default of the host classes), one that wants the statistic calls this.  mk[t]: the sum over the cells; active[t]: 1 iff a cell
+ * with i >= 1 holds an entity (PTM:2461,2480: the topic leaves inActiveTopicIndex).  The root level (PTM:2491-2517: K * M draws) stays
+ * with the host. */
+int mvhdp_dp_table_statistics(mvhdp_handle h, int32_t m, const int32_t* hist /*[K][hist_len]*/, int32_t hist_len, const double* conc /*[K]*/,
+                              uint64_t seed, uint32_t round, double* mk /*[K]*/, uint8_t* active /*[K]*/);
+/* n independent draws of the same kind -- optimizeDP's root level PTM:2491-2517 asks for K * M of them, randAntoniak(gammaRoot,
+ * ceil(mk[m][t])): tables[j] = the number of tables a CRP(conc[j]) makes of items[j] items; items <= 0: 0, 1: 1, more than 20000
+ * (the reference's MAXSTIRLING, Samplers.java:1024: its call throws there and PTM:2507-2509 falls back to one table): 1. */
+int mvhdp_antoniak_draws(mvhdp_handle h, int32_t n, const int32_t* items /*[n]*/, const double* conc /*[n]*/, uint64_t seed, uint32_t round, int32_t* tables /*[n]*/);
 /* printDocumentTopics PTM:2871-2899 (and the inferencer's INF:383-411): topic proportions of entities [d0, d1),
  * out[(d-d0)*K + k] = sum_m w[m]*(n_dk[m][k] + gamma[m]*alpha[m][k])/(len[m] + gamma[m]*alphaSum[m]) / sum_m w[m],
  * w[m] = (m == 0 ? 1 : discrWeightPerModality[m]) * pMean[0][m].  As in the reference, whose topicCounts[m] / docLen[m]

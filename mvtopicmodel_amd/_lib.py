@@ -15,7 +15,7 @@ ABI_SYMBOLS = [
     "mvhdp_build_inference_trees", "mvhdp_init_assignments_from_trees",
     "mvhdp_get_counts", "mvhdp_set_counts", "mvhdp_get_tree", "mvhdp_get_doc_topic_hist",
     "mvhdp_get_count_histogram", "mvhdp_view_overlap_sums", "mvhdp_model_log_likelihood", "mvhdp_doc_topic_proportions",
-    "mvhdp_gamma_doc_statistics",
+    "mvhdp_gamma_doc_statistics", "mvhdp_dp_table_statistics", "mvhdp_antoniak_draws",
     "mvhdp_sweep", "mvhdp_sweep_many", "mvhdp_get_tuning", "mvhdp_set_tuning", "mvhdp_plan_probe", "mvhdp_tuner_probe",
     "mvhdp_apply_delta", "mvhdp_apply_delta_begin", "mvhdp_apply_delta_rows", "mvhdp_apply_delta_end",
     "mvhdp_trees_current", "mvhdp_get_view_weights",
@@ -204,6 +204,8 @@ def load_library():
     L.mvhdp_model_log_likelihood.argtypes = [vp, vp]
     L.mvhdp_doc_topic_proportions.argtypes = [vp, vp, i64, i64, vp]
     L.mvhdp_gamma_doc_statistics.argtypes = [vp, i32, C.c_double, u64, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.mvhdp_dp_table_statistics.argtypes = [vp, i32, vp, i32, vp, u64, u32, vp, vp]
+    L.mvhdp_antoniak_draws.argtypes = [vp, i32, vp, vp, u64, u32, vp]
     L.mvhdp_sweep.argtypes = [vp, u32, u64, u32, vp, C.POINTER(DebugC), C.POINTER(SweepStatsC)]
     L.mvhdp_sweep_many.argtypes = [vp, u32, i32, u64, u32, vp]
     L.mvhdp_get_tuning.argtypes = [vp, C.POINTER(TuningC)]

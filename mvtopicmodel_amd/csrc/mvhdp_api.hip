@@ -1750,6 +1750,57 @@ extern "C" int mvhdp_gamma_doc_statistics(mvhdp_handle h, int32_t m, double gamm
     return MVHDP_OK;
 }
 
+// optimizeDP's view-table simulation PTM:2454-2488 on the device (opt-in: mvhdp_stats.hip dp_tables_kernel).  The histogram comes from
+// the host -- a single handle's mvhdp_get_doc_topic_hist or a sharded model's mvhdp_group_doc_topic_hist: the draw of a cell belongs to
+// the WHOLE model's cell, so the statistic is the same however the entities are sharded.
+extern "C" int mvhdp_dp_table_statistics(mvhdp_handle h, int32_t m, const int32_t* hist, int32_t hist_len, const double* conc, uint64_t seed, uint32_t round,
+                                         double* mk, uint8_t* active)
+{
+    CHECK_H(h);
+    MvModel& mm = h->mm;
+    const int K = mm.K;
+    if (m < 0 || m >= mm.M || !hist || hist_len < 1 || !conc || !mk || !active) FAIL(h, MVHDP_ERR_INVALID_ARG, "dp_table_statistics: bad argument");
+    HIPC(h, hipSetDevice(h->device));
+    const size_t hb = (size_t)K * hist_len * sizeof(int32_t);
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, hb + (size_t)K * (2 * sizeof(double) + 8));
+    if (e != hipSuccess) HIPC(h, e);
+    int32_t* d_hist = (int32_t*)d;
+    double* d_conc = (double*)((char*)d + ((hb + 7) & ~(size_t)7));
+    double* d_mk = d_conc + K;
+    uint8_t* d_act = (uint8_t*)(d_mk + K);
+    e = hipMemcpyAsync(d_hist, hist, hb, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_conc, conc, (size_t)K * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = mvhdp_launch_dp_tables(d_hist, hist_len, K, m, d_conc, (uint32_t)seed, (uint32_t)(seed >> 32), round, d_mk, d_act, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mk, d_mk, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(active, d_act, (size_t)K, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    HIPC(h, e);
+    return MVHDP_OK;
+}
+
+// n independent Antoniak draws (optimizeDP's root level PTM:2491-2517 with the device option): see antoniak_draws_kernel
+extern "C" int mvhdp_antoniak_draws(mvhdp_handle h, int32_t n, const int32_t* items, const double* conc, uint64_t seed, uint32_t round, int32_t* tables)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && (!items || !conc || !tables))) FAIL(h, MVHDP_ERR_INVALID_ARG, "antoniak_draws: bad argument");
+    if (n == 0) return MVHDP_OK;
+    HIPC(h, hipSetDevice(h->device));
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, (size_t)n * (sizeof(double) + 2 * sizeof(int32_t)));
+    if (e != hipSuccess) HIPC(h, e);
+    double* d_conc = (double*)d; int32_t* d_items = (int32_t*)(d_conc + n); int32_t* d_tab = d_items + n;
+    e = hipMemcpyAsync(d_conc, conc, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_items, items, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = mvhdp_launch_antoniak_draws(n, d_items, d_conc, (uint32_t)seed, (uint32_t)(seed >> 32), round, d_tab, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tables, d_tab, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    HIPC(h, e);
+    return MVHDP_OK;
+}
+
 // modelLogLikelihood PTM:3322-3452 in two parts, so that a group of document shards can put them together (mvhdp_group_log_likelihood):
 // the DOCUMENT part of view m (PTM:3341-3367) belongs to the entities of a handle -- *ll and *cnt (modalityCnt) continue a sequential
 // sum in entity order --, the MODEL part (PTM:3373-3441: the modalityCnt term, the topic-word term over n_wk, the n_k terms) to the

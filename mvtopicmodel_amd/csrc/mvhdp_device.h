@@ -172,6 +172,9 @@ hipError_t mvhdp_launch_loglik_doc(const MvModel& mm, int m, double* doc_out, hi
 hipError_t mvhdp_launch_loglik_topic(const MvModel& mm, int m, double* partial, int n_partial, unsigned long long* nonzero, hipStream_t s);
 hipError_t mvhdp_launch_gamma_doc_stats(const MvModel& mm, int m, double gamma_m, uint32_t seed_lo, uint32_t seed_hi, uint32_t round,
                                         double* partial, int n_blocks, hipStream_t s);
+hipError_t mvhdp_launch_dp_tables(const int32_t* hist, int hist_len, int K, int m, const double* conc, uint32_t seed_lo, uint32_t seed_hi, uint32_t round,
+                                  double* mk, uint8_t* active, hipStream_t s);
+hipError_t mvhdp_launch_antoniak_draws(int n, const int32_t* items, const double* conc, uint32_t seed_lo, uint32_t seed_hi, uint32_t round, int32_t* tables, hipStream_t s);
 // counts every entity's topic list from z: writes MvModel::nslots and the histograms of SweepLaunch::slot_hist
 hipError_t mvhdp_launch_slot_hist(const MvModel& mm, unsigned long long* hist, hipStream_t s);
 struct DocTopicCarry { const int64_t* src[MVHDP_MAXM]; };   // per view [D]: the entity whose counts score entity d (PTM:2873-2886)

@@ -311,6 +311,79 @@ __global__ __launch_bounds__(256) void gamma_doc_stats_kernel(MvModel mm, int m,
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sh[0][0]; partial[2 * blockIdx.x + 1] = sh[1][0]; }
 }
 
+// optimizeDP, the view-table simulation PTM:2454-2488, one thread per (topic t, count i) cell of topicDocCounts[m]: a cell with
+// i == 1 holds entities with one table each; a cell with i > 1 takes ONE draw of the number of tables a Chinese restaurant process of
+// concentration conc[t] = gamma_m * alpha[m][t] makes of i items (Antoniak 1974), times the entities in the cell (the reference draws
+// once per cell, PTM:2471-2477).  The number of tables of a CRP is a sum of independent Bernoullis, table l + 1 opened with probability
+// conc / (conc + l): the distribution Samplers.randAntoniak draws from through its table of Stirling numbers (Samplers.java:1086-1110),
+// without that table -- and without the call's in-place scaling of the CACHED row, which in the reference carries one call's alpha powers
+// into the next.  Streams: Philox keyed by (seed, round), counter (draw, view, topic, count): reproducible, independent of the launch.
+// mk[t] = sum over the cells; active[t] = 1 iff a cell with i >= 1 holds an entity (the topic leaves inActiveTopicIndex, PTM:2461,2480).
+__global__ __launch_bounds__(256) void dp_tables_kernel(const int32_t* __restrict__ hist, int hist_len, int m, const double* __restrict__ conc,
+                                                        uint32_t seed_lo, uint32_t seed_hi, uint32_t round, double* __restrict__ mk, uint8_t* __restrict__ active)
+{
+    __shared__ double sh[256];
+    __shared__ int any;
+    const int t = blockIdx.x;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    const double a = conc[t];
+    double acc = 0.0;
+    for (int i = 1 + (int)threadIdx.x; i < hist_len; i += blockDim.x) {
+        const int n = hist[(int64_t)t * hist_len + i];
+        if (n <= 0) continue;
+        any = 1;
+        if (i == 1) { acc += (double)n; continue; }                     // PTM:2479-2483
+        int tables = 1;                                                 // (the first item opens the first table)
+        if (a > 0.0) {
+            PhiloxStream r;
+            r.c0 = 0; r.c1 = 0x300u + (uint32_t)m; r.c2 = (uint32_t)t; r.c3 = (uint32_t)i;
+            r.k0 = seed_lo ^ round; r.k1 = seed_hi; r.have = 0;
+            for (int l = 1; l < i; l++) tables += (r.uniform() * (a + (double)l) < a) ? 1 : 0;
+        }
+        acc += (double)n * (double)tables;                              // PTM:2477
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) { if ((int)threadIdx.x < s2) sh[threadIdx.x] += sh[threadIdx.x + s2]; __syncthreads(); }
+    if (threadIdx.x == 0) { mk[t] = sh[0]; active[t] = any ? 1 : 0; }
+}
+
+hipError_t mvhdp_launch_dp_tables(const int32_t* hist, int hist_len, int K, int m, const double* conc, uint32_t seed_lo, uint32_t seed_hi, uint32_t round,
+                                  double* mk, uint8_t* active, hipStream_t s)
+{
+    hipLaunchKernelGGL(dp_tables_kernel, dim3(K), dim3(256), 0, s, hist, hist_len, m, conc, seed_lo, seed_hi, round, mk, active);
+    return hipGetLastError();
+}
+
+// n independent Antoniak draws, one thread each (optimizeDP's root level PTM:2491-2517: K * M of them, of up to MAXSTIRLING items each):
+// tables[j] = the number of tables a CRP(conc[j]) makes of items[j] items.  items <= 0: 0; 1: 1; more than 20000: 1 -- the reference's
+// table of Stirling numbers ends there (Samplers.java:1024,1034: allss = new double[MAXSTIRLING][]), its call throws and the caller
+// falls back to one table (PTM:2507-2509).  Filling that table up to the largest count asked for is what an optimising iteration of the
+// host loop spends its time on (n^2 / 2 products: 0.4 s at C4).
+__global__ __launch_bounds__(256) void antoniak_draws_kernel(int n, const int32_t* __restrict__ items, const double* __restrict__ conc,
+                                                             uint32_t seed_lo, uint32_t seed_hi, uint32_t round, int32_t* __restrict__ tables)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int it = items[j];
+    const double a = conc[j];
+    int t = it <= 0 ? 0 : 1;
+    if (it > 1 && it <= 20000 && a > 0.0) {
+        PhiloxStream r;
+        r.c0 = 0; r.c1 = 0x400u; r.c2 = (uint32_t)j; r.c3 = round;
+        r.k0 = seed_lo; r.k1 = seed_hi; r.have = 0;
+        for (int l = 1; l < it; l++) t += (r.uniform() * (a + (double)l) < a) ? 1 : 0;
+    }
+    tables[j] = t;
+}
+
+hipError_t mvhdp_launch_antoniak_draws(int n, const int32_t* items, const double* conc, uint32_t seed_lo, uint32_t seed_hi, uint32_t round, int32_t* tables, hipStream_t s)
+{
+    hipLaunchKernelGGL(antoniak_draws_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, items, conc, seed_lo, seed_hi, round, tables);
+    return hipGetLastError();
+}
+
 hipError_t mvhdp_launch_gamma_doc_stats(const MvModel& mm, int m, double gamma_m, uint32_t seed_lo, uint32_t seed_hi, uint32_t round,
                                         double* partial, int n_blocks, hipStream_t s)
 {

@@ -542,6 +542,26 @@ JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGammaDocStati
     env->SetDoubleArrayRegion(out, 0, 2, v);
 }
 
+// optimizeDP's view-table simulation PTM:2454-2488: hist [K][histLen] (of the whole model), conc [K] = gamma[m] * alpha[m][t]; mk [K], active [K] filled
+JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nDpTableStatistics(JNIEnv* env, jclass, jlong p, jint m, jintArray hist, jint histLen, jdoubleArray conc,
+                                                                                      jlong seed, jint round, jdoubleArray mk, jbyteArray active)
+{
+    ShardPin pin_(p); Shard* s = pin_.s;
+    if (!s) { throw_msg(env, "java/lang/IllegalStateException", "NativeSampler is closed"); return; }
+    if (m < 0 || m >= s->M || histLen < 1) { throw_msg(env, "java/lang/IllegalArgumentException", "dpTableStatistics: bad view or histLen"); return; }
+    if (bad_len(env, hist, (jlong)s->K * histLen, "dpTableStatistics hist [K][histLen]") || bad_len(env, conc, s->K, "dpTableStatistics conc") ||
+        bad_len(env, mk, s->K, "dpTableStatistics mk") || bad_len(env, active, s->K, "dpTableStatistics active")) return;
+    std::vector<double> cv(static_cast<size_t>(s->K)), mv(static_cast<size_t>(s->K));
+    std::vector<uint8_t> av(static_cast<size_t>(s->K));
+    env->GetDoubleArrayRegion(conc, 0, s->K, cv.data());
+    int rc;
+    { Ints a(env, hist, 0); if (a.failed()) return;
+      rc = mvhdp_dp_table_statistics(s->h, m, reinterpret_cast<const int32_t*>(a.p), histLen, cv.data(), static_cast<uint64_t>(seed), static_cast<uint32_t>(round), mv.data(), av.data()); }
+    if (rc) { throw_rt(env, s->h, rc, "mvhdp_dp_table_statistics"); return; }
+    env->SetDoubleArrayRegion(mk, 0, s->K, mv.data());
+    env->SetByteArrayRegion(active, 0, s->K, reinterpret_cast<const jbyte*>(av.data()));
+}
+
 JNIEXPORT void JNICALL Java_org_madgik_MVTopicModel_NativeSampler_nGroupDrain(JNIEnv* env, jclass, jlong p)
 {
     GroupPin gpin_(p); Group* gr = gpin_.s;

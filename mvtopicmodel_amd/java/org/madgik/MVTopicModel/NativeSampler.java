@@ -76,6 +76,8 @@ public final class NativeSampler implements AutoCloseable {
     public double[] viewOverlapSums(int numModalities) { double[] s = new double[numModalities * numModalities]; nViewOverlapSums(handle, s); return s; }
     /** optimizeGamma's document level (lines 2415-2433): {qs, qw}, every entity drawing from its own counter-based stream. */
     public double[] gammaDocStatistics(int m, double gammaM, long seed, int round) { double[] o = new double[2]; nGammaDocStatistics(handle, m, gammaM, seed, round, o); return o; }
+    /** optimizeDP's view-table simulation PTM:2454-2488 over topicDocCounts[m] (hist [K][histLen], of the whole model): mk [K] and active [K] are filled. */
+    public void dpTableStatistics(int m, int[] hist, int histLen, double[] conc, long seed, int round, double[] mk, byte[] active) { nDpTableStatistics(handle, m, hist, histLen, conc, seed, round, mk, active); }
 
     /**
      * n sweeps (indices firstIdx .. firstIdx+n-1) enqueued back to back, one synchronisation at the end: the iteration loop
@@ -226,6 +228,7 @@ public final class NativeSampler implements AutoCloseable {
     private static native void nGetCountHistogram(long h, int m, int[] hist);
     private static native void nViewOverlapSums(long h, double[] sums);
     private static native void nGammaDocStatistics(long h, int m, double gammaM, long seed, int round, double[] out);
+    private static native void nDpTableStatistics(long h, int m, int[] hist, int histLen, double[] conc, long seed, int round, double[] mk, byte[] active);
     private static native void nGroupAbort(long g);
     private static native void nGroupDrain(long g);
     private static native void nGroupModelLogLikelihood(long g, double[] out);

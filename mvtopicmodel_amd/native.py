@@ -332,6 +332,21 @@ class NativeSampler:
                 setattr(t, k, v)
         self._ck(self.L.mvhdp_set_tuning(self.h, C.byref(t)))
 
+    def dp_table_statistics(self, m, hist, conc, seed, round_idx):
+        """optimizeDP's view-table simulation on the device (mvhdp_dp_table_statistics): (mk [K], active [K])."""
+        hist = np.ascontiguousarray(hist, dtype=np.int32)
+        conc = np.ascontiguousarray(conc, dtype=np.float64)
+        mk = np.zeros(self.K, dtype=np.float64); act = np.zeros(self.K, dtype=np.uint8)
+        self._ck(self.L.mvhdp_dp_table_statistics(self.h, int(m), _ptr(hist), int(hist.shape[1]), _ptr(conc), int(seed), int(round_idx), _ptr(mk), _ptr(act)))
+        return mk, act
+
+    def antoniak_draws(self, items, conc, seed, round_idx):
+        """n independent draws of the number of tables a CRP(conc[j]) makes of items[j] items (mvhdp_antoniak_draws)."""
+        items = np.ascontiguousarray(items, dtype=np.int32); conc = np.ascontiguousarray(conc, dtype=np.float64)
+        out = np.zeros(len(items), dtype=np.int32)
+        self._ck(self.L.mvhdp_antoniak_draws(self.h, len(items), _ptr(items), _ptr(conc), int(seed), int(round_idx), _ptr(out)))
+        return out
+
     def apply_delta(self, activated_topic=-1, activated_modality=-1):
         self._ck(self.L.mvhdp_apply_delta(self.h, int(activated_topic), int(activated_modality)))
 

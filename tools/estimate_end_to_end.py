@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--optimize-interval", type=int, default=50)
     ap.add_argument("--live", action="store_true")
     ap.add_argument("--device-gamma", action="store_true", help="optimizeGamma's per-entity sums on the device")
+    ap.add_argument("--device-tables", action="store_true", help="optimizeDP's view-table simulation (the Antoniak draws) on the device")
     ap.add_argument("--shards", type=int, default=1, help="keep the model as n document shards behind an mvhdp_group (all on this GPU)")
     args = ap.parse_args()
     from mvtopicmodel_amd import synth
@@ -48,6 +49,7 @@ def main():
     model.setOptimizeInterval(args.optimize_interval); model.setRandomSeed(1)
     model.setLiveUpdates(args.live)
     model.setDeviceGammaStatistics(args.device_gamma)
+    model.setDeviceTableStatistics(args.device_tables)
     model.setNumShards(args.shards)
     t0 = time.perf_counter()
     model.addInstances(training)
@@ -60,20 +62,25 @@ def main():
     it = np.arange(1, len(ms) + 1)
     opt = (it > args.burnin) & (it % args.optimize_interval == 0)
     ll = (it % 10 == 0)
-    plain = ~opt & ~ll
+    tw = (it % 50 == 0)                          # displayTopWords every showTopicsInterval = 50 iterations (PTM:117,1150-1152): the reference's logging, on the host
+    plain = ~opt & ~ll & ~tw
     kern = np.array([x[1]["sweep_kernel_ms"] for x in log])
     out = {
-        "workload": args.workload, "entities": model.num_entities(), "tokens": c.total_tokens, "update_mode": "live" if args.live else "deferred", "optimizeGamma_document_sums": "device" if args.device_gamma else "host loop (reference)", "shards": args.shards,
+        "workload": args.workload, "entities": model.num_entities(), "tokens": c.total_tokens, "update_mode": "live" if args.live else "deferred", "optimizeGamma_document_sums": "device" if args.device_gamma else "host loop (reference)", "optimizeDP_view_tables": "device" if args.device_tables else "host loop (reference)", "shards": args.shards,
         "iterations": args.iterations, "burnin": args.burnin, "optimize_interval": args.optimize_interval,
         "addInstances_s": round(t_add, 3), "estimate_s": round(t_est, 3),
         "ms_per_plain_iteration_median": round(float(np.median(ms[plain])), 3),
         "sweep_kernel_ms_median": round(float(np.median(kern)), 3),
-        "ms_per_iteration_with_LL_median": round(float(np.median(ms[ll & ~opt])), 3),
-        "ms_per_optimising_iteration_median": round(float(np.median(ms[opt])), 3) if opt.any() else None,
+        "ms_per_iteration_with_LL_median": round(float(np.median(ms[ll & ~opt & ~tw])), 3),
+        "ms_per_optimising_iteration_median": round(float(np.median(ms[opt & ~tw])), 3) if (opt & ~tw).any() else None,
+        "ms_per_iteration_with_top_words_median": round(float(np.median(ms[tw & ~opt])), 3) if (tw & ~opt).any() else None,
         "optimising_iterations": int(opt.sum()),
         "share_of_estimate_time": {"sweeps": round(float(kern.sum() / 1e3 / t_est), 3),
-                                   "optimise_extra": round(float((ms[opt] - np.median(ms[plain])).sum() / 1e3 / t_est), 3) if opt.any() else 0.0,
-                                   "log_likelihood_extra": round(float((ms[ll & ~opt] - np.median(ms[plain])).sum() / 1e3 / t_est), 3)},
+                                   "optimise_extra": round(float((ms[opt & ~tw] - np.median(ms[plain])).sum() / 1e3 / t_est), 3) if (opt & ~tw).any() else 0.0,
+                                   "top_words_extra": round(float((ms[tw & ~opt] - np.median(ms[plain])).sum() / 1e3 / t_est), 3) if (tw & ~opt).any() else 0.0,
+                                   "log_likelihood_extra": round(float((ms[ll & ~opt & ~tw] - np.median(ms[plain])).sum() / 1e3 / t_est), 3)},
+        # between two optimisations past the burn-in: the sweeps' share of the interval's wall time (logging apart)
+        "sweeps_share_of_an_optimise_interval": round(float(args.optimize_interval * np.median(ms[plain]) / (args.optimize_interval * np.median(ms[plain]) + (np.median(ms[opt & ~tw]) - np.median(ms[plain])))), 3) if (opt & ~tw).any() else None,
         "tokens_per_s_over_estimate": round(c.total_tokens * args.iterations / t_est / 1e9, 3),
         "LL_per_token_view0": [round(float(x), 4) for x in model.perplexities(0)[1:]][:: max(1, args.iterations // 100)],
     }

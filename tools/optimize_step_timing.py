@@ -13,6 +13,8 @@ for m in range(M):
     training.append((have.astype(np.int64), off, c.tokens[m], V[m]))
 model = FastQMVWVParallelTopicModel(K, M, 0.1, 0.01)
 model.setNumIterations(30); model.setBurninPeriod(100); model.setOptimizeInterval(50); model.setRandomSeed(1)
+if len(sys.argv) > 2 and sys.argv[2] == "device":
+    model.setDeviceGammaStatistics(True); model.setDeviceTableStatistics(True)
 model.addInstances(training); model.estimate()
 out = {}
 for nm, fn in (("optimizeP", model.optimizeP), ("optimizeDP", model.optimizeDP), ("optimizeGamma", model.optimizeGamma), ("optimizeBeta", model.optimizeBeta), ("modelLogLikelihood", model.modelLogLikelihood)):
