@@ -35,7 +35,7 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
     """The two ceilings that can actually bind the sweep kernels, as fractions below 1 (the fixed-byte yardstick of SURVEY 8d assumes
     4-byte counts and a whole row per token; the kernels gather 2-byte cells, so that fraction passes 1):
 
-      physical  fabric bytes per token -- (TCC_EA0_RDREQ x 128 B + WRITE_SIZE), the PMC passes of profiles/profile_r04.sh over the very
+      physical  fabric bytes per token -- (TCC_EA0_RDREQ x 128 B + WRITE_SIZE), the PMC passes of profiles/profile_r05.sh over the very
                 window this command times -- x tokens per launch / the kernel time measured HERE, against the 8 TB/s HBM peak and
                 against what a bare gather of the same rows reaches on this chip (tools/microbench/gather_patterns.hip)
       issue     cycles per token during which a SIMD's vector ALU (scalar unit) is busy -- SQ_ACTIVE_INST_VALU / _SCA x 4 of the SQ
@@ -44,8 +44,12 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
     Counters cannot be read inside an un-profiled run: the per-token figures are the committed profile's (same build, same command),
     the rate is this run's.  Returns (physical, issue) dicts or (None, None) when the profile of this workload is not committed."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r04_roofline_inputs.json")))
-        w = prof["workloads"][workload][mode]
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r05_roofline_inputs.json")))
+            w = prof["workloads"][workload][mode]
+        except Exception:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r04_roofline_inputs.json")))     # (a workload profiled in round 4 only: the deferred kernels are unchanged)
+            w = prof["workloads"][workload][mode]
     except Exception:
         return None, None
     tok_s = tokens_per_launch / avg_kernel_s
@@ -72,16 +76,32 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
 
 
 def sweep_equivalents(K):
-    """GPU sweeps per sweep of the CPU restatement of the reference (view 0, CPU sweeps 5..100), by update mode; profiles/r04_ll_curves.md."""
-    if K >= 256:
-        return {"source": "profiles/r04_ll_curves.md, section C4 (200k-entity slice, K = 400): profiles/r04_ll_cpu_c4_200k.json against "
-                          "r04_ll_gpu_c4_200k_live16_vs_live32.json (two seeds) and r04_ll_gpu_c4_200k_modes.json",
-                "gpu_sweeps_per_reference_sweep": {"deferred": [1.5, 3.2], "live": [0.98, 1.18], "live_8_segments": [0.93, 1.03], "segmented": [1.02, 1.12]},
-                "note": "deferred: not reached within 120 sweeps beyond CPU sweep 40; live = the library's default of 4 segments"}
-    return {"source": "profiles/r04_ll_curves.md, section C3 (K = 200): profiles/r02_ll_cpu.json against r04_ll_gpu_c3_live16_vs_live32.json "
-                      "(two seeds) and r04_ll_gpu_c3_modes.json",
-            "gpu_sweeps_per_reference_sweep": {"deferred": [1.4, 2.3], "live": [0.92, 1.05], "live_8_segments": [0.92, 1.0], "segmented": [0.94, 1.07]},
-            "note": "deferred: not reached within 100 sweeps beyond CPU sweep 45; live = the library's default of 4 segments"}
+    """GPU sweeps per sweep of the CPU restatement of the reference, PER VIEW, by update mode: how many sweeps of the mode reach the
+    LL/token the reference reaches after n sweeps (n = 10 .. 100), against two chains of the (nondeterministic) reference and every seed
+    of the mode -- tools/ll_curves.py equivalents, committed as profiles/r05_sweep_equivalents_*.json.  `worst_view` is the range of the
+    view that needs most; `cpu_band` is the reference against itself (one chain's sweeps to reach the other's LL)."""
+    name = "r05_sweep_equivalents_c4_200k.json" if K >= 256 else "r05_sweep_equivalents_c3.json"
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception as e:
+        return {"source": f"profiles/{name} missing ({e!r})", "gpu_sweeps_per_reference_sweep": {}, "per_view": {}}
+    key = {"deferred": "gpu deferred (snapshot sweep)", "live": "gpu live, default segment(s) per sweep",
+           "segmented": "gpu deferred in 8 segments, applied in between", "live_stored_trees_4_segments": "gpu live, 4 segment(s) per sweep (stored trees rebuilt per segment)"}
+    out, per_view = {}, {}
+    for mode, run in key.items():
+        d = j["modes"].get(run)
+        if not d:
+            continue
+        pv = {v: ([round(x["min"], 3), round(x["max"], 3)] if x["min"] is not None else None) for v, x in d["per_view"].items()}
+        nr = {v: f"{x['not_reached']}/{x['n']}" for v, x in d["per_view"].items() if x["not_reached"]}
+        per_view[mode] = {"range": pv, "not_reached": nr}
+        worst = max((x["max"] for x in d["per_view"].values() if x["max"] is not None), default=None)
+        best = min((x["min"] for x in d["per_view"].values() if x["min"] is not None), default=None)
+        out[mode] = [round(best, 3), round(worst, 3)] if worst is not None else None
+    return {"source": f"profiles/{name} ({j['workload']}, {j['docs']} entities; CPU sweeps {j['cpu_sweeps'][0]}..{j['cpu_sweeps'][-1]}; sources {', '.join(j['sources'])})",
+            "gpu_sweeps_per_reference_sweep": out,           # over ALL views: [fewest, most]
+            "per_view": per_view, "cpu_band": j.get("cpu_band"),
+            "note": "ranges over two CPU chains x the mode's seeds x CPU sweeps 10..100; 'not_reached': comparisons in which the mode's run ended below the reference's LL"}
 
 
 def algorithmic_bytes_per_token(K):
@@ -341,7 +361,7 @@ def main():
     if physical:
         traffic_note = (f"{physical['bytes_per_token']:.0f} B/token = TCC_EA0_RDREQ x 128 B (= 2 x FETCH_SIZE: the gfx950 correction, calibrated on "
                         "this access pattern in profiles/r02_fetch_calibration.txt) + WRITE_SIZE, Infinity-Cache hits included; PMC passes of "
-                        "profiles/profile_r04.sh over the timed sweeps of this very command (a rocprofv3 run of its own, same build), the rate is this run's")
+                        "profiles/profile_r05.sh over the timed sweeps of this very command (a rocprofv3 run of its own, same build), the rate is this run's")
     binding = None
     if physical and issue:
         fabric = physical.get("frac_of_gather_ceiling") or physical["frac"]
@@ -375,12 +395,12 @@ def main():
         # update and tree rebuild of the row ranges (mvhdp_group_info.last_exchange_ms)
         "phase_ms": {k: v / max(1, phases.get("n", 1)) for k, v in phases.items() if k != "n"},
         "exchange": exchange,
-        "update_mode": ("live, %d tree rebuilds per sweep" % (args.live_segments or 4)) if args.live else "deferred (snapshot sweep, bit-reproducible)",
+        "update_mode": ("live (live-rows form), %d segment(s) per sweep" % (args.live_segments or 1)) if args.live else "deferred (snapshot sweep, bit-reproducible)",
         "step_calls": "one mvhdp_sweep_many call for the K steps" if (args.batch and world == 1) else "one call per step",
-        # What a sweep of each update mode is worth, in sweeps of the CPU restatement of the reference's thread topology: GPU sweeps
-        # needed to reach the log-likelihood the reference reaches in one, from the curves of the configuration that is timed -- the
-        # 200k-entity slice of C4 (K = 400: where live sweeps run on the 16-bit mirror) for K >= 256, C3 (K = 200) below; two seeds per
-        # live form (profiles/r04_ll_curves.md).  Tokens/s of different modes are comparable only after dividing by it.
+        # What a sweep of each update mode is worth IN EVERY VIEW, in sweeps of the CPU restatement of the reference's thread topology: GPU
+        # sweeps needed to reach the log-likelihood the reference reaches in one, from the curves of the configuration that is timed -- the
+        # 200k-entity slice of C4 (K = 400: where live sweeps run on the 16-bit mirror) for K >= 256, C3 (K = 200) below; two CPU chains,
+        # two seeds per live form (profiles/r05_ll_curves.md).  Tokens/s of different modes are comparable only after dividing by it.
         "reference_sweep_equivalent": sweep_equivalents(K),
     }
     # order-independent fingerprint of the final global counts: must not depend on the number of shards
@@ -388,7 +408,7 @@ def main():
     out["final_nk_fingerprint"] = nk_fp
     eq = out["reference_sweep_equivalent"]["gpu_sweeps_per_reference_sweep"]
     main_mode = "live" if args.live else "deferred"
-    out["value_in_reference_sweeps"] = {main_mode: [value / eq[main_mode][1], value / eq[main_mode][0]]}
+    out["value_in_reference_sweeps"] = {main_mode: [value / eq[main_mode][1], value / eq[main_mode][0]]} if eq.get(main_mode) else {}
     if args.live_steps is None:
         args.live_steps = 10 if world == 1 else 0
     sec_warm = 3                                    # warm-up sweeps of a secondary mode (its kernels' flavours and thresholds settle)
@@ -399,10 +419,21 @@ def main():
             step(first_idx + k, flags)
         barrier()
         t1 = time.perf_counter()
+        km = []
         for k in range(args.live_steps):
-            step(first_idx + sec_warm + k, flags)
+            km.append(step(first_idx + sec_warm + k, flags).sweep_kernel_ms)
         barrier()
+        mode_kernel_ms[0] = float(np.mean(km)) if km else 0.0
         return max_over_ranks(time.perf_counter() - t1)
+
+    mode_kernel_ms = [0.0]
+
+    def mode_rooflines(mode):
+        """the two ceilings of a secondary mode's sweep kernels, from the PMC / SQ passes over ITS window of this command (profiles/profile_r05.sh)"""
+        if mode_kernel_ms[0] <= 0:
+            return {}
+        ph, iss = physical_rooflines(args.workload, local_tokens, mode_kernel_ms[0] / 1e3, mode)
+        return {"roofline": {"avg_kernel_ms": mode_kernel_ms[0], "physical": ph, "issue": iss}} if ph else {"roofline": {"avg_kernel_ms": mode_kernel_ms[0], "physical": None}}
 
     if not args.live and args.live_steps > 0:
         # The other update mode, timed after (and outside) the K steps above: MVHDP_SWEEP_LIVE, the reference's own discipline
@@ -412,10 +443,13 @@ def main():
             dl = time_mode(lf, base_idx)
             v = total_tokens * args.live_steps / dl
             out["live"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm,
-                           "ms_per_step": dl / args.live_steps * 1e3, "tree_rebuilds_per_sweep": args.live_segments or 4,
-                           "note": "MVHDP_SWEEP_LIVE (on the 16-bit mirror where K >= 256, segments overlapped), timed after the K deferred "
-                                   "steps; not bit-reproducible; what a sweep of it is worth: reference_sweep_equivalent"}
-            out["value_in_reference_sweeps"]["live"] = [v / eq["live"][1], v / eq["live"][0]]
+                           "ms_per_step": dl / args.live_steps * 1e3, "segments_per_sweep": args.live_segments or 1,
+                           "note": "MVHDP_SWEEP_LIVE in its live-rows form (the tree branch samples from the word's live count row, on the 16-bit "
+                                   "mirror where K >= 256; one segment), timed after the K deferred steps; not bit-reproducible; what a sweep of it "
+                                   "is worth in every view: reference_sweep_equivalent"}
+            out["live"].update(mode_rooflines("live"))
+            if eq.get("live"):
+                out["value_in_reference_sweeps"]["live"] = [v / eq["live"][1], v / eq["live"][0]]
         except Exception as e:                      # the secondary measurement must never cost the primary one
             out["live"] = {"error": repr(e)}
     if world == 1 and not args.live and args.live_steps > 0:
@@ -429,7 +463,9 @@ def main():
                                 "ms_per_step": dsg / args.live_steps * 1e3, "segments": 8,
                                 "note": "MVHDP_SWEEP_SEGMENT_APPLY: deferred sweep in 8 segments, deltas applied and trees rebuilt in "
                                         "between; deterministic (oracle-checked), about one reference sweep per sweep"}
-            out["value_in_reference_sweeps"]["segmented"] = [v / eq["segmented"][1], v / eq["segmented"][0]]
+            out["segmented"].update(mode_rooflines("segmented"))
+            if eq.get("segmented"):
+                out["value_in_reference_sweeps"]["segmented"] = [v / eq["segmented"][1], v / eq["segmented"][0]]
         except Exception as e:
             out["segmented"] = {"error": repr(e)}
         # ... and the deferred sweep once more, at the chain age the two modes above were timed at: `value` is taken over sweeps
@@ -438,7 +474,7 @@ def main():
         try:
             dd = time_mode(0, base_idx + 2 * (sec_warm + args.live_steps))
             v = total_tokens * args.live_steps / dd
-            out["deferred_same_age"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm, "ms_per_step": dd / args.live_steps * 1e3,
+            out["deferred_same_age"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm, "ms_per_step": dd / args.live_steps * 1e3, **mode_rooflines("deferred_same_age"),
                                         "note": "the deferred mode timed like `live` and `segmented`, after them: the denominator for comparing the modes"}
             for k in ("live", "segmented"):
                 if "value" in out.get(k, {}):

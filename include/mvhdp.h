@@ -126,9 +126,16 @@ typedef struct {
 /* The reference's own update discipline (UPD:197-218 applied WHILE the workers sample; PTM:84-87: racy reads by design):
  * the sweep's n_wk atomics go straight to the shared count array and every later token of the sweep reads them.  Not
  * reproducible run to run (like the reference); counts stay consistent with z.  The entities are cut into
- * MVHDP_SWEEP_LIVE_SEGMENTS(n) interleaved segments (n = 1..255, 0 = library default 4); at each segment boundary the
- * tokensPerTopic updates of the segment (privatised per workgroup: M*K hot words) land and the F+trees are rebuilt from
- * the live counts (with REUSE_TREES: no rebuild at all, the host's PTM:1209 cadence).
+ * MVHDP_SWEEP_LIVE_SEGMENTS(n) interleaved segments (n = 1..255, 0 = library default); at each segment boundary the
+ * tokensPerTopic updates of the segment (privatised per workgroup: M*K hot words) land.
+ * The tree branch (WRK:533-535) -- two forms, mvhdp_tuning.live_rows:
+ *   live rows (default wherever every kernel of the sweep is register-resident; default 1 segment): no stored tree is sampled for a
+ *     word of at most 65534 tokens; the branch draws from leaf_k = coef_k * (n_wk + beta) with n_wk the word's LIVE row, read when the
+ *     token's turn comes, and coef_k = gamma alpha_k / (n_k + beta Sigma) of the segment start -- what the reference's updater achieves
+ *     by refreshing the two touched leaves with every delta (UPD:242-260 -> FT:138-147).  Heavier words keep stored trees, rebuilt from
+ *     the live counts over and over by a kernel that runs beside the samplers;
+ *   stored trees (live_rows = 0, and wherever the generic kernel serves: default 4 segments): the F+trees are rebuilt from the live
+ *     counts at every segment boundary (with REUSE_TREES: no rebuild at all, the host's PTM:1209 cadence).
  * With NO_APPLY the delta buffer receives (counts after - counts before) of this shard and counts are restored, so the
  * multi-GPU sequence all-reduce + mvhdp_apply_delta is the same as for a deferred sweep.  Not combinable with FROZEN.
  * (LIVE_SEGMENTS without LIVE cuts a deferred sweep into the same segments: same integers as one segment.)
@@ -305,10 +312,9 @@ typedef struct {
     int32_t live_overlap;                        /* MVHDP_SWEEP_LIVE with several segments: -1 (default) / 1: the next segment's trees are rebuilt (from the live counts)
                                                     and its kernels launched when the current segment is nearly through, so that no segment border idles the chip;
                                                     0: one segment after the other (the round-3 form) */
-    int32_t live_rows;                           /* MVHDP_SWEEP_LIVE: -1 (default) / 1: the tree branch of a token (WRK:533-535) samples from the word's LIVE count row and
-                                                    tree[1] follows every delta by an atomic -- what the reference's updater achieves by refreshing the two touched leaves
-                                                    per delta (UPD:242-260) -- wherever every kernel of the sweep is register-resident; no stored trees, two segments;
-                                                    0: stored trees rebuilt at every segment border, four segments (the round-4 form) */
+    int32_t live_rows;                           /* MVHDP_SWEEP_LIVE: -1 (default) / 1: the tree branch of a token (WRK:533-535) samples from the word's LIVE count row
+                                                    (see MVHDP_SWEEP_LIVE) wherever every kernel of the sweep is register-resident; one segment per sweep by default;
+                                                    0: stored trees rebuilt at every segment border, four segments by default (the round-4 form) */
 } mvhdp_tuning;
 int mvhdp_get_tuning(mvhdp_handle h, mvhdp_tuning* t);
 int mvhdp_set_tuning(mvhdp_handle h, const mvhdp_tuning* t);
