@@ -104,8 +104,12 @@ def run(args):
         ks = sorted(glob.glob(os.path.join(wd, "prof", "**", "*kernel_stats.csv"), recursive=True))
         if ks:
             per = {}
+            allk = {}
             for row in csv.DictReader(open(ks[-1])):
-                n = row["Name"].split("(")[0].replace("void ", "")
+                allk[row["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:80]] = round(float(row["TotalDurationNs"]) / 1e6 / (args.warmup + args.steps), 4)
+            form["all_kernels_rank0_ms_per_sweep"] = dict(sorted(allk.items(), key=lambda kv: -kv[1])[:30])
+            for row in csv.DictReader(open(ks[-1])):
+                n = row["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 if any(t in n for t in ("pack_rows", "unpack_rows", "add_remote", "add_into", "apply_delta", "apply_nk")):
                     per[n] = {"calls": int(row["Calls"]), "ms_per_sweep_all_sweeps": float(row["TotalDurationNs"]) / 1e6 / (args.warmup + args.steps)}
             form["exchange_side_kernels_rank0"] = per
