@@ -462,7 +462,7 @@ def main():
             out["segmented"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm,
                                 "ms_per_step": dsg / args.live_steps * 1e3, "segments": 8,
                                 "note": "MVHDP_SWEEP_SEGMENT_APPLY: deferred sweep in 8 segments, deltas applied and trees rebuilt in "
-                                        "between; deterministic (oracle-checked), about one reference sweep per sweep"}
+                                        "between; deterministic (oracle-checked); what a sweep of it is worth in every view: reference_sweep_equivalent"}
             out["segmented"].update(mode_rooflines("segmented"))
             if eq.get("segmented"):
                 out["value_in_reference_sweeps"]["segmented"] = [v / eq["segmented"][1], v / eq["segmented"][0]]

@@ -224,3 +224,27 @@ def test_a_rank_that_dies_gives_its_peers_an_error_not_a_hang(tmp_path, fake_rcc
         assert procs[r].returncode == 0 and logs[r] is not None, outs[r][-3000:]
         assert logs[r]["events"][0]["ok"] and logs[r]["peer_error"], logs[r]
         assert logs[r]["seconds"] < 60
+
+
+def _bench_line(args, env, timeout=420):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                 # (rank 0 prints ONE JSON line)
+    return json.loads(lines[0])
+
+
+def test_bench_with_two_ranks_takes_the_native_group_and_ends_at_the_single_gpu_counts(fake_rccl):
+    """`python bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), both ranks on cuda:0 with the
+    test-side collective: the N > 1 leg of the bench -- the id broadcast, mvhdp_group_create_rank, the exchange inside the library -- runs
+    for real instead of ending in the fallback, and since deferred sweeps do not depend on the sharding the final counts are those of
+    the one-GPU run of the same command."""
+    common = ["--workload", "C3", "--docs", "24000", "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--live-steps", "0"]
+    env = dict(os.environ)
+    one = _bench_line(["--gpus", "1"] + common, env)
+    env2 = dict(env, MVHDP_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_MS="60000")
+    two = _bench_line(["--gpus", "2", "--rehearse-native"] + common, env2)
+    assert two["n_gpus"] == 2 and two["exchange"]["kind"].startswith("native"), two["exchange"]
+    assert "fallback_reason" not in two["exchange"]
+    assert two["final_nk_fingerprint"] == one["final_nk_fingerprint"]
+    assert two["config"]["tokens"] == one["config"]["tokens"] and two["value"] > 0
