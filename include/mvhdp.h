@@ -359,7 +359,7 @@ int mvhdp_tuner_probe(int32_t num_modalities, const double* tree_branch_share /*
  * path), pipelined in row ranges with the update and F+tree rebuild of the rows that have arrived; with inactive topics the
  * activation key (MVHDP_ACT_KEY) is MIN-reduced so that every replica activates the same topic (UPD:263-270).  Results are
  * bit-identical to one handle holding every entity.  RCCL is opened at run time (a copy already mapped into the process, else the
- * file MVHDP_RCCL_LIB names, else librccl.so.1): a single-GPU host never loads it.  A handle belongs to at most one group; destroy
+ * file MVHDP_RCCL_LIB names, else librccl.so.1; MVHDP_RCCL_LIB_FIRST=1 tries the named file before a mapped copy -- tests): a single-GPU host never loads it.  A handle belongs to at most one group; destroy
  * the group before its members (a group call on a group whose member is gone returns MVHDP_ERR_STATE).  Group calls leave the
  * caller's current HIP device as they found it. */
 typedef struct mvhdp_group_ctx* mvhdp_group;

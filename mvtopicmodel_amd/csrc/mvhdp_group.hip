@@ -48,8 +48,14 @@ Rccl* rccl()
     // host names (MVHDP_RCCL_LIB: mvtopicmodel_amd/_lib.py points it at the torch wheel's copy so that a later `import torch` shares
     // it), then the installation's own.  (The plain soname first would always succeed through this library's RUNPATH and the
     // override would never be looked at.)
+    // MVHDP_RCCL_LIB_FIRST=1 (tests, diagnostics): the named file even when a copy is mapped -- a host process that has imported PyTorch
+    // (bench.py) holds the real RCCL, which refuses two ranks on one device; the rank tests name their stand-in this way.
     std::string errs;
-    if (void* l = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD)) { g_rccl.lib = l; g_rccl.path = "librccl.so.1 (already mapped)"; }
+    const char* named = getenv("MVHDP_RCCL_LIB");
+    const char* first = getenv("MVHDP_RCCL_LIB_FIRST");
+    const bool named_first = named && first && atoi(first) != 0;
+    if (!named_first)
+        if (void* l = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD)) { g_rccl.lib = l; g_rccl.path = "librccl.so.1 (already mapped)"; }
     std::vector<std::string> names;
     if (const char* e = getenv("MVHDP_RCCL_LIB")) names.push_back(e);
     names.push_back("librccl.so.1");

@@ -242,7 +242,7 @@ def test_bench_with_two_ranks_takes_the_native_group_and_ends_at_the_single_gpu_
     common = ["--workload", "C3", "--docs", "24000", "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--live-steps", "0"]
     env = dict(os.environ)
     one = _bench_line(["--gpus", "1"] + common, env)
-    env2 = dict(env, MVHDP_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_MS="60000")
+    env2 = dict(env, MVHDP_RCCL_LIB=fake_rccl, MVHDP_RCCL_LIB_FIRST="1", FAKE_RCCL_TIMEOUT_MS="60000")   # (FIRST: torch has mapped the real RCCL in these processes)
     two = _bench_line(["--gpus", "2", "--rehearse-native"] + common, env2)
     assert two["n_gpus"] == 2 and two["exchange"]["kind"].startswith("native"), two["exchange"]
     assert "fallback_reason" not in two["exchange"]
