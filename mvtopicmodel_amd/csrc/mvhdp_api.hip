@@ -53,6 +53,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_LIVE_OVERLAP")) h->tu.live_overlap = atoi(f);
     if (const char* f = getenv("MVHDP_LIVE_ROWS")) h->tu.live_rows = atoi(f);                     // 0: stored trees rebuilt at every segment border (the round-4 form of a live sweep)
     if (const char* f = getenv("MVHDP_LIVE_ROWS_THETA")) h->tu.live_rows_theta = atof(f);
+    if (const char* f = getenv("MVHDP_COEF_LDS_KB")) h->tu.coef_lds_max_bytes = std::max(0, std::min(64, atoi(f))) * 1024;   // (experiment: the live-rows coefficient table in LDS up to this size)
     if (const char* f = getenv("MVHDP_LIVE_ROWS_SEGMENTS")) h->tu.live_rows_segments = std::max(1, std::min(255, atoi(f)));
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
@@ -138,6 +139,8 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMemset(mm.delta, 0, cbytes));
     CREATE_HIP(hipMalloc(&mm.trees, (size_t)nrows * 2 * K * sizeof(double)));
     CREATE_HIP(hipMalloc(&mm.root, (size_t)nrows * sizeof(double)));
+    CREATE_HIP(hipMalloc(&mm.mass0, (size_t)nrows * sizeof(float)));
+    CREATE_HIP(hipMemset(mm.mass0, 0, (size_t)nrows * sizeof(float)));
     CREATE_HIP(hipMalloc(&mm.coef, (size_t)M * (((K + 7) & ~7) + K + 8) * sizeof(float)));   // coef [M][Kp] (zero-padded rows), then the smoothing running sums [M][K]
     {
         // descent table layout (MvModel::dtab): internal levels nlev, first block dt_f levels, then blocks of three
@@ -183,7 +186,7 @@ static void release_device_resources(mvhdp_ctx* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
     for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); fr(h->d_present[m]); }
-    fr(h->mm.counts); fr(h->mm.delta16); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.coef); fr(h->mm.dtab); fr(h->mm.p);
+    fr(h->mm.counts); fr(h->mm.delta16); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.coef); fr(h->mm.mass0); fr(h->mm.dtab); fr(h->mm.p);
     fr(h->d_alpha); fr(h->d_inactive); fr(h->d_ctl);
     if (h->h_ctl) { hipHostFree(h->h_ctl); h->h_ctl = nullptr; }
     h->d_stats = nullptr; h->d_act_key = nullptr; h->d_doc_counter = nullptr; h->d_ovf_meta = nullptr;
@@ -1102,7 +1105,8 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
             if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&h->ev_rf_done, hipEventDisableTiming);
             if (e1 != hipSuccess) return e1;
         }
-        return mvhdp_launch_live_rows_prepare(mm, from_mirror, p.live16, p.live16 ? h->d_heavy_list : nullptr, p.live16 ? h->d_heavy_ctl : nullptr, MVHDP_HEAVY_CAP, s);
+        return mvhdp_launch_live_rows_prepare(mm, from_mirror, p.live16, p.live16 ? h->d_heavy_list : nullptr, p.live16 ? h->d_heavy_ctl : nullptr, MVHDP_HEAVY_CAP,
+                                              p.live16 ? 512 : 256 /* cells of one register batch of a row: row_sample_live */, s);
     };
     auto rebuild_trees = [&]() {
         step(mvhdp_launch_build_trees(mm, false, p.need_full, s));

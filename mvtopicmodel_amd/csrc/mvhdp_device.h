@@ -48,6 +48,9 @@ struct MvModel {
     // two touched leaves and the root path, without a tree.
     float* coef;                       // [M][Kp] (Kp = K rounded up to a multiple of 8, the pad zero), then [M][K] the running sums over k of
                                        //   coef[m][k] * beta_m (the smoothing part of every leaf of the view)
+    float* mass0;                      // [sumV] live-rows form, rows of TWO register batches (K above 512 cells of the mirror / 256 of the 32-bit table):
+                                       //   sum over the FIRST batch's topics of coef_k * n_wk at the segment start (live_rows_prepare_kernel) -- a target
+                                       //   beyond S_m + mass0 starts in the second batch, so ONE speculative row load serves either half (row_sample_live)
     // Descent table: what FTree.sample (FT:118-132) reads -- tree[1] and the left-child sums tree[2i] of the
     // internal nodes i -- regrouped so that three consecutive levels of one path share a 64-byte block
     // (8 doubles: L[b]; L[2b], L[2b+1]; L[4b..4b+3]; spare, = tree[1] in block 0; L[i] = tree[2i]).
@@ -143,7 +146,7 @@ hipError_t mvhdp_launch_widen_mirror(const MvModel& mm, hipStream_t s);
 // 16-bit mirror (sweep start: from the 32-bit table; from_mirror: a later segment of a live16 sweep, light rows read from the mirror) and
 // MvModel::root = sum_k coef_k (n_wk + beta) -- no tree, no descent table: one pass over the counts; then the stored trees of the HEAVY
 // rows alone (with_heavy_trees: a sweep on the mirror, whose heavy words walk them)
-hipError_t mvhdp_launch_live_rows_prepare(const MvModel& mm, bool from_mirror, bool with_heavy_trees, int32_t* heavy_list, unsigned int* heavy_ctl, int heavy_cap, hipStream_t s);
+hipError_t mvhdp_launch_live_rows_prepare(const MvModel& mm, bool from_mirror, bool with_heavy_trees, int32_t* heavy_list, unsigned int* heavy_ctl, int heavy_cap, int batch_cells, hipStream_t s);
 // the stored trees of the listed heavy rows rebuilt from the live counts again and again until ctl[1] (stop) is set or 2 s have passed
 hipError_t mvhdp_launch_heavy_refresh(const MvModel& mm, const int32_t* heavy_list, const unsigned int* ctl, int heavy_cap, int blocks, hipStream_t s);
 hipError_t mvhdp_launch_set_u32(unsigned int* p, unsigned int v, hipStream_t s);

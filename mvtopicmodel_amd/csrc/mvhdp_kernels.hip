@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64) void live_coef_kernel(MvModel mm)
 }
 
 template <int TB>
-__global__ __launch_bounds__(64) void live_rows_prepare_kernel(MvModel mm, bool from_mirror, int32_t* heavy_list, unsigned int* heavy_n, int heavy_cap)
+__global__ __launch_bounds__(64) void live_rows_prepare_kernel(MvModel mm, bool from_mirror, int32_t* heavy_list, unsigned int* heavy_n, int heavy_cap, int batch_cells)
 {
     const int K = mm.K, lane = threadIdx.x;
     const int64_t nrows = mm.rowbase[mm.M];
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64) void live_rows_prepare_kernel(MvModel mm, bool 
             hv = sum > 65534;
             if (lane == 0) mm.heavy[row] = hv ? MVHDP_ROW_HEAVY : (sum > 32767 ? MVHDP_ROW_BIG : 0);
         }
-        double acc = 0.0;
+        double acc = 0.0, acc0 = 0.0;                                // acc0: the topics of the row's first register batch alone (MvModel::mass0)
         for (int k0 = 0; k0 < K; k0 += WAVE * TB) {
             int cv[TB];
             float fv[TB];
@@ -533,13 +533,15 @@ __global__ __launch_bounds__(64) void live_rows_prepare_kernel(MvModel mm, bool 
                 const int k = k0 + u * WAVE + lane;
                 if (k < K) {
                     if (!from_mirror) c16[k] = hv ? (uint16_t)65535 : (uint16_t)cv[u];
-                    acc += (double)fv[u] * (double)cv[u];
+                    const double t = (double)fv[u] * (double)cv[u];
+                    acc += t;
+                    if (k < batch_cells) acc0 += t;
                 }
             }
         }
 #pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, WAVE);
-        if (lane == 0) mm.root[row] = (double)smp_total + acc;
+        for (int sft = 32; sft >= 1; sft >>= 1) { acc += __shfl_xor(acc, sft, WAVE); acc0 += __shfl_xor(acc0, sft, WAVE); }
+        if (lane == 0) { mm.root[row] = (double)smp_total + acc; mm.mass0[row] = (float)acc0; }
         // the HEAVY rows (a few hundred at most: each holds more than 65534 tokens), listed for the kernel that keeps their stored trees current
         if (lane == 0 && heavy_list && mm.heavy[row] == MVHDP_ROW_HEAVY) {
             const unsigned int i = atomicAdd(heavy_n, 1u);
@@ -606,15 +608,15 @@ hipError_t mvhdp_launch_set_u32(unsigned int* p, unsigned int v, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t mvhdp_launch_live_rows_prepare(const MvModel& mm, bool from_mirror, bool with_heavy_trees, int32_t* heavy_list, unsigned int* heavy_ctl, int heavy_cap, hipStream_t s)
+hipError_t mvhdp_launch_live_rows_prepare(const MvModel& mm, bool from_mirror, bool with_heavy_trees, int32_t* heavy_list, unsigned int* heavy_ctl, int heavy_cap, int batch_cells, hipStream_t s)
 {
     const int64_t nrows = mm.rowbase[mm.M];
     hipLaunchKernelGGL(live_coef_kernel, dim3(mm.M), dim3(64), 0, s, mm);
     if (nrows <= 0) return hipGetLastError();
     const int grid = (int)(nrows < 65536 ? nrows : 65536);
     if (heavy_ctl) { hipError_t e = hipMemsetAsync(heavy_ctl, 0, 2 * sizeof(unsigned int), s); if (e != hipSuccess) return e; }     // rows listed, stop
-    if (mm.K > 512) hipLaunchKernelGGL(live_rows_prepare_kernel<8>, dim3(grid), dim3(64), 0, s, mm, from_mirror, heavy_list, heavy_ctl, heavy_cap);
-    else hipLaunchKernelGGL(live_rows_prepare_kernel<4>, dim3(grid), dim3(64), 0, s, mm, from_mirror, heavy_list, heavy_ctl, heavy_cap);
+    if (mm.K > 512) hipLaunchKernelGGL(live_rows_prepare_kernel<8>, dim3(grid), dim3(64), 0, s, mm, from_mirror, heavy_list, heavy_ctl, heavy_cap, batch_cells);
+    else hipLaunchKernelGGL(live_rows_prepare_kernel<4>, dim3(grid), dim3(64), 0, s, mm, from_mirror, heavy_list, heavy_ctl, heavy_cap, batch_cells);
     // the HEAVY words (more than 65534 tokens: a few hundred rows at most) keep a stored tree, built from the 32-bit table where their
     // counts live; the flags are those the pass above has just written (or kept)
     if (with_heavy_trees)

@@ -143,6 +143,7 @@ struct PlanTuning {
     int live_rows = -1;                         // live sweeps sample their tree branch from the live count rows (no stored trees): -1 / 1 wherever every kernel is
                                                 //   register-resident (default), 0: stored trees rebuilt at every segment border (the round-4 form)
     int live_rows_segments = 1;                 // segments of such a sweep when the flags name none (a border refreshes tokensPerTopic and the roots: one pass over the counts)
+    int coef_lds_max_bytes = 12 * 1024;         // live-rows form: the coefficient table [M][Kp] sits in every block's LDS up to this size (C4: 4.8 KB; C5's 20 KB stay in global memory by default)
     double live_rows_theta = 0.3;               // steered views: a token's row is loaded ahead of its turn iff its u1 reaches this (a token below it that reaches the tree
                                                 //   branch after all loads it then)
 };
@@ -361,7 +362,7 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     // the slot state: those read it from global memory)
     {
         const size_t coef_bytes = (size_t)M * ((K + 7) & ~7) * sizeof(float);
-        p.coef_lds = want_rows && coef_bytes <= 12 * 1024;
+        p.coef_lds = want_rows && coef_bytes <= (size_t)tu.coef_lds_max_bytes;
         if (p.coef_lds) p.block_shared_bytes += (uint32_t)((coef_bytes + 16 + 15) & ~(size_t)15);
     }
 

@@ -197,9 +197,15 @@ __device__ __forceinline__ int row_batch_pick(rowq_t q, coefq_t c0, coefq_t c1, 
 }
 
 // in_lds: the view's coefficients (row padded to a multiple of 8 with zeros) come from LDS (cf_lds), else from global memory (cf_g)
-template <bool CELL16>
+// A row of TWO batches (K above 512 cells of the mirror, 256 of the 32-bit table: C5) would need its second batch on demand -- a load behind
+// the next token's gather, 6400 cycles per tree-branch token at C5 --, so the FIRST batch's mass of the segment start is stored with the
+// root (MvModel::mass0): a target at or beyond it starts in the second batch with that mass as its base (`bq` = the batch chosen that way,
+// decided at the chunk head; q0 holds THAT batch when the token's row was loaded ahead).  Like the root itself the stored mass is not
+// followed during the segment.  When the chosen batch does not hold the target after all (the live masses have moved), the batches are
+// scanned in order with their live masses, as rows of any other length are.
+template <bool CELL16, bool TWOB>
 __device__ __forceinline__ int row_sample_live(rowq_t q0, bool have_q0, bool in_lds, const __attribute__((address_space(3))) float* cf_lds, const float* __restrict__ cf_g, const float* __restrict__ smp, float S,
-                                                gptr_t rowp, int K, float u2f, float rootf, int lane, unsigned long long* t_after_wait)
+                                                gptr_t rowp, int K, float u2f, float rootf, int bq, float mass0, int lane, unsigned long long* t_after_wait)
 {
     constexpr int CPL = CELL16 ? 8 : 4;
     (void)t_after_wait;
@@ -209,11 +215,13 @@ __device__ __forceinline__ int row_sample_live(rowq_t q0, bool have_q0, bool in_
     float base = 0.0f;
     int lastb = -1;
     const int nb = (K + WAVE * CPL - 1) / (WAVE * CPL);
+    if (!TWOB || nb != 2) bq = 0;                                          // (TWOB: the kernel flavour compiled for rows of two batches; the others scan in order)
+    const float bbase = bq ? mass0 : 0.0f;
     if (have_q0 && in_lds) {
         // The common path, kept apart from the general loop below: row in registers since the top of the token's turn, coefficients from
         // LDS -- no vector-memory operation is issued here, so the wait in front of the arithmetic is for the row alone (vmcnt counts in
         // order: a load issued on ANY path through here would make the compiler wait for everything, the next token's gather included).
-        int kl = lane * CPL;
+        int kl = (bq * WAVE + lane) * CPL;
         asm volatile("" : "+v"(kl));                                       // (formed here: hoisted out of the token loop it is spilled, and its reload is a vector-memory operation)
         coefq_t c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (kl < K) {                                                      // (a lane beyond the row has no cells: the view's table ends at Kp, the last view's at the end of the block's)
@@ -224,16 +232,32 @@ __device__ __forceinline__ int row_sample_live(rowq_t q0, bool have_q0, bool in_
 #ifdef MVHDP_TIMING
         { unsigned int probe = q0.x; asm volatile("v_mov_b32 %0, %0" : "+v"(probe)); *t_after_wait = __builtin_amdgcn_s_memtime(); }   // (the row has arrived)
 #endif
-        const int r = row_batch_pick<CELL16>(q0, c0, c1, 0, 0.0f, target, false, tot, any);
+        const int r = row_batch_pick<CELL16>(q0, c0, c1, bq * WAVE * CPL, bbase, target, false, tot, any);
         if (r >= 0) return r;
         if (nb == 1) {
             if (any) return row_batch_pick<CELL16>(q0, c0, c1, 0, 0.0f, 0.0f, true, tot, any);   // the target lies beyond the row's mass: the last cell that has any
             return smoothing_sample_live(smp, K, u2f * S, lane);          // (a word without a counted token: a first visit of an unassigned one)
         }
+    } else if (TWOB && nb == 2) {
+        // the same first try for a token whose row was not loaded ahead (or whose coefficients are not in LDS): the chosen batch, its stored base
+        const rowq_t q = have_q0 ? q0 : row_batch_load<CELL16>(rowp, K, bq, lane);
+        const int kl = (bq * WAVE + lane) * CPL;
+        coefq_t c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (kl >= K) { }
+        else if (in_lds) {
+            c0 = *(const __attribute__((address_space(3))) coefq_t*)(cf_lds + kl);
+            if (CELL16) c1 = *(const __attribute__((address_space(3))) coefq_t*)(cf_lds + kl + 4);
+        } else {
+            c0 = *(const __attribute__((address_space(1))) coefq_t*)(cf_g + kl);
+            if (CELL16) c1 = *(const __attribute__((address_space(1))) coefq_t*)(cf_g + kl + 4);
+        }
+        float tot; bool any;
+        const int r = row_batch_pick<CELL16>(q, c0, c1, bq * WAVE * CPL, bbase, target, false, tot, any);
+        if (r >= 0) return r;
     }
     for (int pass = 0; pass < 2; pass++) {                                  // (pass 1: the target lies beyond the row's mass -- the last cell that has any)
         for (int b = (pass ? lastb : 0); b < (pass ? lastb + 1 : nb); b++) {
-            const rowq_t q = (b == 0 && have_q0) ? q0 : row_batch_load<CELL16>(rowp, K, b, lane);
+            const rowq_t q = (b == bq && have_q0) ? q0 : row_batch_load<CELL16>(rowp, K, b, lane);
             const int kl = (b * WAVE + lane) * CPL;                         // (the view's table is padded to Kp = K rounded up to 8: the lane that holds cell K-1 reads zeros behind it)
             coefq_t c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
             if (kl >= K) { }                                                // (a lane beyond the row has no cells)
@@ -260,7 +284,9 @@ __device__ __forceinline__ int row_sample_live(rowq_t q0, bool have_q0, bool in_
 // spills cost -- C5's 2-round kernel 16.9 ms at 6 waves, 18.4 at 7; C4's (K = 400) gains 2 % at 7.
 // LIVEROWS (walk flavour only): the live-rows form of a live sweep (SweepLaunch::live_rows) -- a flavour of its own so that the kernels of
 // every other mode stay what they were, register for register.
-template <int RMAX, bool DEBUG, bool WALK, bool NARROW, bool ROOMY = false, bool LIVEROWS = false>
+// LIVEROWS = 2: the same with the two-batch shortcut of row_sample_live compiled in (rows of the mirror longer than one register batch,
+// K in 513 .. 1024: C5) -- a flavour of its own because its few extra scalars cost the K <= 512 kernels 5 % through their spills (C4: 24.1 -> 25.4 ms)
+template <int RMAX, bool DEBUG, bool WALK, bool NARROW, bool ROOMY = false, int LIVEROWS = 0>
 __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB4 : (RMAX == 2 ? (ROOMY ? MVHDP_LB2_ROOMY : (LIVEROWS ? MVHDP_LB_ROWS : MVHDP_LB2)) : (RMAX == 1 ? (LIVEROWS ? MVHDP_LB_ROWS : WALK ? MVHDP_LB1W : MVHDP_LB1) : MVHDP_LB16))))) void sweep_fast_kernel(MvModel mm, SweepLaunch sl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -648,6 +674,17 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 const float root32_l = (float)root_l;
                 // live-rows form: the tree branch's uniform is kept (the walk on demand of the other flavours draws it again: ten Philox rounds per tree-branch token)
                 const float u2f_l = LIVEROWS ? (float)u2_l : 0.0f;
+                // live-rows form, rows of two register batches: the batch a tree-branch token of this lane would start in (row_sample_live: the
+                // first batch's stored mass against the token's target) -- known here, so that the token's turn loads THAT batch ahead
+                unsigned long long bselm = 0ull;
+                if (LIVEROWS == 2) {
+                    constexpr int BCELLS = WAVE * (NARROW ? 8 : 4);
+                    if (K > BCELLS && K <= 2 * BCELLS) {
+                        float mass0_l = 0.0f;                                // (needed again by the token that does take the branch: read then, through the scalar cache)
+                        if (tvalid && w_l >= 0 && !heavy_l) mass0_l = mm.mass0[row0 + W_ROW(w_l)];
+                        bselm = __ballot(tvalid && w_l >= 0 && !heavy_l && (u2f_l * root32_l) - smS >= mass0_l);
+                    }
+                }
                 MVHDP_TMAIN(th, te, tt);
                 // software pipeline: the n_wk values of the listed topics are gathered NB tokens ahead, into NB
                 // register buffers used in turn (the token loop is unrolled NB times so that no buffer is ever
@@ -833,13 +870,17 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
 
 // debug launches always take the WALK flavour (one instantiation fewer per variant; a threshold of 0 walks every token)
 static bool roomy_build(int rmax, int K) { return rmax == 2 && K >= 512; }
+// live-rows flavour with the two-batch shortcut: a row of the 16-bit mirror in exactly two register batches of 512 cells (the roomy 2-round
+// build, which exists for K >= 512 only, is always that flavour: the shortcut checks the batch count at run time as well)
+static bool two_batch_rows(int K) { return K > 512 && K <= 1024; }
 
 template <int RMAX>
 static const void* fast_kernel_ptr(bool debug, bool walk, bool narrow, int K = 0, bool live_rows = false)
 {
     if (live_rows && !debug) {
-        if constexpr (RMAX == 2) { if (narrow && roomy_build(RMAX, K)) return (const void*)sweep_fast_kernel<2, false, true, true, true, true>; }
-        return narrow ? (const void*)sweep_fast_kernel<RMAX, false, true, true, false, true> : (const void*)sweep_fast_kernel<RMAX, false, true, false, false, true>;
+        if constexpr (RMAX == 2) { if (narrow && roomy_build(RMAX, K)) return (const void*)sweep_fast_kernel<2, false, true, true, true, 2>; }
+        if (narrow && two_batch_rows(K)) return (const void*)sweep_fast_kernel<RMAX, false, true, true, false, 2>;
+        return narrow ? (const void*)sweep_fast_kernel<RMAX, false, true, true, false, 1> : (const void*)sweep_fast_kernel<RMAX, false, true, false, false, 1>;
     }
     if (narrow && walk && !debug) {
         if constexpr (RMAX == 2) { if (roomy_build(RMAX, K)) return (const void*)sweep_fast_kernel<2, false, true, true, true>; }
@@ -862,9 +903,10 @@ static hipError_t launch_fast(const MvModel& mm, const SweepLaunch& sl, int grid
     }
     if (debug)        hipLaunchKernelGGL((sweep_fast_kernel<RMAX, true, true, false>), dim3(grid_blocks), block, lds, s, mm, sl);
     else if (rows) {
-        if (narrow && roomy_build(RMAX, mm.K)) { if constexpr (RMAX == 2) hipLaunchKernelGGL((sweep_fast_kernel<2, false, true, true, true, true>), dim3(grid_blocks), block, lds, s, mm, sl); }
-        else if (narrow) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, true, false, true>), dim3(grid_blocks), block, lds, s, mm, sl);
-        else             hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, false, false, true>), dim3(grid_blocks), block, lds, s, mm, sl);
+        if (narrow && roomy_build(RMAX, mm.K)) { if constexpr (RMAX == 2) hipLaunchKernelGGL((sweep_fast_kernel<2, false, true, true, true, 2>), dim3(grid_blocks), block, lds, s, mm, sl); }
+        else if (narrow && two_batch_rows(mm.K)) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, true, false, 2>), dim3(grid_blocks), block, lds, s, mm, sl);
+        else if (narrow) hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, true, false, 1>), dim3(grid_blocks), block, lds, s, mm, sl);
+        else             hipLaunchKernelGGL((sweep_fast_kernel<RMAX, false, true, false, false, 1>), dim3(grid_blocks), block, lds, s, mm, sl);
     }
     else if (narrow && roomy_build(RMAX, mm.K)) {
         // (the plan sized the grid for the 72-register build: the seventh block of a CU waits for a free slot and finds the queue empty)

@@ -926,7 +926,10 @@ static int row_batch_pick(const int32_t* row, const float* cf, int K, int cpl, i
     return b * 64 * cpl + hl * cpl + (pp < ns ? 2 * pp : 2 * (pp - ns) + 1);
 }
 
-int orc_row_sample_live(const int32_t* row, const float* cf, const float* smp, int K, int cell16, float u2f, float rootf)
+/* mass0: the first batch's mass at the segment start (MvModel::mass0), used by rows of the 16-bit mirror in exactly two batches: a target at or beyond it
+   is first looked for in the second batch with that mass as its base; only when the chosen batch does not hold it are the batches scanned
+   in order with their live masses */
+int orc_row_sample_live(const int32_t* row, const float* cf, const float* smp, int K, int cell16, float u2f, float rootf, float mass0)
 {
     const int cpl = cell16 ? 8 : 4;
     const float S = smp[K - 1];
@@ -936,6 +939,12 @@ int orc_row_sample_live(const int32_t* row, const float* cf, const float* smp, i
     float base = 0.0f;
     int lastb = -1;
     const int nb = (K + 64 * cpl - 1) / (64 * cpl);
+    if (cell16 && nb == 2) {                              /* (the 16-bit mirror alone: the kernel flavours of the 32-bit table scan in order) */
+        const int bq = target >= mass0;
+        float tot; int any;
+        const int r = row_batch_pick(row, cf, K, cpl, bq, bq ? mass0 : 0.0f, target, 0, &tot, &any);
+        if (r >= 0) return r;
+    }
     for (int b = 0; b < nb; b++) {
         float tot; int any;
         const int r = row_batch_pick(row, cf, K, cpl, b, base, target, 0, &tot, &any);
@@ -951,6 +960,7 @@ typedef struct {
     float* coef;      /* [M][K] */
     float* smp;       /* [M][K] */
     double* root;     /* [sumV] */
+    float* mass0;     /* [sumV] the first row batch's mass at the segment start */
     uint8_t* heavy;   /* [sumV] more than 65534 tokens at the sweep start */
     int32_t* nk_seg;  /* [M][K] tokensPerTopic of the segment start */
     int32_t* nk_delta;
@@ -984,6 +994,13 @@ static void live_prepare(orc_model* o, live_state* ls, int rows, int cell16, int
             for (int l = 0; l < 64; l++) { acc[l] = 0.0; for (int k = l; k < K; k += 64) acc[l] += (double)cf[k] * (double)o->nwk[(size_t)r * K + k]; }
             for (int sft = 32; sft >= 1; sft >>= 1) { double t[64]; for (int l = 0; l < 64; l++) t[l] = acc[l] + acc[l ^ sft]; memcpy(acc, t, sizeof t); }
             ls->root[r] = (double)smp[K - 1] + acc[0];
+            {   /* the same sum over the topics of the first register batch alone */
+                const int b0 = cell16 ? 512 : 256;
+                double a0[64];
+                for (int l = 0; l < 64; l++) { a0[l] = 0.0; for (int k = l; k < K && k < b0; k += 64) a0[l] += (double)cf[k] * (double)o->nwk[(size_t)r * K + k]; }
+                for (int sft = 32; sft >= 1; sft >>= 1) { double t[64]; for (int l = 0; l < 64; l++) t[l] = a0[l] + a0[l ^ sft]; memcpy(a0, t, sizeof t); }
+                ls->mass0[r] = (float)a0[0];
+            }
         }
     }
 }
@@ -1072,7 +1089,7 @@ static int sample_one_doc_live(orc_model* o, live_state* ls, int rows, int cell1
                     } else {
                         st->word_ftree_mass_cnt++;
                         if (!rows || (cell16 && ls->heavy[r])) newTopic = orc_ftree_sample(o->trees + r * 2 * K, K, u2);
-                        else newTopic = orc_row_sample_live(cnt, ls->coef + (size_t)m * K, ls->smp + (size_t)m * K, K, cell16, (float)u2, (float)root);
+                        else newTopic = orc_row_sample_live(cnt, ls->coef + (size_t)m * K, ls->smp + (size_t)m * K, K, cell16, (float)u2, (float)root, ls->mass0[r]);
                         if (newTopic == -2) return 1;
                     }
                 }
@@ -1114,7 +1131,7 @@ int orc_sweep_live_seq(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t 
     if (!p) { p_own = (double*)malloc((size_t)(o->D > 0 ? o->D : 1) * M * M * sizeof(double)); orc_draw_p_philox(o, seed, sweep_idx, doc_id_base, p_own); p = p_own; }
     live_state ls;
     ls.coef = (float*)calloc((size_t)M * K, sizeof(float)); ls.smp = (float*)calloc((size_t)M * K, sizeof(float));
-    ls.root = (double*)calloc((size_t)(nrows > 0 ? nrows : 1), sizeof(double)); ls.heavy = (uint8_t*)calloc((size_t)(nrows > 0 ? nrows : 1), 1);
+    ls.root = (double*)calloc((size_t)(nrows > 0 ? nrows : 1), sizeof(double)); ls.mass0 = (float*)calloc((size_t)(nrows > 0 ? nrows : 1), sizeof(float)); ls.heavy = (uint8_t*)calloc((size_t)(nrows > 0 ? nrows : 1), 1);
     ls.nk_seg = (int32_t*)calloc((size_t)M * K, sizeof(int32_t)); ls.nk_delta = (int32_t*)calloc((size_t)M * K, sizeof(int32_t));
     int32_t* localTopicCounts = (int32_t*)malloc((size_t)M * K * sizeof(int32_t));
     int32_t* localTopicIndex = (int32_t*)malloc((size_t)(K + 1) * sizeof(int32_t));
@@ -1141,7 +1158,7 @@ int orc_sweep_live_seq(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t 
             if (local.activated_topic < 0) { local.activated_topic = t; local.activated_modality = mv; local.activation_key = act_key; }
         }
     }
-    free(ls.coef); free(ls.smp); free(ls.root); free(ls.heavy); free(ls.nk_seg); free(ls.nk_delta);
+    free(ls.coef); free(ls.smp); free(ls.root); free(ls.mass0); free(ls.heavy); free(ls.nk_seg); free(ls.nk_delta);
     free(localTopicCounts); free(localTopicIndex); free(topicDocWordMasses); free(totalMassOtherModalities); free(p_own);
     if (st) *st = local;
     return 0;

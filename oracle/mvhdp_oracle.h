@@ -141,7 +141,7 @@ int orc_sweep(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_ba
  * order: entities in the product's longest-first order; rows / cell16: which form of the tree branch. */
 int orc_sweep_live_seq(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base, const double* p_in,
                        const int64_t* order, int64_t n_order, int nseg, int rows, int cell16, orc_stats* st);
-int orc_row_sample_live(const int32_t* row, const float* cf, const float* smp, int K, int cell16, float u2f, float rootf);
+int orc_row_sample_live(const int32_t* row, const float* cf, const float* smp, int K, int cell16, float u2f, float rootf, float mass0);
 int orc_sweep_list(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t doc_id_base,
                    const double* p, uint32_t flags, orc_stats* st, int32_t* delta_nwk, int32_t* delta_nk,
                    const int64_t* doc_list, int64_t n_list);
