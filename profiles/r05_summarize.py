@@ -53,8 +53,11 @@ def one(W, tokens, warm, steps, views):
 def merge():
     import glob
     out = {"workloads": {}}
-    for f in sorted(glob.glob(f"{ROOT}/gpurun_out/r05_c?_counters.json")):
+    # the committed summaries first, then whatever this run profiled anew (a run that profiles one workload must not drop the others)
+    for f in sorted(glob.glob(f"{ROOT}/profiles/r05_c?_counters.json")) + sorted(glob.glob(f"{ROOT}/gpurun_out/r05_c?_counters.json")):
         j = json.load(open(f))
+        if not any(isinstance(v, dict) and v.get("fabric_read_requests_per_token") for v in j.values()):
+            continue                                  # (a summary of passes that did not run)
         out["workloads"][j["workload"]] = {k: v for k, v in j.items() if isinstance(v, dict)}
     # the bare-gather ceilings of the access patterns: measured in round 4 on the same chip (tools/microbench/row_gather_ceiling.hip)
     try:
