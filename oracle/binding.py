@@ -93,6 +93,8 @@ def lib():
     L.orc_sweep_list.restype = C.c_int
     L.orc_sweep_live_seq.argtypes = [vp, u32, u64, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, P(Stats)]
     L.orc_sweep_live_seq.restype = C.c_int
+    L.orc_row_sample_live.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.orc_row_sample_live.restype = C.c_int
     L.orc_apply_delta.argtypes = [vp, vp, vp, i32, i32]
     L.orc_log_gamma_stirling.argtypes = [dbl]; L.orc_log_gamma_stirling.restype = dbl
     L.orc_mallet_digamma.argtypes = [dbl]; L.orc_mallet_digamma.restype = dbl

@@ -373,3 +373,48 @@ def test_numpy_java_random_init_equals_the_host_mirror_and_the_jdk_known_answers
     off = [np.array([0, 200000], dtype=np.int64)]
     big = (1 << 30) + 12345
     assert np.array_equal(ref(big, off, 5)[0], java_init.init_assignments(big, off, 5)[0])
+
+
+@pytest.mark.parametrize("K,cell16", [(200, 1), (400, 1), (400, 0), (600, 1), (1000, 1), (1000, 0)])
+def test_kat9_the_live_rows_tree_branch_samples_the_leaves_of_the_reference(oracle_lib, K, cell16):
+    """The tree branch of a live sweep in its live-rows form (orc_row_sample_live = row_sample_live of the HIP kernels, which the GPU tests
+    hold equal to it integer for integer) must sample topic k with the probability FTree.sample gives it on a tree of the same leaves
+    (FT:111-136 over PTM:2670-2678): leaf_k / sum_j leaf_j with leaf_k = coef_k * (n_wk + beta).  Derived here without the function under
+    test: the leaves in fp64 from the definition; the function is swept over a fine grid of u2 and the measure of the u2 it maps to each
+    topic compared with the leaf's share.  K = 600 and 1000 on the mirror are rows of two register batches (the stored first-batch mass
+    decides where the search starts); K = 1000 on the 32-bit table is four batches scanned in order."""
+    L = oracle_lib
+    rng = np.random.default_rng(1000 + K + cell16)
+    beta = 0.01
+    n = np.zeros(K, dtype=np.int32)
+    nz = rng.choice(K, size=max(8, K // 9), replace=False)                 # a sparse row, like a word's
+    n[nz] = rng.integers(1, 400, size=len(nz))
+    n[nz[0]] = 5000                                                         # and one dominant topic
+    coef = (1.0 / (rng.integers(50, 50000, size=K) + 50.0)).astype(np.float32)
+    coef[rng.choice(K, size=K // 10, replace=False)] = 0.0                  # inactive topics: no leaf
+    smp = np.cumsum((coef * np.float32(beta)).astype(np.float32), dtype=np.float32).astype(np.float32)
+    # (the running sums the library keeps are a sequential fp32 sum: restate that exactly)
+    run = np.float32(0.0)
+    for k in range(K):
+        run = np.float32(run + np.float32(coef[k] * np.float32(beta)))
+        smp[k] = run
+    S = float(smp[K - 1])
+    leaves = coef.astype(np.float64) * (n.astype(np.float64) + np.float64(np.float32(beta)))
+    root = float(S + np.dot(coef.astype(np.float64), n.astype(np.float64)))
+    b0 = 512 if cell16 else 256
+    mass0 = np.float32(np.dot(coef[:b0].astype(np.float64), n[:b0].astype(np.float64)))
+    G = 400000
+    hits = np.zeros(K, dtype=np.int64)
+    rowp, cfp, smpp = n.ctypes.data, coef.ctypes.data, smp.ctypes.data
+    for i in range(G):
+        u2 = (i + 0.5) / G
+        k = L.orc_row_sample_live(rowp, cfp, smpp, K, cell16, C.c_float(u2), C.c_float(root), C.c_float(float(mass0)))
+        assert 0 <= k < K
+        hits[k] += 1
+    got = hits / G
+    want = leaves / leaves.sum()
+    # fp32 arithmetic (2^-24 relative per operation over at most K terms), the grid (1 / G per interval end) and the order of the
+    # cells inside a lane (even cells first) move interval ends, not masses: 2e-5 absolute per topic is an order above all of them
+    assert np.abs(got - want).max() < 2e-5, (np.abs(got - want).argmax(), np.abs(got - want).max())
+    assert hits[coef == 0].sum() == 0                                       # an inactive topic is never drawn
+    assert abs(leaves.sum() - root) < 1e-6 * root
