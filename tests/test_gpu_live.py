@@ -337,3 +337,27 @@ def test_one_wave_live_sweep_with_unassigned_tokens_and_an_inactive_topic_equals
         assert np.array_equal(a, o.get_alpha()) and np.array_equal(ina, o.get_inactive())
     assert acts >= 1
     s.close()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_one_wave_live_sweep_fuzz_against_the_sequential_oracle(case):
+    """Random shapes of the live-rows form against the sequential oracle: K from a handful to beyond 1024 (one, two -- the stored first-batch
+    mass -- and three or more register batches of a row, on the mirror and on the 32-bit table), one to three views, every register variant
+    that holds the corpus' longest entity, one to four segments."""
+    rng = np.random.default_rng(7000 + case)
+    K = int(rng.choice([8, 33, 64, 100, 255, 256, 257, 400, 512, 513, 600, 777, 1000, 1024, 1025, 1100]))
+    M = int(rng.integers(1, 4))
+    V = [int(rng.integers(30, 900))] + [int(rng.integers(10, 90)) for _ in range(M - 1)]
+    lam = [int(rng.integers(20, 150))] + [int(rng.integers(2, 20)) for _ in range(M - 1)]
+    D = int(rng.integers(30, 90))
+    c = small_corpus(K, V, D, lam, 7100 + case)
+    longest = int(max(sum(int(c.doc_off[m][d + 1] - c.doc_off[m][d]) for m in range(c.M)) for d in range(c.D)))
+    force = int(rng.choice([r for r in (1, 2, 4, 8, 16) if 64 * r >= min(longest, K)]))
+    live16 = int(rng.integers(0, 2))
+    nseg = int(rng.choice([1, 2, 4]))
+    hy = Hyper.defaults(K, V)
+    o = make_oracle(c, hy)
+    s = make_native(c, hy, [o.get_assignments(m) for m in range(c.M)])
+    s.set_tuning(live16=live16, single_wave=1, live_rows=1, force_primary=force)
+    _one_wave_against_the_oracle(o, s, _longest_first(c.doc_off), c.M, 2, nseg, 1, live16, 100 + case)
+    s.close()
