@@ -75,12 +75,12 @@ def physical_rooflines(workload, tokens_per_launch, avg_kernel_s, mode="deferred
     return physical, issue
 
 
-def sweep_equivalents(K):
+def sweep_equivalents(K, workload=None):
     """GPU sweeps per sweep of the CPU restatement of the reference, PER VIEW, by update mode: how many sweeps of the mode reach the
     LL/token the reference reaches after n sweeps (n = 10 .. 100), against two chains of the (nondeterministic) reference and every seed
     of the mode -- tools/ll_curves.py equivalents, committed as profiles/r05_sweep_equivalents_*.json.  `worst_view` is the range of the
     view that needs most; `cpu_band` is the reference against itself (one chain's sweeps to reach the other's LL)."""
-    name = "r05_sweep_equivalents_c4_200k.json" if K >= 256 else "r05_sweep_equivalents_c3.json"
+    name = "r05_sweep_equivalents_c5_100k.json" if workload == "C5" else "r05_sweep_equivalents_c4_200k.json" if K >= 256 else "r05_sweep_equivalents_c3.json"
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception as e:
@@ -399,9 +399,9 @@ def main():
         "step_calls": "one mvhdp_sweep_many call for the K steps" if (args.batch and world == 1) else "one call per step",
         # What a sweep of each update mode is worth IN EVERY VIEW, in sweeps of the CPU restatement of the reference's thread topology: GPU
         # sweeps needed to reach the log-likelihood the reference reaches in one, from the curves of the configuration that is timed -- the
-        # 200k-entity slice of C4 (K = 400: where live sweeps run on the 16-bit mirror) for K >= 256, C3 (K = 200) below; two CPU chains,
-        # two seeds per live form (profiles/r05_ll_curves.md).  Tokens/s of different modes are comparable only after dividing by it.
-        "reference_sweep_equivalent": sweep_equivalents(K),
+        # 200k-entity slice of C4 (K = 400: where live sweeps run on the 16-bit mirror) for K >= 256, C3 (K = 200) below, the 100k-entity slice
+        # of C5 for C5 (a truncated HDP: profiles/r05_ll_curves_c5.md); two CPU chains, two seeds per live form (profiles/r05_ll_curves.md).  Tokens/s of different modes are comparable only after dividing by it.
+        "reference_sweep_equivalent": sweep_equivalents(K, args.workload),
     }
     # order-independent fingerprint of the final global counts: must not depend on the number of shards
     nk_fp = [int(np.asarray(s.get_counts(m)[1], dtype=np.int64).dot(np.arange(1, K + 1, dtype=np.int64))) for m in range(M)]

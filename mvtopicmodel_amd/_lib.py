@@ -83,7 +83,7 @@ class PlanInputC(C.Structure):
                 ("max_entity_tokens", C.c_int64), ("entities_longer_than", C.c_int64 * 5),
                 ("tokens_by_list_rounds", C.c_uint64 * 17), ("entities_by_class", C.c_uint64 * 8),
                 ("flags", C.c_uint32), ("debug", C.c_int32), ("batch", C.c_int32), ("trees_current", C.c_int32),
-                ("num_cus", C.c_int32), ("kernel_registers", (C.c_int32 * 3) * 6)]
+                ("num_cus", C.c_int32), ("kernel_registers", (C.c_int32 * 3) * 6), ("inactive_topics", C.c_int32)]
 
 
 class PlanOutputC(C.Structure):

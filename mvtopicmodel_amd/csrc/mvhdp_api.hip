@@ -55,6 +55,7 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_LIVE_ROWS_THETA")) h->tu.live_rows_theta = atof(f);
     if (const char* f = getenv("MVHDP_COEF_LDS_KB")) h->tu.coef_lds_max_bytes = std::max(0, std::min(64, atoi(f))) * 1024;   // (experiment: the live-rows coefficient table in LDS up to this size)
     if (const char* f = getenv("MVHDP_LIVE_ROWS_SEGMENTS")) h->tu.live_rows_segments = std::max(1, std::min(255, atoi(f)));
+    if (const char* f = getenv("MVHDP_LIVE_ROWS_BIRTH_SEGMENTS")) h->tu.live_rows_birth_segments = std::max(1, std::min(255, atoi(f)));   // ... of a sweep that starts with inactive topics
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_LIVE_TREE_EVERY")) h->live_tree_every = std::max(1, atoi(f));   // (diagnostics: a live sweep rebuilds its trees at every n-th segment border only)
@@ -1546,7 +1547,7 @@ extern "C" int mvhdp_plan_probe(const mvhdp_plan_input* pi, const mvhdp_tuning* 
     for (int b = 0; b < MVHDP_HIST_BINS; b++) in.tok_hist[b] = pi->tokens_by_list_rounds[b];
     for (int b = 0; b < MVHDP_ENT_BINS; b++) in.ent_hist[b] = pi->entities_by_class[b];
     in.flags = pi->flags; in.debug = pi->debug != 0; in.batch = pi->batch != 0; in.trees_current = pi->trees_current != 0;
-    in.first_inactive = -1;
+    in.first_inactive = pi->inactive_topics ? 0 : -1;
     in.num_cus = pi->num_cus > 0 ? pi->num_cus : 256;
     for (int c = 0; c < MVHDP_N_CLASSES; c++) for (int f = 0; f < 3; f++) in.regs.regs[c][f] = pi->kernel_registers[c][f];
     PlanTuning tu;

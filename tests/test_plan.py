@@ -12,7 +12,7 @@ SWEEP_REUSE_TREES, SWEEP_NO_APPLY, SWEEP_FROZEN, SWEEP_LIVE, SWEEP_SEGMENT_APPLY
 
 
 def probe(K=400, M=3, D=1_000_000, mdt=250, longer=(1_000_000, 900_000, 40, 0, 0), tok=None, ent=None, flags=0, tuning=None,
-          batch=0, debug=0, trees_current=0):
+          batch=0, debug=0, trees_current=0, inactive=0):
     L = _lib.load_library()
     pi = _lib.PlanInputC()
     pi.num_topics, pi.num_modalities, pi.num_entities, pi.max_entity_tokens = K, M, D, mdt
@@ -23,6 +23,7 @@ def probe(K=400, M=3, D=1_000_000, mdt=250, longer=(1_000_000, 900_000, 40, 0, 0
     for i, v in enumerate(ent or []):
         pi.entities_by_class[i] = v
     pi.flags, pi.debug, pi.batch, pi.trees_current, pi.num_cus = flags, debug, batch, trees_current, 256
+    pi.inactive_topics = inactive
     for c in range(6):
         for f in range(3):
             pi.kernel_registers[c][f] = REGS[c][f]
@@ -152,6 +153,11 @@ def test_forced_variants_flags_and_errors():
     assert probe(flags=SWEEP_LIVE | (3 << 16)).segments == 3 and probe(flags=SWEEP_LIVE | (3 << 16)).live_rows == 1
     assert probe(flags=SWEEP_LIVE, debug=1).live_rows == 0 and probe(flags=SWEEP_LIVE | SWEEP_REUSE_TREES, trees_current=1).live_rows == 0
     assert probe(K=2048, M=2, D=1000, mdt=5000, longer=(1000, 900, 800, 500, 100), flags=SWEEP_LIVE).live_rows == 0      # (the generic kernel can be reached)
+    # ... and while a topic is still inactive (a truncated HDP) sixteen: a live sweep gives birth to one topic per segment border where the
+    # reference's updater does it delta by delta (UPD:263-270); not for a document shard, whose group activates once per exchange
+    assert probe(flags=SWEEP_LIVE, inactive=1).segments == 16 and probe(flags=SWEEP_LIVE, inactive=1).live_rows == 1
+    assert probe(flags=SWEEP_LIVE | (2 << 16), inactive=1).segments == 2 and probe(flags=SWEEP_LIVE | SWEEP_NO_APPLY, inactive=1).segments == 1
+    assert probe(flags=SWEEP_LIVE, inactive=1, tuning=dict(live_rows=0)).segments == 4
     assert probe(D=3, longer=(3, 3, 0, 0, 0), flags=SWEEP_LIVE | (200 << 16)).segments == 3        # never more segments than entities
     assert probe(flags=SWEEP_SEGMENT_APPLY | SWEEP_NO_APPLY).status == -1
     assert probe(flags=SWEEP_LIVE | SWEEP_FROZEN).status == -1
