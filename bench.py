@@ -80,7 +80,7 @@ def sweep_equivalents(K, workload=None):
     LL/token the reference reaches after n sweeps (n = 10 .. 100), against two chains of the (nondeterministic) reference and every seed
     of the mode -- tools/ll_curves.py equivalents, committed as profiles/r05_sweep_equivalents_*.json.  `worst_view` is the range of the
     view that needs most; `cpu_band` is the reference against itself (one chain's sweeps to reach the other's LL)."""
-    name = "r05_sweep_equivalents_c5_100k.json" if workload == "C5" else "r05_sweep_equivalents_c4_200k.json" if K >= 256 else "r05_sweep_equivalents_c3.json"
+    name = "r05_sweep_equivalents_c5_100k.json" if workload == "C5" else "r05_sweep_equivalents_c2.json" if workload == "C2" else "r05_sweep_equivalents_c4_200k.json" if K >= 256 else "r05_sweep_equivalents_c3.json"
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception as e:
@@ -420,13 +420,17 @@ def main():
         barrier()
         t1 = time.perf_counter()
         km = []
+        mode_births[0] = 0
         for k in range(args.live_steps):
-            km.append(step(first_idx + sec_warm + k, flags).sweep_kernel_ms)
+            st_ = step(first_idx + sec_warm + k, flags)
+            km.append(st_.sweep_kernel_ms)
+            mode_births[0] += int(st_.activations)
         barrier()
         mode_kernel_ms[0] = float(np.mean(km)) if km else 0.0
         return max_over_ranks(time.perf_counter() - t1)
 
     mode_kernel_ms = [0.0]
+    mode_births = [0]                               # topics activated (UPD:263-270) during a mode's timed sweeps (a truncated HDP: C5)
 
     def mode_rooflines(mode):
         """the two ceilings of a secondary mode's sweep kernels, from the PMC / SQ passes over ITS window of this command (profiles/profile_r05.sh)"""
@@ -443,7 +447,9 @@ def main():
             dl = time_mode(lf, base_idx)
             v = total_tokens * args.live_steps / dl
             out["live"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm,
-                           "ms_per_step": dl / args.live_steps * 1e3, "segments_per_sweep": args.live_segments or 1,
+                           "ms_per_step": dl / args.live_steps * 1e3,
+                           "segments_per_sweep": args.live_segments or "library default: 1, and 16 while a topic is still inactive (one topic is born per segment border)",
+                           "topics_born_in_the_timed_sweeps": mode_births[0],
                            "note": "MVHDP_SWEEP_LIVE in its live-rows form (the tree branch samples from the word's live count row, on the 16-bit "
                                    "mirror where K >= 256; one segment), timed after the K deferred steps; not bit-reproducible; what a sweep of it "
                                    "is worth in every view: reference_sweep_equivalent"}
