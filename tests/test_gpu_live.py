@@ -361,3 +361,31 @@ def test_one_wave_live_sweep_fuzz_against_the_sequential_oracle(case):
     s.set_tuning(live16=live16, single_wave=1, live_rows=1, force_primary=force)
     _one_wave_against_the_oracle(o, s, _longest_first(c.doc_off), c.M, 2, nseg, 1, live16, 100 + case)
     s.close()
+
+
+def test_a_live_sweep_takes_sixteen_segments_while_a_topic_is_inactive():
+    """A live sweep gives birth to one topic per segment border (above); the reference's updater does it delta by delta and has every
+    inactive topic of C5 active within its first sweep.  So a live-rows sweep that STARTS with an inactive topic takes 16 segments by
+    default (PlanTuning::live_rows_birth_segments) and one segment again once every topic is active; a segment count named in the flags
+    is kept as it is."""
+    K, V = 60, [500, 60]
+    c = small_corpus(K, V, 400, [40, 6], 45)
+    inactive = np.zeros(K, dtype=np.uint8); inactive[40:] = 1                 # 20 inactive topics
+    hy = Hyper.defaults(K, V, inactive=inactive); hy.alpha[:, K] = 50.0        # (a new-topic mass that is drawn often)
+    o = make_oracle(c, hy)
+    z = [o.get_assignments(m) for m in range(c.M)]
+    for m in range(c.M):
+        z[m][z[m] >= 40] = 7
+    s = make_native(c, hy, z)
+    born = []
+    for it in range(4):
+        st = s.sweep(it, 5, flags=SWEEP_LIVE)
+        born.append(int(st.activations))
+        _check_counts_are_counts_of_z(c, s, K)
+    assert born[0] == 16 and sum(born) == 20 and born[-1] == 0, born      # sixteen borders, sixteen births; the rest in the sweeps behind
+    assert int(s.get_alpha()[1].sum()) == 0
+    s.close()
+    s = make_native(c, hy, z)
+    assert s.sweep(0, 5, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1)).activations == 1
+    assert s.sweep(1, 5, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(3)).activations == 3
+    s.close()
