@@ -448,7 +448,7 @@ def main():
             v = total_tokens * args.live_steps / dl
             out["live"] = {"value": v, "unit": "tokens/s", "steps": args.live_steps, "warmup": sec_warm,
                            "ms_per_step": dl / args.live_steps * 1e3,
-                           "segments_per_sweep": args.live_segments or "library default: 1, and 16 while a topic is still inactive (one topic is born per segment border)",
+                           "segments_per_sweep": args.live_segments or 1,
                            "topics_born_in_the_timed_sweeps": mode_births[0],
                            "note": "MVHDP_SWEEP_LIVE in its live-rows form (the tree branch samples from the word's live count row, on the 16-bit "
                                    "mirror where K >= 256; one segment), timed after the K deferred steps; not bit-reproducible; what a sweep of it "

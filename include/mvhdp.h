@@ -129,8 +129,7 @@ typedef struct {
  * MVHDP_SWEEP_LIVE_SEGMENTS(n) interleaved segments (n = 1..255, 0 = library default); at each segment boundary the
  * tokensPerTopic updates of the segment (privatised per workgroup: M*K hot words) land.
  * The tree branch (WRK:533-535) -- two forms, mvhdp_tuning.live_rows:
- *   live rows (default wherever every kernel of the sweep is register-resident; default 1 segment, 16 while inActiveTopicIndex holds a
- *     topic -- see "Topic activation" below): no stored tree is sampled for a
+ *   live rows (default wherever every kernel of the sweep is register-resident; default 1 segment): no stored tree is sampled for a
  *     word of at most 65534 tokens; the branch draws from leaf_k = coef_k * (n_wk + beta) with n_wk the word's LIVE row, read when the
  *     token's turn comes, and coef_k = gamma alpha_k / (n_k + beta Sigma) of the segment start -- what the reference's updater achieves
  *     by refreshing the two touched leaves with every delta (UPD:242-260 -> FT:138-147).  Heavier words keep stored trees, rebuilt from
@@ -143,9 +142,11 @@ typedef struct {
  * Topic activation (UPD:263-270): the first delta of a SEGMENT that lands on an inactive topic activates it at the segment's
  * end -- alpha[m][k] takes alpha[m][K], the topic leaves inActiveTopicIndex, the next segment's new-topic draws go to the
  * next inactive index (WRK:523-526) -- so one sweep can give birth to up to n topics (mvhdp_sweep_stats.activations); the
- * reference's updater does it delta by delta (on C5 its 100 inactive topics are all born within the first sweep), which is why a
- * live-rows sweep that starts with inactive topics takes 16 segments by default.  With NO_APPLY nothing is activated here (the
- * caller reduces the key first). */
+ * reference's updater does it delta by delta (on C5 its 100 inactive topics are all born within the first sweep).  A live sweep in
+ * its live-rows form does it chunk by chunk: a new-topic draw takes the first inactive topic no delta has reached yet, a chunk whose
+ * deltas reach it moves the samplers on to the next, and the segment's end activates every topic that was reached, in index order
+ * (mvhdp_sweep_stats.activations can exceed the segment count).  With NO_APPLY nothing is activated here (the caller reduces the
+ * key first). */
 #define MVHDP_SWEEP_LIVE        0x20u
 #define MVHDP_SWEEP_LIVE_SEGMENTS(n) (((uint32_t)(n) & 0xffu) << 16)
 

@@ -55,7 +55,6 @@ static void read_environment(mvhdp_ctx* h)
     if (const char* f = getenv("MVHDP_LIVE_ROWS_THETA")) h->tu.live_rows_theta = atof(f);
     if (const char* f = getenv("MVHDP_COEF_LDS_KB")) h->tu.coef_lds_max_bytes = std::max(0, std::min(64, atoi(f))) * 1024;   // (experiment: the live-rows coefficient table in LDS up to this size)
     if (const char* f = getenv("MVHDP_LIVE_ROWS_SEGMENTS")) h->tu.live_rows_segments = std::max(1, std::min(255, atoi(f)));
-    if (const char* f = getenv("MVHDP_LIVE_ROWS_BIRTH_SEGMENTS")) h->tu.live_rows_birth_segments = std::max(1, std::min(255, atoi(f)));   // ... of a sweep that starts with inactive topics
     if (const char* f = getenv("MVHDP_WIDEST_ON_MAIN")) h->tu.widest_on_main = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_NARROW_WIDE")) h->tu.narrow_wide = atoi(f) != 0;
     if (const char* f = getenv("MVHDP_LIVE_TREE_EVERY")) h->live_tree_every = std::max(1, atoi(f));   // (diagnostics: a live sweep rebuilds its trees at every n-th segment border only)
@@ -159,6 +158,9 @@ extern "C" int mvhdp_create(const mvhdp_config* cfg, mvhdp_handle* out)
     CREATE_HIP(hipMalloc(&h->d_alpha, (size_t)M * (K + 1) * sizeof(double)));
     CREATE_HIP(hipMalloc(&h->d_inactive, (size_t)K));
     CREATE_HIP(hipMemset(h->d_inactive, 0, (size_t)K));
+    CREATE_HIP(hipMalloc(&h->d_births, (size_t)(2 + 2 * K) * sizeof(int32_t)));
+    CREATE_HIP(hipMemset(h->d_births, 0, (size_t)(2 + 2 * K) * sizeof(int32_t)));
+    CREATE_HIP(hipMalloc(&h->d_birth_keys, (size_t)K * sizeof(long long)));
     CREATE_HIP(hipMalloc(&h->d_ctl, CTL_WORDS * sizeof(unsigned long long)));
     CREATE_HIP(hipMemset(h->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long)));
     h->d_stats = h->d_ctl;
@@ -187,7 +189,7 @@ static void release_device_resources(mvhdp_ctx* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fr = [](auto*& p) { if (p) { hipFree((void*)p); p = nullptr; } };
     for (int m = 0; m < MVHDP_MAXM; m++) { fr(h->d_doc_off[m]); fr(h->d_tok[m]); fr(h->d_z[m]); fr(h->d_carry[m]); fr(h->d_present[m]); }
-    fr(h->mm.counts); fr(h->mm.delta16); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.coef); fr(h->mm.mass0); fr(h->mm.dtab); fr(h->mm.p);
+    fr(h->mm.counts); fr(h->mm.delta16); fr(h->mm.counts16); fr(h->mm.heavy); fr(h->mm.delta); fr(h->mm.trees); fr(h->mm.root); fr(h->mm.coef); fr(h->mm.mass0); fr(h->d_births); fr(h->d_birth_keys); fr(h->mm.dtab); fr(h->mm.p);
     fr(h->d_alpha); fr(h->d_inactive); fr(h->d_ctl);
     if (h->h_ctl) { hipHostFree(h->h_ctl); h->h_ctl = nullptr; }
     h->d_stats = nullptr; h->d_act_key = nullptr; h->d_doc_counter = nullptr; h->d_ovf_meta = nullptr;
@@ -581,6 +583,54 @@ static int apply_activation(mvhdp_ctx* h, int32_t activated_topic, int32_t activ
         for (int k = 0; k < mm.K; k++) if (h->h_inactive[k]) { mm.first_inactive = k; break; }
         HIPC(h, hipMemcpy(h->d_alpha, h->h_alpha.data(), h->h_alpha.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPC(h, hipMemcpy(h->d_inactive, h->h_inactive.data(), (size_t)mm.K, hipMemcpyHostToDevice));
+    }
+    return MVHDP_OK;
+}
+
+// Births of a live sweep, chunk by chunk (SweepLaunch::births): the reference's updater takes a topic out of inActiveTopicIndex with the
+// FIRST delta that reaches it (UPD:263-270) and its samplers then draw the next inactive index (WRK:523-526) -- all 100 inactive topics of
+// C5 are active within its first sweep.  A segment starts with the list of the topics that are inactive now (births_begin); its kernels
+// move along that list as their chunks' deltas land; births_end activates what was reached, in index order, each topic's alpha[m][K]
+// going to the view of its first delta.
+static hipError_t births_begin(mvhdp_ctx* h, hipStream_t s)
+{
+    const int K = h->mm.K;
+    h->h_births.assign((size_t)2 + 2 * K, -1);
+    int n = 0;
+    for (int k = 0; k < K; k++) if (h->h_inactive[k]) { h->h_births[(size_t)2 + K + k] = n; h->h_births[(size_t)2 + n++] = k; }
+    h->h_births[0] = 0; h->h_births[1] = n;
+    h->h_birth_keys.assign((size_t)K, LLONG_MAX);
+    hipError_t e = hipMemcpyAsync(h->d_births, h->h_births.data(), h->h_births.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_birth_keys, h->h_birth_keys.data(), (size_t)K * sizeof(long long), hipMemcpyHostToDevice, s);
+    return e;
+}
+static int births_end(mvhdp_ctx* h, hipStream_t s, SweepOutcome& oc)
+{
+    MvModel& mm = h->mm;
+    const int K = mm.K;
+    int32_t head[2] = {0, 0};
+    HIPC(h, hipMemcpyAsync(head, h->d_births, sizeof head, hipMemcpyDeviceToHost, s));
+    HIPC(h, hipStreamSynchronize(s));
+    const int n = std::min(head[0], std::min(head[1], K));
+    if (n <= 0) return MVHDP_OK;
+    HIPC(h, hipMemcpy(h->h_birth_keys.data(), h->d_birth_keys, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    bool any = false;
+    for (int r = 0; r < n; r++) {
+        const int t = h->h_births[(size_t)2 + r];
+        const long long key = h->h_birth_keys[(size_t)r];
+        if (t < 0 || t >= K || key == LLONG_MAX || !h->h_inactive[t]) continue;          // (cannot happen: position r is passed only by a delta that reached it)
+        const int mv = MVHDP_ACT_KEY_VIEW(key);
+        if (mv < 0 || mv >= mm.M) FAIL(h, MVHDP_ERR_STATE, "births: bad activation key");
+        h->h_inactive[t] = 0;
+        h->h_alpha[(size_t)mv * (K + 1) + t] = h->h_alpha[(size_t)mv * (K + 1) + K];
+        if (oc.n_activations++ == 0) oc.first_act = key;
+        any = true;
+    }
+    if (any) {
+        mm.first_inactive = -1;
+        for (int k = 0; k < K; k++) if (h->h_inactive[k]) { mm.first_inactive = k; break; }
+        HIPC(h, hipMemcpy(h->d_alpha, h->h_alpha.data(), h->h_alpha.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPC(h, hipMemcpy(h->d_inactive, h->h_inactive.data(), (size_t)K, hipMemcpyHostToDevice));
     }
     return MVHDP_OK;
 }
@@ -1068,6 +1118,9 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
     sl.delta16 = p.delta16 ? 1 : 0;
     sl.stats = d_stats;
     sl.act_key = h->d_act_key;
+    // a live sweep in its live-rows form over a truncated HDP: topics are born chunk by chunk (births_begin / births_end), not one per segment
+    const bool births = p.live_rows && !(flags & MVHDP_SWEEP_NO_APPLY) && mm.first_inactive >= 0 && p.only_seg < 0;
+    if (births) { sl.births = h->d_births; sl.birth_keys = h->d_birth_keys; }
     sl.slot_hist = (unsigned long long*)h->d_ovf_meta + META_HIST;
     if (db) {
         for (int m = 0; m < M; m++) sl.tok_dbg[m] = db->tok_dbg[m];
@@ -1143,6 +1196,7 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
     }
     // this sweep's counters, "no activation yet", the histograms for the next plan, the class list lengths, the queue heads: one launch
     step(mvhdp_launch_ctl_reset(d_stats, ST_COUNT, h->d_act_key, (unsigned long long*)h->d_ovf_meta, META_WORDS64, nullptr, h->d_doc_counter, s));
+    if (births) step(births_begin(h, s));
     step(hipEventRecord(ev_k0, s));
 
     const int seg_lo = p.only_seg >= 0 ? p.only_seg : 0, seg_hi = p.only_seg >= 0 ? p.only_seg + 1 : nseg;
@@ -1155,6 +1209,13 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
             // index (WRK:523-526): a sweep whose counts are kept current does the same at every segment border -- the
             // segment's first such delta (by entity, view, position) activates its topic before the next segment starts.
             // Not with MVHDP_SWEEP_NO_APPLY: there the caller reduces the key over all document shards first.
+            if (births && e == hipSuccess) {
+                const int rc = births_end(h, s, oc);                                     // every topic the segment's deltas reached
+                if (rc != MVHDP_OK) return rc;
+                mk.first_inactive = mm.first_inactive;
+                step(births_begin(h, s));                                                // (an empty list once every topic is active)
+                step(mvhdp_launch_ctl_reset(nullptr, 0, h->d_act_key, nullptr, 0, nullptr, nullptr, s));
+            } else
             if ((p.live || p.seg_apply) && !(flags & MVHDP_SWEEP_NO_APPLY) && mm.first_inactive >= 0 && e == hipSuccess) {
                 long long key = LLONG_MAX;
                 step(hipMemcpyAsync(&key, h->d_act_key, sizeof key, hipMemcpyDeviceToHost, s));
@@ -1320,6 +1381,7 @@ int mvhdp_sweep_begin(mvhdp_ctx* h, uint32_t sweep_idx, uint64_t seed, uint32_t 
     if (h->dbg_env) debug_print_plan(h, ps.p, sweep_idx);
     if (ps.debug) { rc = alloc_debug(h, dbg, ps.db); if (rc) return rc; }
     HIPC(h, hipEventRecord(h->ev[0], s));
+    ps.births = ps.p.live_rows && !(flags & MVHDP_SWEEP_NO_APPLY) && h->mm.first_inactive >= 0 && ps.p.only_seg < 0;   // (as enqueue_sweep decides it)
     rc = enqueue_sweep(h, ps.p, sweep_idx, seed, p_override, ps.debug ? &ps.db : nullptr, h->d_stats, h->ev[1], h->ev[2], ps.oc);
     if (rc) { ps.db.release(); return rc; }
     // counters | activation key | histograms: one copy into the handle's pinned buffer, in stream order behind the kernels
@@ -1379,8 +1441,13 @@ int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats)
         h->have_trees = false;
         if (p.seg_apply) h->delta_clean = true;                      // apply_delta_kernel zeroed what it added
         if (p.seg_apply && p.overlap) h->ov.deltas_dirty = false;
-        ret = apply_activation(h, st.activated_topic, st.activated_modality);
-        if (st.activated_topic >= 0) n_activations++;
+        if (ps.births) {                                             // the last segment's births (the earlier segments' were applied at their borders)
+            ret = births_end(h, s, ps.oc);
+            n_activations = ps.oc.n_activations;
+        } else {
+            ret = apply_activation(h, st.activated_topic, st.activated_modality);
+            if (st.activated_topic >= 0) n_activations++;
+        }
         if (ps.oc.first_act != LLONG_MAX) {                          // report the sweep's first activation
             st.activation_key = ps.oc.first_act;
             st.activated_topic = MVHDP_ACT_KEY_TOPIC(ps.oc.first_act); st.activated_modality = MVHDP_ACT_KEY_VIEW(ps.oc.first_act);

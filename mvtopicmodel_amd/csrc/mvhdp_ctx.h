@@ -56,6 +56,10 @@ struct mvhdp_ctx {
     unsigned long long* h_ctl = nullptr;     // pinned host copy of the first three parts (a sweep's read-back)
     unsigned long long* d_stats = nullptr;   //   = d_ctl
     long long* d_act_key = nullptr;          //   = d_ctl + ST_COUNT
+    int32_t* d_births = nullptr;             // [2 + 2K] births of a live sweep (SweepLaunch::births)
+    long long* d_birth_keys = nullptr;       // [K]
+    std::vector<int32_t> h_births;           // host copies of the two (the list a segment starts with; what it ended with)
+    std::vector<long long> h_birth_keys;
     unsigned long long* d_doc_counter = nullptr;
     int32_t* d_doc_order = nullptr;          // entities by decreasing token count (work-queue order)
     unsigned int* d_ovf_meta = nullptr;      // META_*: the next sweep's histograms (tokens by list size, entities by kernel class), per-class list lengths, misroutes
@@ -151,6 +155,7 @@ struct PendingSweep {
     const mvhdp_debug* dbg = nullptr;
     DebugBufs db;
     bool open = false;
+    bool births = false;                     // a live sweep whose topics are born chunk by chunk (SweepLaunch::births): the last segment's are applied by the finish
 };
 int mvhdp_sweep_begin(mvhdp_ctx* h, uint32_t sweep_idx, uint64_t seed, uint32_t flags, const double* p_override, const mvhdp_debug* dbg, PendingSweep& ps);
 int mvhdp_sweep_finish(mvhdp_ctx* h, PendingSweep& ps, mvhdp_sweep_stats* stats);

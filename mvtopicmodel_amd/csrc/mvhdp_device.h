@@ -86,6 +86,12 @@ struct SweepLaunch {
     uint32_t wave_bytes;               // per-wave LDS region
     unsigned long long* stats;         // [16] device counters
     long long* act_key;                // activation key (atomicMin)
+    // births of a live sweep (UPD:263-270 chunk by chunk; null: one activation per segment, by act_key): births[0] = how many of the topics
+    // that were inactive at the segment start have been reached by a delta, [1] = their number n, [2 .. 2+n) = those topics in index order
+    // (a new-topic draw, WRK:523-526, goes to births[2 + births[0]]), [2+K .. 2+2K) = a topic's position in that list or -1;
+    // birth_keys[r] = the first delta (MVHDP_ACT_KEY) that reached topic births[2 + r] (its view takes alpha[m][K], UPD:268)
+    int32_t* births;
+    long long* birth_keys;
     // Work queue: waves pull entities in batches from one head.  Queue position q maps to an entity through two
     // segments: first the entities the route pass listed for this kernel (q_list[0 .. *q_list_count)), then
     // q_order_count entities of a static order (q_order[q_order_start + i*q_order_stride], or the identity when q_order

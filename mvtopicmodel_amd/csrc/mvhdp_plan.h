@@ -142,7 +142,6 @@ struct PlanTuning {
     int live16 = -1;                            // live sweeps keep the light rows current in the 16-bit mirror: -1 where a row has at least 1 KiB (K >= 256), 0 never, 1 always
     int live_rows = -1;                         // live sweeps sample their tree branch from the live count rows (no stored trees): -1 / 1 wherever every kernel is
                                                 //   register-resident (default), 0: stored trees rebuilt at every segment border (the round-4 form)
-    int live_rows_birth_segments = 16;          // ... while a topic is still inactive (a truncated HDP): one topic is activated per segment border
     int live_rows_segments = 1;                 // segments of such a sweep when the flags name none (a border refreshes tokensPerTopic and the roots: one pass over the counts)
     int coef_lds_max_bytes = 12 * 1024;         // live-rows form: the coefficient table [M][Kp] sits in every block's LDS up to this size (C4: 4.8 KB; C5's 20 KB stay in global memory by default)
     double live_rows_theta = 0.3;               // steered views: a token's row is loaded ahead of its turn iff its u1 reaches this (a token below it that reaches the tree
@@ -335,12 +334,9 @@ static inline void plan_sweep(const PlanIn& in, const PlanTuning& tu, WalkTuner&
     bool want_rows = p.live && !p.frozen && !in.debug && tu.live_rows != 0 && !(flags & (MVHDP_SWEEP_REUSE_TREES | MVHDP_SWEEP_GENERIC_KERNEL)) &&
                      tu.force_primary != 32 && std::min<int64_t>(in.K, std::max<int64_t>(in.mdt, 1)) <= 1024 && in.mdt <= 65535;
     int nseg = (int)((flags >> 16) & 0xffu);
-    // While inActiveTopicIndex holds topics a live sweep gives birth to ONE per segment border (the host activates the segment's first such
-    // delta, UPD:263-270) where the reference's updater does it delta by delta -- its C5 slice has all 100 of them active within the first
-    // sweep.  One segment per sweep would make that 100 sweeps (measured: view 0 of the C5 slice 0.16 nats behind the reference after 100
-    // sweeps, profiles/r05_ll_curves_c5.md): so as long as a topic is inactive the default is live_rows_birth_segments borders per sweep.
-    const bool births = in.first_inactive >= 0 && !(flags & MVHDP_SWEEP_NO_APPLY);
-    if (nseg == 0) nseg = want_rows ? std::max(1, births ? tu.live_rows_birth_segments : tu.live_rows_segments) : (p.live || p.seg_apply) ? 4 : 1;
+    // (a truncated HDP needs no more: in the live-rows form topics are born chunk by chunk, SweepLaunch::births -- the stored-tree form and a
+    // document shard give birth to one topic per segment border / exchange)
+    if (nseg == 0) nseg = want_rows ? std::max(1, tu.live_rows_segments) : (p.live || p.seg_apply) ? 4 : 1;
     p.only_seg = (int)(flags >> 24) - 1;                  // MVHDP_SWEEP_ONLY_SEGMENT(s): -1 = every segment
     // (more segments than entities: a whole sweep uses fewer; a single-segment call keeps the caller's count -- segments beyond the
     // last entity are empty -- so that document shards of different sizes walk through the same number of exchanges)

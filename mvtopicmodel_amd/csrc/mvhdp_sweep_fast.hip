@@ -786,6 +786,10 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                         if (mm.first_inactive >= 0 && mm.inactive[znew_l]) {          // UPD:263
                             long long key = (long long)MVHDP_ACT_KEY(dg, m, ti, znew_l);
                             atomicMin(sl.act_key, key);
+                            if (sl.births) {                                 // the samplers move on to the next inactive index (WRK:523-526)
+                                const int r_ = sl.births[2 + K + znew_l];
+                                if (r_ >= 0) { atomicMin(&sl.birth_keys[r_], key); atomicMax(&sl.births[0], r_ + 1); }
+                            }
                         }
                     }
                 }

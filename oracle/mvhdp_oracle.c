@@ -961,6 +961,12 @@ typedef struct {
     float* smp;       /* [M][K] */
     double* root;     /* [sumV] */
     float* mass0;     /* [sumV] the first row batch's mass at the segment start */
+    /* births (rows = 1): the topics that are inactive at the segment start, in index order; a new-topic draw (WRK:523-526) goes to
+       b_list[b_pos], and a chunk whose deltas reach b_list[r] moves b_pos to r + 1 (UPD:263-270 applied chunk by chunk) */
+    int births, b_n, b_pos;
+    int32_t* b_list;  /* [K] */
+    int32_t* b_rank;  /* [K] position in b_list, -1: active */
+    int64_t* b_key;   /* [K] the first delta (entity, view, position) that reached b_list[r] */
     uint8_t* heavy;   /* [sumV] more than 65534 tokens at the sweep start */
     int32_t* nk_seg;  /* [M][K] tokensPerTopic of the segment start */
     int32_t* nk_delta;
@@ -1078,7 +1084,7 @@ static int sample_one_doc_live(orc_model* o, live_state* ls, int rows, int cell1
                 const double root = ls->root[r];
                 double sample = u1 * (newTopicMass + mass + root);
                 int newTopic = -1;
-                if (sample < newTopicMass) { st->new_mass_cnt++; newTopic = first_inactive; }
+                if (sample < newTopicMass) { st->new_mass_cnt++; newTopic = !ls->births ? first_inactive : (ls->b_pos < ls->b_n ? ls->b_list[ls->b_pos] : -1); }
                 else {
                     sample -= newTopicMass;
                     if (sample < mass) {
@@ -1111,6 +1117,10 @@ static int sample_one_doc_live(orc_model* o, live_state* ls, int rows, int cell1
                     if (ch_old[i] != -1) { o->nwk[rr + ch_old[i]]--; ls->nk_delta[(size_t)m * K + ch_old[i]]--; }
                     o->nwk[rr + ch_new[i]]++; ls->nk_delta[(size_t)m * K + ch_new[i]]++;
                     if (o->inactive[ch_new[i]] && ch_key[i] < *act_key) *act_key = ch_key[i];
+                    if (ls->births && o->inactive[ch_new[i]]) {
+                        const int r = ls->b_rank[ch_new[i]];
+                        if (r >= 0) { if (ch_key[i] < ls->b_key[r]) ls->b_key[r] = ch_key[i]; if (r + 1 > ls->b_pos) ls->b_pos = r + 1; }
+                    }
                 }
                 n_ch = 0;
             }
@@ -1133,6 +1143,8 @@ int orc_sweep_live_seq(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t 
     ls.coef = (float*)calloc((size_t)M * K, sizeof(float)); ls.smp = (float*)calloc((size_t)M * K, sizeof(float));
     ls.root = (double*)calloc((size_t)(nrows > 0 ? nrows : 1), sizeof(double)); ls.mass0 = (float*)calloc((size_t)(nrows > 0 ? nrows : 1), sizeof(float)); ls.heavy = (uint8_t*)calloc((size_t)(nrows > 0 ? nrows : 1), 1);
     ls.nk_seg = (int32_t*)calloc((size_t)M * K, sizeof(int32_t)); ls.nk_delta = (int32_t*)calloc((size_t)M * K, sizeof(int32_t));
+    ls.births = rows != 0;                                   /* (the live-rows form of the library; its stored-tree form activates one topic per segment) */
+    ls.b_list = (int32_t*)calloc((size_t)K, sizeof(int32_t)); ls.b_rank = (int32_t*)calloc((size_t)K, sizeof(int32_t)); ls.b_key = (int64_t*)calloc((size_t)K, sizeof(int64_t));
     int32_t* localTopicCounts = (int32_t*)malloc((size_t)M * K * sizeof(int32_t));
     int32_t* localTopicIndex = (int32_t*)malloc((size_t)(K + 1) * sizeof(int32_t));
     double* topicDocWordMasses = (double*)malloc((size_t)(K + 1) * sizeof(double));
@@ -1143,6 +1155,8 @@ int orc_sweep_live_seq(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t 
         for (int k = 0; k < K; k++) if (o->inactive[k]) { first_inactive = k; break; }
         live_prepare(o, &ls, rows, cell16, seg == 0);
         int64_t act_key = INT64_MAX;
+        ls.b_n = 0; ls.b_pos = 0;
+        for (int k = 0; k < K; k++) { ls.b_rank[k] = -1; if (o->inactive[k]) { ls.b_rank[k] = ls.b_n; ls.b_key[ls.b_n] = INT64_MAX; ls.b_list[ls.b_n++] = k; } }
         for (int64_t q = seg; q < n_order; q += nseg) {
             const int64_t d = order[q];
             if (d < 0 || d >= o->D) continue;
@@ -1152,13 +1166,20 @@ int orc_sweep_live_seq(orc_model* o, uint32_t sweep_idx, uint64_t seed, int64_t 
                                     localTopicCounts, localTopicIndex, topicDocWordMasses, totalMassOtherModalities)) local.aborted_docs++;
         }
         for (size_t i = 0; i < (size_t)M * K; i++) o->nk[i] += ls.nk_delta[i];          /* the block's private tokensPerTopic table lands */
+        if (ls.births) {                                                               /* every topic a chunk's deltas reached, in index order */
+            for (int r = 0; r < ls.b_pos; r++) {
+                const int t = ls.b_list[r], mv = (int)((ls.b_key[r] >> 31) & 7);
+                if (o->inactive[t]) { o->inactive[t] = 0; o->alpha[(size_t)mv * (K + 1) + t] = o->alpha[(size_t)mv * (K + 1) + K]; }
+                if (local.activated_topic < 0) { local.activated_topic = t; local.activated_modality = mv; local.activation_key = ls.b_key[r]; }
+            }
+        } else
         if (act_key != INT64_MAX) {                                                    /* UPD:263-270 at the segment's end */
             const int t = (int)(act_key & 0x7ff), mv = (int)((act_key >> 31) & 7);
             if (o->inactive[t]) { o->inactive[t] = 0; o->alpha[(size_t)mv * (K + 1) + t] = o->alpha[(size_t)mv * (K + 1) + K]; }
             if (local.activated_topic < 0) { local.activated_topic = t; local.activated_modality = mv; local.activation_key = act_key; }
         }
     }
-    free(ls.coef); free(ls.smp); free(ls.root); free(ls.mass0); free(ls.heavy); free(ls.nk_seg); free(ls.nk_delta);
+    free(ls.coef); free(ls.smp); free(ls.root); free(ls.mass0); free(ls.heavy); free(ls.nk_seg); free(ls.nk_delta); free(ls.b_list); free(ls.b_rank); free(ls.b_key);
     free(localTopicCounts); free(localTopicIndex); free(topicDocWordMasses); free(totalMassOtherModalities); free(p_own);
     if (st) *st = local;
     return 0;

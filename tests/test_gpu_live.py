@@ -363,11 +363,11 @@ def test_one_wave_live_sweep_fuzz_against_the_sequential_oracle(case):
     s.close()
 
 
-def test_a_live_sweep_takes_sixteen_segments_while_a_topic_is_inactive():
-    """A live sweep gives birth to one topic per segment border (above); the reference's updater does it delta by delta and has every
-    inactive topic of C5 active within its first sweep.  So a live-rows sweep that STARTS with an inactive topic takes 16 segments by
-    default (PlanTuning::live_rows_birth_segments) and one segment again once every topic is active; a segment count named in the flags
-    is kept as it is."""
+def test_a_live_sweep_gives_birth_to_topics_chunk_by_chunk():
+    """UPD:263-270 takes a topic out of inActiveTopicIndex with the FIRST delta that reaches it and the samplers then draw the next
+    inactive index (WRK:523-526): the reference has every inactive topic of C5 active within its first sweep.  In its live-rows form a
+    live sweep does the same chunk by chunk (SweepLaunch::births): ONE segment gives birth to many topics, in index order without gaps,
+    each topic's alpha[m][K] going to the view of its first delta; the stored-tree form keeps one birth per segment border."""
     K, V = 60, [500, 60]
     c = small_corpus(K, V, 400, [40, 6], 45)
     inactive = np.zeros(K, dtype=np.uint8); inactive[40:] = 1                 # 20 inactive topics
@@ -378,14 +378,22 @@ def test_a_live_sweep_takes_sixteen_segments_while_a_topic_is_inactive():
         z[m][z[m] >= 40] = 7
     s = make_native(c, hy, z)
     born = []
-    for it in range(4):
-        st = s.sweep(it, 5, flags=SWEEP_LIVE)
+    for it in range(3):
+        ina_before = s.get_alpha()[1].copy()
+        st = s.sweep(it, 5, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1))
+        a, ina = s.get_alpha()
         born.append(int(st.activations))
+        assert int(ina_before.sum()) - int(ina.sum()) == st.activations
+        newly = np.flatnonzero(ina_before.astype(bool) & ~ina.astype(bool))
+        assert np.array_equal(newly, np.flatnonzero(ina_before)[:st.activations])          # in index order, no gaps
+        if st.activations:
+            assert st.activated_topic == int(np.flatnonzero(ina_before)[0])
+            assert all((a[:, t] == 50.0).sum() == 1 for t in newly)                        # UPD:268: the view of the topic's first delta, that view only
         _check_counts_are_counts_of_z(c, s, K)
-    assert born[0] == 16 and sum(born) == 20 and born[-1] == 0, born      # sixteen borders, sixteen births; the rest in the sweeps behind
-    assert int(s.get_alpha()[1].sum()) == 0
+    assert born[0] >= 8 and sum(born) == 20, born                            # one segment, many births; all twenty within three sweeps
     s.close()
     s = make_native(c, hy, z)
+    s.set_tuning(live_rows=0)                                                 # the stored-tree form: one birth per segment border
     assert s.sweep(0, 5, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(1)).activations == 1
     assert s.sweep(1, 5, flags=SWEEP_LIVE | SWEEP_LIVE_SEGMENTS(3)).activations == 3
     s.close()

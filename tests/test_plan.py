@@ -153,10 +153,9 @@ def test_forced_variants_flags_and_errors():
     assert probe(flags=SWEEP_LIVE | (3 << 16)).segments == 3 and probe(flags=SWEEP_LIVE | (3 << 16)).live_rows == 1
     assert probe(flags=SWEEP_LIVE, debug=1).live_rows == 0 and probe(flags=SWEEP_LIVE | SWEEP_REUSE_TREES, trees_current=1).live_rows == 0
     assert probe(K=2048, M=2, D=1000, mdt=5000, longer=(1000, 900, 800, 500, 100), flags=SWEEP_LIVE).live_rows == 0      # (the generic kernel can be reached)
-    # ... and while a topic is still inactive (a truncated HDP) sixteen: a live sweep gives birth to one topic per segment border where the
-    # reference's updater does it delta by delta (UPD:263-270); not for a document shard, whose group activates once per exchange
-    assert probe(flags=SWEEP_LIVE, inactive=1).segments == 16 and probe(flags=SWEEP_LIVE, inactive=1).live_rows == 1
-    assert probe(flags=SWEEP_LIVE | (2 << 16), inactive=1).segments == 2 and probe(flags=SWEEP_LIVE | SWEEP_NO_APPLY, inactive=1).segments == 1
+    # ... also over a truncated HDP (inActiveTopicIndex not empty): the live-rows form gives birth to topics chunk by chunk, the stored-tree
+    # form one per segment border
+    assert probe(flags=SWEEP_LIVE, inactive=1).segments == 1 and probe(flags=SWEEP_LIVE, inactive=1).live_rows == 1
     assert probe(flags=SWEEP_LIVE, inactive=1, tuning=dict(live_rows=0)).segments == 4
     assert probe(D=3, longer=(3, 3, 0, 0, 0), flags=SWEEP_LIVE | (200 << 16)).segments == 3        # never more segments than entities
     assert probe(flags=SWEEP_SEGMENT_APPLY | SWEEP_NO_APPLY).status == -1
