@@ -81,8 +81,10 @@ typedef struct {
     int64_t activation_key;       /* ordering key of that first delta, MVHDP_ACT_KEY(doc, view, pos, topic); INT64_MAX if none */
     double  sweep_kernel_ms;      /* device time of the sweep kernel alone (hipEvents on the handle's stream) */
     double  total_ms;             /* device time of the whole call: trees + view weights + sweep + apply */
-    int32_t activations;          /* topics that left inActiveTopicIndex during this call: 0 or 1 for a deferred sweep; a LIVE or
-                                     SEGMENT_APPLY sweep activates at every segment border (activated_topic is then the first);
+    int32_t activations;          /* topics that left inActiveTopicIndex during this call: 0 or 1 for a deferred sweep; a SEGMENT_APPLY sweep or a
+                                     LIVE sweep on stored trees activates one per segment border (up to its segment count); a LIVE sweep in its
+                                     live-rows form gives birth chunk by chunk (any number: see MVHDP_SWEEP_LIVE); activated_topic is the FIRST of them
+                                     -- a host pulls alpha / inActiveTopicIndex with mvhdp_get_alpha whenever activated_topic >= 0;
                                      0 with MVHDP_SWEEP_NO_APPLY / FROZEN (the caller activates) */
     int32_t reserved;
 } mvhdp_sweep_stats;

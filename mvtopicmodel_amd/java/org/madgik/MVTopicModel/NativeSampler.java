@@ -33,7 +33,7 @@ public final class NativeSampler implements AutoCloseable {
         public int activatedTopic, activatedModality;
         public long activationKey;
         public double sweepKernelMs, totalMs;
-        public int activations;          // topics activated during the call (a live / segmented sweep activates at every segment border)
+        public int activations;          // topics activated during the call (a segmented sweep: one per segment border; a live sweep in its live-rows form: chunk by chunk, any number)
     }
 
     private long handle;   // mvhdp_handle

@@ -234,8 +234,9 @@ def _bench_line(args, env, timeout=420):
     return json.loads(lines[0])
 
 
-def test_bench_with_two_ranks_takes_the_native_group_and_ends_at_the_single_gpu_counts(fake_rccl):
-    """`python bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), both ranks on cuda:0 with the
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_with_several_ranks_takes_the_native_group_and_ends_at_the_single_gpu_counts(fake_rccl, nranks):
+    """`python bench.py --gpus N` (N = 2, 4) as the driver launches it (torch.distributed.run, one process per rank), all ranks on cuda:0 with the
     test-side collective: the N > 1 leg of the bench -- the id broadcast, mvhdp_group_create_rank, the exchange inside the library -- runs
     for real instead of ending in the fallback, and since deferred sweeps do not depend on the sharding the final counts are those of
     the one-GPU run of the same command."""
@@ -243,8 +244,8 @@ def test_bench_with_two_ranks_takes_the_native_group_and_ends_at_the_single_gpu_
     env = dict(os.environ)
     one = _bench_line(["--gpus", "1"] + common, env)
     env2 = dict(env, MVHDP_RCCL_LIB=fake_rccl, MVHDP_RCCL_LIB_FIRST="1", FAKE_RCCL_TIMEOUT_MS="60000")   # (FIRST: torch has mapped the real RCCL in these processes)
-    two = _bench_line(["--gpus", "2", "--rehearse-native"] + common, env2)
-    assert two["n_gpus"] == 2 and two["exchange"]["kind"].startswith("native"), two["exchange"]
+    two = _bench_line(["--gpus", str(nranks), "--rehearse-native"] + common, env2)
+    assert two["n_gpus"] == nranks and two["exchange"]["kind"].startswith("native"), two["exchange"]
     assert "fallback_reason" not in two["exchange"]
     assert two["final_nk_fingerprint"] == one["final_nk_fingerprint"]
     assert two["config"]["tokens"] == one["config"]["tokens"] and two["value"] > 0
