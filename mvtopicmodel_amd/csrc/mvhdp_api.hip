@@ -1201,9 +1201,7 @@ static int enqueue_sweep(mvhdp_ctx* h, const SweepPlan& p, uint32_t sweep_idx, u
 
     const int seg_lo = p.only_seg >= 0 ? p.only_seg : 0, seg_hi = p.only_seg >= 0 ? p.only_seg + 1 : nseg;
     for (int seg = seg_lo; seg < seg_hi && e == hipSuccess && mm.D > 0; seg++) {
-        // segment seg = positions seg, seg + nseg, ... of the order; a prefix [0, P) of the order holds share(P) of them
-        auto share = [&](int64_t P) -> int64_t { return P > seg ? (P - seg + nseg - 1) / nseg : 0; };
-        const int64_t n_seg = share(mm.D);
+        // segment seg = positions seg, seg + nseg, ... of the order
         if (seg > seg_lo) {
             // UPD:263-270 acts as soon as a delta lands on an inactive topic, and the samplers then draw the NEXT inactive
             // index (WRK:523-526): a sweep whose counts are kept current does the same at every segment border -- the

@@ -158,7 +158,6 @@ hipError_t mvhdp_launch_heavy_refresh(const MvModel& mm, const int32_t* heavy_li
 hipError_t mvhdp_launch_set_u32(unsigned int* p, unsigned int v, hipStream_t s);
 hipError_t mvhdp_launch_apply_nk(const MvModel& mm, unsigned long long* negatives, hipStream_t s);
 // overlapped segments: dst (counts / mirror / descent tables of the copy segment s + 2 reads) += dA (+ dB, zeroed), trees rebuilt; see the kernel
-hipError_t mvhdp_launch_apply2(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, bool write_full, unsigned long long* negatives, int max_blocks, hipStream_t s);
 hipError_t mvhdp_launch_apply2_counts(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, unsigned long long* negatives, hipStream_t s);
 hipError_t mvhdp_launch_apply_sparse(const MvModel& dst, int32_t* d, bool use_mirror, hipStream_t s);
 hipError_t mvhdp_launch_gate(const unsigned long long* qhead, unsigned long long threshold, hipStream_t s);

@@ -277,62 +277,14 @@ hipError_t mvhdp_launch_build_trees_from_mirror(const MvModel& mm, bool write_fu
 // Overlapped segments (MVHDP_SWEEP_SEGMENT_OVERLAP, mvhdp_api.hip enqueue_overlapped): the updater's catch-up for one
 // segment runs BESIDE the sampling of the next.  The model is kept twice (counts, mirror, descent tables); this kernel
 // brings the copy that segment s + 2 will read up to date from the deltas of segments s - 1 and s:
-//     dst += dA (+ dB), dB = 0, the row's tree built from the updated row
+//     dst += dA (+ dB), dB = 0            (apply2_counts_kernel below; the trees stay those of the sweep start: a form that also rebuilt
+//                                          the row's tree here was measured in round 4 -- 2.6-3 ms beside the samplers -- and removed)
 // with memory-side atomics for the count cells -- another kernel (segment s + 1's samplers) is running on the same chip,
 // and an atomic is what every L2 sees at once (tools/microbench/live_staleness.hip) -- and only where a delta is not zero.
 // The row's weight class does not change (a row's total is constant while every token is assigned: the plan refuses
 // the mode otherwise), so a light row's mirror cells take the same delta, packed (+-d << 16 for the upper cell: no
 // cell of a light row can leave [0, 65534]); a heavy row's mirror cells stay 65535.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void apply2_trees_kernel(MvModel mm, const int32_t* __restrict__ dA, int32_t* __restrict__ dB, bool use_mirror,
-                                                          bool write_full, unsigned long long* negatives)
-{
-    extern __shared__ double t[];                  // 2K doubles
-    const int K = mm.K, lane = threadIdx.x;
-    const int64_t nrows = mm.rowbase[mm.M];
-    const int32_t* nk_all = mm.counts + nrows * K;
-    int neg = 0;
-    // this kernel runs beside the next segment's samplers, in the one block slot per CU they leave free, and the segment after that
-    // waits for it: let its waves win the instruction arbiter
-    __builtin_amdgcn_s_setprio(3);
-    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
-        int m = 0;
-        while (m + 1 < mm.M && row >= mm.rowbase[m + 1]) m++;
-        int32_t* cnt = mm.counts + row * K;
-        const int32_t* a = dA + row * K;
-        int32_t* b = dB ? dB + row * K : nullptr;
-        unsigned int* m32 = (unsigned int*)mm.counts16;
-        const bool light = use_mirror && mm.heavy[row] != MVHDP_ROW_HEAVY;
-        const int32_t* nk = nk_all + (int64_t)m * K;
-        const double* al = mm.alpha + (int64_t)m * (K + 1);
-        const double beta = mm.beta[m], beta_sum = mm.beta_sum[m], gamma = mm.gamma[m];
-        for (int k = lane; k < K; k += WAVE) {
-            int c = cnt[k];
-            int d = a[k];
-            if (b) { const int d2 = b[k]; if (d2) { d += d2; b[k] = 0; } }
-            if (d) {
-                __hip_atomic_fetch_add(&cnt[k], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                c += d;
-                neg += c < 0;                                          // UPD:202-215 logs a negative count; here it is reported
-                if (light) { const int64_t cell = row * K + k; __hip_atomic_fetch_add(&m32[cell >> 1], (unsigned int)d << ((cell & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-            double leaf;
-            if (mm.inactive[k]) leaf = 0.0;                            // PTM:2670-2671
-            else {
-                double p_wt = ((double)c + beta) / ((double)nk[k] + beta_sum);   // PTM:2676
-                leaf = gamma * al[k] * p_wt;                            // PTM:2678
-            }
-            t[K + k] = leaf;
-        }
-        tree_from_leaves(mm, row, t, lane, write_full);
-    }
-    if (negatives) {
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) neg += __shfl_xor(neg, sft, WAVE);
-        if (lane == 0 && neg) atomicAdd(negatives, (unsigned long long)neg);
-    }
-}
-
 // tokensPerTopic of the same update (M*K words, before the rows: every leaf needs all of it)
 __global__ __launch_bounds__(256) void apply2_nk_kernel(int32_t* nk_dst, const int32_t* __restrict__ dA, int32_t* __restrict__ dB, int n, unsigned long long* negatives)
 {
@@ -341,19 +293,6 @@ __global__ __launch_bounds__(256) void apply2_nk_kernel(int32_t* nk_dst, const i
     int d = dA[i];
     if (dB) { const int d2 = dB[i]; if (d2) { d += d2; dB[i] = 0; } }
     if (d) { const int c = nk_dst[i] + d; nk_dst[i] = c; if (c < 0 && negatives) atomicAdd(negatives, 1ull); }
-}
-
-hipError_t mvhdp_launch_apply2(const MvModel& dst, const int32_t* dA, int32_t* dB, bool use_mirror, bool write_full, unsigned long long* negatives, int max_blocks, hipStream_t s)
-{
-    const int64_t nrows = dst.rowbase[dst.M];
-    const int n = dst.M * dst.K;
-    const int64_t off = nrows * dst.K;
-    hipLaunchKernelGGL(apply2_nk_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst.counts + off, dA + off, dB ? dB + off : nullptr, n, negatives);
-    if (nrows <= 0) return hipGetLastError();
-    int grid = (int)(nrows < 65536 ? nrows : 65536);
-    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
-    hipLaunchKernelGGL(apply2_trees_kernel, dim3(grid), dim3(64), (size_t)2 * dst.K * sizeof(double), s, dst, dA, dB, use_mirror, write_full, negatives);
-    return hipGetLastError();
 }
 
 // The same update without the trees (MVHDP_SWEEP_SEGMENT_OVERLAP keeps the sweep-start trees for every segment -- a deviation from the

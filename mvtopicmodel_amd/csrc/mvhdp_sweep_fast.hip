@@ -605,7 +605,6 @@ __global__ __launch_bounds__(256, (RMAX == 8 ? MVHDP_LB8 : (RMAX == 4 ? MVHDP_LB
                 }
                 const float u1f_l = (float)u1_l;                             // (may round to 1.0f: the screening then hands the token to fp64)
                 int znew_l = z_l;
-                const int nt = min(WAVE, lenm - c0);
 
                 // FT:118-132 for the whole chunk, one lane per token.  The trees do not change during a
                 // sweep and u2 belongs to the token, so the topic the tree branch WOULD return (WRK:533-535)
